@@ -1,0 +1,223 @@
+/*
+ * maniac_gpu.h -- C ABI of the MI355X (gfx950) GCMC energy engine.
+ *
+ * This is the drop-in boundary for MANIAC's per-move energy path.  The reference has no FFI:
+ * the path sits behind Fortran module procedures called from ComputeOldEnergy / ComputeNewEnergy
+ * (/root/reference/src/monte_carlo_utils.f90:275-395), the move drivers' save/restore calls and
+ * main.f90:27.  Every entry point below names the reference procedure(s) it replaces; the
+ * ISO_C_BINDING interface module a MANIAC maintainer would add is in INTEGRATION.md and
+ * maniac_mc_amd/fortran/maniac_gpu.f90.
+ *
+ * Conventions
+ *   - plain C types, caller-owned host buffers, engine-owned device buffers, no hidden globals:
+ *     any number of engines (one per GPU x force field x box) may coexist in a process;
+ *   - every function returns an int status (MGPU_OK = 0) instead of the reference's `stop`
+ *     (output_utils.f90:535-562); mgpu_last_error() holds the message of the calling thread;
+ *   - indices are 0-based (the reference is 1-based): residue type t, molecule slot m, site a;
+ *   - energies are in Kelvin (E / k_B), lengths in Angstrom, charges in e, as in the reference;
+ *   - an engine holds `n_replicas` independent configurations ("replicas": separate GCMC chains
+ *     sharing box, force field and k-vector table), so that many trial moves -- one or more per
+ *     replica -- are evaluated by one kernel launch;
+ *   - site coordinates are ABSOLUTE positions com + offset, i.e. the sum the reference forms
+ *     before every use (geometry_utils.f90:379-382, ewald_phase.f90:398-399);
+ *   - the engine fails loudly (MGPU_ERR_NO_DEVICE / MGPU_ERR_HIP) when no gfx950 device or
+ *     kernel image is available; there is no CPU fallback.
+ */
+#ifndef MANIAC_GPU_H
+#define MANIAC_GPU_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGPU_OK 0
+#define MGPU_ERR_INVALID_ARG 1
+#define MGPU_ERR_HIP 2
+#define MGPU_ERR_CAPACITY 3
+#define MGPU_ERR_NO_DEVICE 4
+#define MGPU_ERR_STATE 5
+
+/* candidate kinds for the reciprocal-space update, ewald_energy.f90:241-256 */
+#define MGPU_MOVE 0      /* A += sum q (phi_new - phi_old)   translation / rotation */
+#define MGPU_CREATION 1  /* A += sum q phi_new                insertion              */
+#define MGPU_DELETION 2  /* A -= sum q phi_old                deletion               */
+#define MGPU_NONE 3      /* A unchanged: E = sum ff W |A|^2   (ComputeOldEnergy's recip call, where
+                            the new tables equal the saved ones, monte_carlo_utils.f90:388)    */
+
+/* which kernel mgpu_profile_get() reports */
+#define MGPU_KERNEL_PAIR 0
+#define MGPU_KERNEL_RECIP 1
+#define MGPU_KERNEL_COMMIT 2
+#define MGPU_KERNEL_SFACTOR 3
+#define MGPU_KERNEL_COUNT 4
+
+typedef struct mgpu_engine mgpu_engine;
+
+/* Message of the last failing call made by this thread ("" if none). */
+const char *mgpu_last_error(void);
+
+/* Library ABI version (bumped on any signature change). */
+int mgpu_abi_version(void);
+
+/* Number of visible HIP devices; MGPU_ERR_NO_DEVICE if the runtime reports none. */
+int mgpu_device_count(int *count);
+
+/* ------------------------------------------------------------------------------------------
+ * Host-side setup arithmetic (no GPU needed).  Replaces the setup half of
+ * PrepareSimulationParameters (prepare_utils.f90:19-41) and PrepareSimulationBox
+ * (geometry_utils.f90:20-57).
+ * ---------------------------------------------------------------------------------------- */
+
+/* DetermineBoxSymmetry + ComputeCellProperties + ComputeInverse (geometry_utils.f90:68-154,
+ * :277-331).  box_matrix[i*3+j] = box%matrix(i+1,j+1); reciprocal likewise.
+ * box_type: 1 cubic, 2 orthorhombic, 3 triclinic. */
+int mgpu_box_prepare(const double box_matrix[9], int *box_type, double *volume,
+                     double reciprocal[9], double metrics[9]);
+
+/* SetupEwald (prepare_utils.f90:103-214): cutoff adjustment, tolerance clamp, alpha, kmax and the
+ * k-vector count.  rc and tol are in/out exactly as the reference mutates input%real_space_cutoff
+ * and input%ewald_tolerance. */
+int mgpu_ewald_setup(const double metrics[9], double *rc, double *tol, double *alpha,
+                     double *screening_factor, double *fourier_precision, int kmax[3],
+                     int *n_kvectors);
+
+/* PrecomputeValidReciprocalVectors (ewald_kvectors.f90:44-87) + ComputeReciprocalWeights
+ * (ewald_kvectors.f90:225-246): the half-space k list in the reference's loop order, |k|^2,
+ * form factor (1 if kx = 0 else 2) and W(k) = exp(-k^2 / 4 alpha^2) / k^2. */
+int mgpu_ewald_kvectors(const double reciprocal[9], double alpha, const int kmax[3], int n_kvectors,
+                        int *kx, int *ky, int *kz, double *k2mag, double *form_factor,
+                        double *weights);
+
+/* ------------------------------------------------------------------------------------------
+ * Engine life cycle
+ * ---------------------------------------------------------------------------------------- */
+
+/* Create an engine on HIP device `device` holding `n_replicas` configurations.
+ *   atoms_in_res[n_res]            nb%atom_in_residue            (simulation_state.f90:122)
+ *   mol_capacity[n_res]            molecule slots per replica    (reference: NB_MAX_MOLECULE)
+ *   atom_types[n_res*max_atom]     primary%atom_types(t,a), 1-based atom type ids
+ *   charges[n_res*max_atom]        primary%atom_charges(t,a)
+ *   is_active[n_res]               input%is_active
+ *   epsilon/sigma[n_types*n_types] per ATOM-TYPE pair, Kelvin / Angstrom -- the reference's 4-D
+ *                                  coeff%epsilon/sigma are functions of the two atom types only
+ *                                  (parameters_parser.f90:89-98, :141-176)
+ *   box_matrix[9], bounds_lo[3]    box%matrix (row-major image), box%bounds(:,1)
+ *   real_space_cutoff, ewald_tolerance  as read from the .maniac file; SetupEwald is applied.
+ * Triclinic boxes (box_type 3) are rejected with MGPU_ERR_INVALID_ARG in this version. */
+int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
+                       const int *atoms_in_res, const int *mol_capacity, int max_atom,
+                       const int *atom_types, const double *charges, const int *is_active,
+                       int n_types, const double *epsilon, const double *sigma,
+                       const double box_matrix[9], const double bounds_lo[3],
+                       double real_space_cutoff, double ewald_tolerance);
+int mgpu_engine_destroy(mgpu_engine *e);
+
+/* Scalars fixed at creation: what LogEwaldParameters prints (prepare_utils.f90:75-97). */
+int mgpu_engine_get_ewald(const mgpu_engine *e, double *alpha, double *real_space_cutoff,
+                          double *ewald_tolerance, int kmax[3], int *n_kvectors, double *volume,
+                          int *box_type);
+int mgpu_engine_get_kvectors(const mgpu_engine *e, int *kx, int *ky, int *kz, double *k2mag,
+                             double *form_factor, double *weights);
+
+/* ------------------------------------------------------------------------------------------
+ * Replica state (replaces the module-global primary%mol_com / site_offset / num_residues)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Load all molecules of residue type t of one replica.  sites[n_mol][atoms_in_res[t]][3]. */
+int mgpu_replica_set_molecules(mgpu_engine *e, int replica, int t, int n_mol, const double *sites);
+int mgpu_replica_get_molecules(mgpu_engine *e, int replica, int t, int *n_mol, double *sites);
+int mgpu_replica_num_molecules(const mgpu_engine *e, int replica, int t, int *n_mol);
+/* Copy a whole configuration (coordinates, counts, A(k)) from replica src to replica dst. */
+int mgpu_replica_copy(mgpu_engine *e, int dst, int src);
+
+/* ------------------------------------------------------------------------------------------
+ * Static energies
+ * ---------------------------------------------------------------------------------------- */
+
+/* ComputeSystemEnergy (energy_utils.f90:18-35).  out[6] = non_coulomb, coulomb, recip_coulomb,
+ * ewald_self, intra_coulomb, total.  Like the reference it does NOT store S(k) into A(k). */
+int mgpu_system_energy(mgpu_engine *e, int replica, double out[6]);
+
+/* The initialisation the reference omits: mode 1 sets A(k) to the full structure
+ * factor S(k) = sum_j q_j exp(i k.r_j) (ComputeRecipAmplitude, ewald_energy.f90:40-77);
+ * mode 0 zeroes it (for as-written comparisons). */
+int mgpu_init_structure_factor(mgpu_engine *e, int replica, int mode);
+/* a[n_kvectors][2] = (re, im) of ewald%recip_amplitude */
+int mgpu_get_structure_factor(mgpu_engine *e, int replica, double *a);
+int mgpu_set_structure_factor(mgpu_engine *e, int replica, const double *a);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched per-move energies.  A candidate c is (replica[c], t[c], m[c], sites[c]):
+ *   m[c] >= 0  the molecule slot being moved / deleted; it is excluded from the pair sweep
+ *              (energy_utils.f90:408-409) and its device-resident sites are the "old" state;
+ *   m[c] = -1  no such molecule (insertion into an empty slot): nothing is excluded;
+ *   sites      candidate site coordinates, [n_candidates][site_stride][3]; row c uses the first
+ *              atoms_in_res[t[c]] entries; may be NULL when no candidate needs it.
+ * None of the evaluate calls mutates engine state.
+ * ---------------------------------------------------------------------------------------- */
+
+/* ComputePairInteractionEnergy_singlemol (energy_utils.f90:374-442) for B candidates.
+ * use_resident[c] != 0: evaluate the molecule where it currently is (sites ignored). */
+int mgpu_pair_energy_candidates(mgpu_engine *e, int n_candidates, const int *replica, const int *t,
+                                const int *m, const int *use_resident, const double *sites,
+                                int site_stride, double *e_non_coulomb, double *e_coulomb);
+
+/* SingleMolFourierTerms + ComputeRecipEnergySingleMol (ewald_phase.f90:383-420,
+ * ewald_energy.f90:191-274) for B candidates, WITHOUT mutating A(k):
+ * u[c] = prefactor * sum_k ff W |A + delta_c|^2 with delta by kind[c] (MGPU_MOVE/...). */
+int mgpu_recip_energy_candidates(mgpu_engine *e, int n_candidates, const int *replica, const int *t,
+                                 const int *m, const int *kind, const double *sites,
+                                 int site_stride, double *u_recip);
+
+/* ComputeEwaldSelfInteractionSingleMol (ewald_energy.f90:308-336); configuration independent. */
+int mgpu_self_energy(const mgpu_engine *e, int t, double *e_self);
+
+/* ComputeIntraResidueRealCoulombEnergySingleMol (ewald_energy.f90:371-411) for B candidates
+ * (use_resident as above). */
+int mgpu_intra_energy_candidates(mgpu_engine *e, int n_candidates, const int *replica, const int *t,
+                                 const int *m, const int *use_resident, const double *sites,
+                                 int site_stride, double *u_intra);
+
+/* One translation / rotation trial per candidate, both halves in one call: what
+ * ComputeOldEnergy + ComputeNewEnergy compute for the default branch
+ * (monte_carlo_utils.f90:384-393, :310-318).  old_/new_ arrays are [n_candidates][3] =
+ * non_coulomb, coulomb, recip_coulomb.  Every candidate costs two pair sweeps and two k sweeps. */
+int mgpu_trial_energy_candidates(mgpu_engine *e, int n_candidates, const int *replica, const int *t,
+                                 const int *m, const double *sites, int site_stride,
+                                 double *old_energy, double *new_energy);
+
+/* Apply accepted candidates (accept[c] != 0), at most one per replica per call:
+ *   MGPU_MOVE      A += delta, slot m <- sites                     (AcceptMove keeps the mutated
+ *                  state, monte_carlo_utils.f90:410-422)
+ *   MGPU_CREATION  A += delta, new molecule appended at slot n_mol, n_mol += 1
+ *                  (create_molecule.f90:64-74)
+ *   MGPU_DELETION  A -= old, last molecule copied into slot m, n_mol -= 1
+ *                  (delete_molecule.f90:67-74, :99-116; intended physics, not defect F3)
+ * Rejected candidates need no call at all: evaluation never mutated anything, which replaces
+ * Save/RestoreSingleMolFourier (ewald_phase.f90:134-255). */
+int mgpu_commit_candidates(mgpu_engine *e, int n_candidates, const int *replica, const int *t,
+                           const int *m, const int *kind, const double *sites, int site_stride,
+                           const int *accept);
+
+/* ReplaceFourierTermsSingleMol + the coordinate copy of RemoveMolecule (ewald_phase.f90:276-322,
+ * delete_molecule.f90:99-116): slot m_dst <- slot m_src. */
+int mgpu_replica_replace_molecule(mgpu_engine *e, int replica, int t, int m_dst, int m_src);
+/* Overwrite the molecule count of a replica's residue type (no coordinates touched). */
+int mgpu_replica_set_num_molecules(mgpu_engine *e, int replica, int t, int n_mol);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement
+ * ---------------------------------------------------------------------------------------- */
+
+/* The engine launches on its own HIP stream.  Block until everything queued so far is done. */
+int mgpu_synchronize(mgpu_engine *e);
+/* When enabled, every launch of the four main kernels is bracketed by HIP events on the engine
+ * stream; mgpu_profile_get returns launches and total device milliseconds since the last reset. */
+int mgpu_profile_enable(mgpu_engine *e, int on);
+int mgpu_profile_reset(mgpu_engine *e);
+int mgpu_profile_get(mgpu_engine *e, int kernel, long long *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MANIAC_GPU_H */

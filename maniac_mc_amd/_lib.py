@@ -1,0 +1,78 @@
+"""Loader for the in-tree HIP shared library ``libmaniac_hip.so`` (C ABI: include/maniac_gpu.h).
+
+There is deliberately no fallback of any kind: if the library is missing, fails to load or
+reports no HIP device, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmaniac_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["mgpu_engine.hip", "mgpu_host_setup.cpp"]
+HEADERS = ["mgpu_kernels.h", "mgpu_internal.h", "mgpu_erfc.h"]
+
+MGPU_OK = 0
+MGPU_MOVE, MGPU_CREATION, MGPU_DELETION, MGPU_NONE = 0, 1, 2, 3
+KERNEL_PAIR, KERNEL_RECIP, KERNEL_COMMIT, KERNEL_SFACTOR = 0, 1, 2, 3
+
+# every symbol include/maniac_gpu.h declares (tests check the library exports each of them)
+EXPORTS = [
+    "mgpu_last_error", "mgpu_abi_version", "mgpu_device_count", "mgpu_box_prepare", "mgpu_ewald_setup",
+    "mgpu_ewald_kvectors", "mgpu_engine_create", "mgpu_engine_destroy", "mgpu_engine_get_ewald",
+    "mgpu_engine_get_kvectors", "mgpu_replica_set_molecules", "mgpu_replica_get_molecules",
+    "mgpu_replica_num_molecules", "mgpu_replica_copy", "mgpu_system_energy", "mgpu_init_structure_factor",
+    "mgpu_get_structure_factor", "mgpu_set_structure_factor", "mgpu_pair_energy_candidates",
+    "mgpu_recip_energy_candidates", "mgpu_self_energy", "mgpu_intra_energy_candidates",
+    "mgpu_trial_energy_candidates", "mgpu_commit_candidates", "mgpu_replica_replace_molecule",
+    "mgpu_replica_set_num_molecules", "mgpu_synchronize", "mgpu_profile_enable", "mgpu_profile_reset",
+    "mgpu_profile_get",
+]
+
+
+class MgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"maniac_gpu error {code}: {msg}")
+        self.code = code
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS if os.path.exists(os.path.join(CSRC, h))]
+    deps.append(os.path.join(_HERE, "..", "include", "maniac_gpu.h"))
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises if it is absent -- never falls back to anything else."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                               "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.mgpu_last_error.restype = C.c_char_p
+        for name in EXPORTS:
+            if name != "mgpu_last_error":
+                getattr(L, name).restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != MGPU_OK:
+        raise MgpuError(rc, lib().mgpu_last_error().decode())

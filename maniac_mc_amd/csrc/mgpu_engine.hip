@@ -1,0 +1,929 @@
+// C-ABI entry points (include/maniac_gpu.h) and host-side orchestration of the HIP kernels.
+// One mgpu_engine = one HIP device + one stream + R replicas sharing box / force field / k table.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/maniac_gpu.h"
+#include "mgpu_internal.h"
+#include "mgpu_kernels.h"
+
+namespace mgpu {
+
+static thread_local std::string g_last_error;
+
+int set_error(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t err__ = (expr);                                                                      \
+        if (err__ != hipSuccess)                                                                        \
+            return set_error(MGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(err__));       \
+    } while (0)
+
+// grow-only device / pinned-host scratch
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need) {
+        if (need <= bytes) return MGPU_OK;
+        if (p) HIP_TRY(hipFree(p));
+        p = nullptr; bytes = 0;
+        size_t cap = std::max<size_t>(need, 4096);
+        cap += cap / 2;
+        HIP_TRY(hipMalloc(&p, cap));
+        bytes = cap;
+        return MGPU_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+struct HostBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need) {
+        if (need <= bytes) return MGPU_OK;
+        if (p) HIP_TRY(hipHostFree(p));
+        p = nullptr; bytes = 0;
+        size_t cap = std::max<size_t>(need, 4096);
+        cap += cap / 2;
+        HIP_TRY(hipHostMalloc(&p, cap, hipHostMallocDefault));
+        bytes = cap;
+        return MGPU_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+};
+
+struct ProfileSlot {
+    long long launches = 0;
+    double total_ms = 0.0;
+};
+
+}  // namespace mgpu
+
+using namespace mgpu;
+
+struct mgpu_engine {
+    int device = 0;
+    int n_replicas = 0;
+    hipStream_t stream = nullptr;
+    Topo tp{};
+    BoxDev bx{};
+    // host copies
+    std::vector<int> atoms_in_res, mol_capacity, is_active, atom_types;  // atom_types 1-based [n_res][max_atom]
+    std::vector<double> charges, epsilon, sigma;
+    std::vector<int> kx, ky, kz;
+    std::vector<double> k2mag, form_factor, weights;
+    std::vector<int> h_nmol;  // [R][n_res]
+    double rc = 0, tol = 0, alpha = 0, volume = 0;
+    int box_type = 0, kmax[3] = {0, 0, 0}, nk = 0;
+    double box_matrix[9]{}, bounds_lo[3]{}, reciprocal[9]{}, metrics[9]{};
+    // device state
+    double *d_pos = nullptr;      // [R][3][Ncap]
+    int *d_nmol = nullptr;        // [R][n_res]
+    double2 *d_A = nullptr;       // [R][Nk]
+    int *d_kpack = nullptr;
+    double *d_kw = nullptr;
+    double2 *d_pair_tab = nullptr;
+    double *d_res_q = nullptr;
+    int *d_res_atype = nullptr;
+    int *d_atom_res = nullptr, *d_atom_mol = nullptr;
+    double *d_atom_q = nullptr;
+    double2 *d_phase_tab = nullptr;  // [ktot][Ncap] scratch for S(k)
+    double2 *d_S = nullptr;          // [Nk] scratch
+    // scratch
+    DevBuf d_items, d_items2, d_sites, d_partials, d_out;
+    HostBuf h_stage, h_out;
+    // profiling
+    bool profiling = false;
+    ProfileSlot prof[MGPU_KERNEL_COUNT];
+    std::vector<hipEvent_t> ev_pool;
+    struct Pending { int kernel; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+};
+
+namespace {
+
+int use_device(const mgpu_engine *e) {
+    HIP_TRY(hipSetDevice(e->device));
+    return MGPU_OK;
+}
+
+int prof_begin(mgpu_engine *e, int kernel, hipEvent_t *a, hipEvent_t *b) {
+    if (!e->profiling) return MGPU_OK;
+    for (hipEvent_t *ev : {a, b}) {
+        if (!e->ev_pool.empty()) { *ev = e->ev_pool.back(); e->ev_pool.pop_back(); }
+        else HIP_TRY(hipEventCreate(ev));
+    }
+    HIP_TRY(hipEventRecord(*a, e->stream));
+    (void)kernel;
+    return MGPU_OK;
+}
+int prof_end(mgpu_engine *e, int kernel, hipEvent_t a, hipEvent_t b) {
+    if (!e->profiling) return MGPU_OK;
+    HIP_TRY(hipEventRecord(b, e->stream));
+    e->pending.push_back({kernel, a, b});
+    return MGPU_OK;
+}
+// after a stream synchronise: fold the recorded event pairs into the per-kernel totals
+int prof_collect(mgpu_engine *e) {
+    for (auto &p : e->pending) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
+        e->prof[p.kernel].launches += 1;
+        e->prof[p.kernel].total_ms += ms;
+        e->ev_pool.push_back(p.a);
+        e->ev_pool.push_back(p.b);
+    }
+    e->pending.clear();
+    return MGPU_OK;
+}
+
+int sync_stream(mgpu_engine *e) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return prof_collect(e);
+}
+
+int check_candidate(const mgpu_engine *e, int c, int replica, int t, int m, bool need_resident) {
+    if (replica < 0 || replica >= e->n_replicas)
+        return set_error(MGPU_ERR_INVALID_ARG, "candidate " + std::to_string(c) + ": replica out of range");
+    if (t < 0 || t >= e->tp.n_res)
+        return set_error(MGPU_ERR_INVALID_ARG, "candidate " + std::to_string(c) + ": residue type out of range");
+    const int nm = e->h_nmol[replica * e->tp.n_res + t];
+    if (m >= nm || m < -1)
+        return set_error(MGPU_ERR_INVALID_ARG, "candidate " + std::to_string(c) + ": molecule slot " +
+                                                   std::to_string(m) + " not live (count " + std::to_string(nm) + ")");
+    if (need_resident && m < 0)
+        return set_error(MGPU_ERR_INVALID_ARG, "candidate " + std::to_string(c) + ": needs a resident molecule");
+    return MGPU_OK;
+}
+
+// number of 64-atom sweep units of one replica (for choosing nsplit)
+int replica_units(const mgpu_engine *e, int replica) {
+    int units = 0;
+    for (int t = 0; t < e->tp.n_res; ++t) {
+        const int nm = e->h_nmol[replica * e->tp.n_res + t], n1 = e->tp.n1[t];
+        if (e->tp.site_major[t]) units += nm * ((n1 + 63) / 64);
+        else units += n1 * ((nm + 63) / 64);
+    }
+    return units;
+}
+
+int choose_nsplit(const mgpu_engine *e, int n_items, int replica_hint) {
+    // fill the chip (256 CUs x 8 resident workgroups) without giving a wave less than one unit
+    const int units = std::max(1, replica_units(e, replica_hint));
+    const int max_split = std::max(1, units / kWavesPerBlock);
+    const int want = (2048 + n_items - 1) / std::max(1, n_items);
+    return std::max(1, std::min(want, max_split));
+}
+
+int upload_sites(mgpu_engine *e, const double *sites, int n_rows, int site_stride) {
+    if (!sites || n_rows == 0) return MGPU_OK;
+    const size_t bytes = (size_t)n_rows * site_stride * 3 * sizeof(double);
+    int rc = e->d_sites.reserve(bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(e->d_sites.p, sites, bytes, hipMemcpyHostToDevice, e->stream));
+    return MGPU_OK;
+}
+
+// launch the pair sweep + finalize for items already on the device; results land in d_lj / d_c
+int launch_pair(mgpu_engine *e, const PairItem *d_items, int n_items, int site_stride, int nsplit, double *d_lj,
+                double *d_c) {
+    int rc = e->d_partials.reserve((size_t)n_items * nsplit * sizeof(double2));
+    if (rc) return rc;
+    hipEvent_t a = nullptr, b = nullptr;
+    rc = prof_begin(e, MGPU_KERNEL_PAIR, &a, &b);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pair_sweep_kernel, dim3(n_items * nsplit), dim3(kBlock), 0, e->stream, e->tp, e->bx, e->d_pos,
+                       e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, d_items, (const double *)e->d_sites.p,
+                       site_stride, nsplit, (double2 *)e->d_partials.p);
+    rc = prof_end(e, MGPU_KERNEL_PAIR, a, b);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pair_finalize_kernel, dim3((n_items + 255) / 256), dim3(256), 0, e->stream,
+                       (const double2 *)e->d_partials.p, n_items, nsplit, d_lj, d_c);
+    HIP_TRY(hipGetLastError());
+    return MGPU_OK;
+}
+
+size_t recip_lds_bytes(const mgpu_engine *e, int n1_max) {
+    const int ktot = e->kmax[0] + e->kmax[1] + e->kmax[2] + 3;
+    return (size_t)2 * n1_max * ktot * sizeof(double2);
+}
+
+int launch_recip(mgpu_engine *e, const RecipItem *d_items, int n_items, int n1_max, int site_stride, bool commit,
+                 double2 *A_base, double *d_u) {
+    const size_t lds = recip_lds_bytes(e, n1_max);
+    if (lds > 64 * 1024)
+        return set_error(MGPU_ERR_CAPACITY, "reciprocal update: molecule too large for the LDS phase tables (" +
+                                                std::to_string(lds) + " B > 64 KiB)");
+    hipEvent_t a = nullptr, b = nullptr;
+    const int slot = commit ? MGPU_KERNEL_COMMIT : MGPU_KERNEL_RECIP;
+    int rc = prof_begin(e, slot, &a, &b);
+    if (rc) return rc;
+    if (commit)
+        hipLaunchKernelGGL(recip_kernel<true>, dim3(n_items), dim3(kBlock), lds, e->stream, e->tp, e->bx, e->d_pos,
+                           e->d_nmol, e->d_res_q, e->d_kpack, e->d_kw, A_base, d_items, (const double *)e->d_sites.p,
+                           site_stride, d_u);
+    else
+        hipLaunchKernelGGL(recip_kernel<false>, dim3(n_items), dim3(kBlock), lds, e->stream, e->tp, e->bx, e->d_pos,
+                           e->d_nmol, e->d_res_q, e->d_kpack, e->d_kw, A_base, d_items, (const double *)e->d_sites.p,
+                           site_stride, d_u);
+    rc = prof_end(e, slot, a, b);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return MGPU_OK;
+}
+
+// S(k) of one replica into dst[Nk]
+int launch_sfactor(mgpu_engine *e, int replica, double2 *dst) {
+    const int ncap = e->tp.n_cap_atoms;
+    hipEvent_t a = nullptr, b = nullptr;
+    int rc = prof_begin(e, MGPU_KERNEL_SFACTOR, &a, &b);
+    if (rc) return rc;
+    hipLaunchKernelGGL(phase_table_kernel, dim3((ncap + 255) / 256), dim3(256), 0, e->stream, e->tp, e->bx, e->d_pos,
+                       e->d_nmol, e->d_atom_res, e->d_atom_mol, replica, e->d_phase_tab);
+    hipLaunchKernelGGL(sfactor_kernel, dim3(e->nk), dim3(kBlock), 0, e->stream, e->tp, e->bx, e->d_nmol, e->d_atom_res,
+                       e->d_atom_mol, e->d_atom_q, e->d_kpack, replica, e->d_phase_tab, dst);
+    rc = prof_end(e, MGPU_KERNEL_SFACTOR, a, b);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return MGPU_OK;
+}
+
+double self_energy_host(const mgpu_engine *e, int t) {
+    // ComputeEwaldSelfInteractionSingleMol, ewald_energy.f90:308-336
+    double s = 0.0;
+    const double sqrtpi = std::sqrt(kPi);
+    for (int a = 0; a < e->tp.n1[t]; ++a) {
+        const double q = e->charges[(size_t)t * e->tp.max_atom + a];
+        if (std::fabs(q) < kErrorTol) continue;
+        s = s - e->alpha / sqrtpi * (q * q);
+    }
+    return s * kEps0InvEvA / kKbEvK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mgpu_last_error(void) { return g_last_error.c_str(); }
+
+int mgpu_abi_version(void) { return 1; }
+
+int mgpu_device_count(int *count) {
+    if (!count) return set_error(MGPU_ERR_INVALID_ARG, "mgpu_device_count: null argument");
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess || n <= 0) {
+        *count = 0;
+        return set_error(MGPU_ERR_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(err));
+    }
+    *count = n;
+    return MGPU_OK;
+}
+
+int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res, const int *atoms_in_res,
+                       const int *mol_capacity, int max_atom, const int *atom_types, const double *charges,
+                       const int *is_active, int n_types, const double *epsilon, const double *sigma,
+                       const double box_matrix[9], const double bounds_lo[3], double real_space_cutoff,
+                       double ewald_tolerance) {
+    if (!out || !atoms_in_res || !mol_capacity || !atom_types || !charges || !is_active || !epsilon || !sigma ||
+        !box_matrix || !bounds_lo)
+        return set_error(MGPU_ERR_INVALID_ARG, "mgpu_engine_create: null argument");
+    *out = nullptr;
+    if (n_replicas < 1) return set_error(MGPU_ERR_INVALID_ARG, "mgpu_engine_create: n_replicas < 1");
+    if (n_res < 1 || n_res > kMaxRes)
+        return set_error(MGPU_ERR_INVALID_ARG, "mgpu_engine_create: n_res must be in [1, " + std::to_string(kMaxRes) + "]");
+    if (n_types < 1 || n_types > kMaxTypes)
+        return set_error(MGPU_ERR_INVALID_ARG, "mgpu_engine_create: n_types must be in [1, " + std::to_string(kMaxTypes) + "]");
+    if (max_atom < 1) return set_error(MGPU_ERR_INVALID_ARG, "mgpu_engine_create: max_atom < 1");
+    for (int t = 0; t < n_res; ++t) {
+        if (atoms_in_res[t] < 1 || atoms_in_res[t] > max_atom || mol_capacity[t] < 1)
+            return set_error(MGPU_ERR_INVALID_ARG, "mgpu_engine_create: bad atoms_in_res / mol_capacity");
+        for (int a = 0; a < atoms_in_res[t]; ++a) {
+            const int ty = atom_types[t * max_atom + a];
+            if (ty < 1 || ty > n_types) return set_error(MGPU_ERR_INVALID_ARG, "mgpu_engine_create: atom type out of range");
+        }
+    }
+    int ndev = 0;
+    int rc = mgpu_device_count(&ndev);
+    if (rc) return rc;
+    if (device < 0 || device >= ndev) return set_error(MGPU_ERR_NO_DEVICE, "mgpu_engine_create: device ordinal out of range");
+
+    auto *e = new mgpu_engine();
+    e->device = device;
+    e->n_replicas = n_replicas;
+    std::memcpy(e->box_matrix, box_matrix, sizeof(double) * 9);
+    std::memcpy(e->bounds_lo, bounds_lo, sizeof(double) * 3);
+    rc = box_prepare(box_matrix, &e->box_type, &e->volume, e->reciprocal, e->metrics);
+    if (rc) { delete e; return rc; }
+    if (e->box_type == 3) {
+        delete e;
+        return set_error(MGPU_ERR_INVALID_ARG, "mgpu_engine_create: triclinic boxes are not supported by this version");
+    }
+    e->rc = real_space_cutoff;
+    e->tol = ewald_tolerance;
+    double screening, fprec;
+    rc = ewald_setup(e->metrics, &e->rc, &e->tol, &e->alpha, &screening, &fprec, e->kmax, &e->nk);
+    if (rc) { delete e; return rc; }
+    if (e->kmax[0] > 127 || e->kmax[1] > 127 || e->kmax[2] > 127) {
+        delete e;
+        return set_error(MGPU_ERR_CAPACITY, "mgpu_engine_create: kmax > 127 does not fit the packed k table");
+    }
+    e->kx.resize(e->nk); e->ky.resize(e->nk); e->kz.resize(e->nk);
+    e->k2mag.resize(e->nk); e->form_factor.resize(e->nk); e->weights.resize(e->nk);
+    rc = ewald_kvectors(e->reciprocal, e->alpha, e->kmax, e->nk, e->kx.data(), e->ky.data(), e->kz.data(),
+                        e->k2mag.data(), e->form_factor.data(), e->weights.data());
+    if (rc) { delete e; return rc; }
+
+    e->atoms_in_res.assign(atoms_in_res, atoms_in_res + n_res);
+    e->mol_capacity.assign(mol_capacity, mol_capacity + n_res);
+    e->is_active.assign(is_active, is_active + n_res);
+    e->atom_types.assign(atom_types, atom_types + (size_t)n_res * max_atom);
+    e->charges.assign(charges, charges + (size_t)n_res * max_atom);
+    e->epsilon.assign(epsilon, epsilon + (size_t)n_types * n_types);
+    e->sigma.assign(sigma, sigma + (size_t)n_types * n_types);
+    e->h_nmol.assign((size_t)n_replicas * n_res, 0);
+
+    Topo &tp = e->tp;
+    tp.n_res = n_res; tp.n_types = n_types; tp.max_atom = max_atom;
+    int off = 0;
+    for (int t = 0; t < n_res; ++t) {
+        tp.n1[t] = atoms_in_res[t];
+        tp.cap[t] = mol_capacity[t];
+        tp.seg_off[t] = off;
+        tp.site_major[t] = atoms_in_res[t] >= 64 ? 1 : 0;
+        off += atoms_in_res[t] * mol_capacity[t];
+    }
+    tp.n_cap_atoms = off;
+
+    BoxDev &bx = e->bx;
+    for (int d = 0; d < 3; ++d) { bx.L[d] = box_matrix[d * 3 + d]; bx.invL[d] = 1.0 / bx.L[d]; bx.kmax[d] = e->kmax[d]; }
+    std::memcpy(bx.rcp, e->reciprocal, sizeof(double) * 9);
+    bx.rc2 = e->rc * e->rc;
+    bx.alpha = e->alpha;
+    bx.volume = e->volume;
+    bx.nk = e->nk;
+
+    // host images of the device tables
+    std::vector<int> kpack(e->nk);
+    std::vector<double> kw(e->nk);
+    for (int i = 0; i < e->nk; ++i) {
+        kpack[i] = e->kx[i] | ((e->ky[i] + 128) << 8) | ((e->kz[i] + 128) << 16);
+        kw[i] = e->form_factor[i] * e->weights[i];  // ewald_energy.f90:266, (ff * W) * |A|^2
+    }
+    std::vector<double2> ptab((size_t)n_types * n_types);
+    for (int i = 0; i < n_types * n_types; ++i) ptab[i] = make_double2(4.0 * epsilon[i], sigma[i] * sigma[i]);
+    std::vector<int> atype0((size_t)n_res * max_atom, 0);
+    for (int t = 0; t < n_res; ++t)
+        for (int a = 0; a < atoms_in_res[t]; ++a) atype0[(size_t)t * max_atom + a] = atom_types[(size_t)t * max_atom + a] - 1;
+    std::vector<int> a_res(tp.n_cap_atoms), a_mol(tp.n_cap_atoms);
+    std::vector<double> a_q(tp.n_cap_atoms);
+    for (int t = 0; t < n_res; ++t)
+        for (int m = 0; m < tp.cap[t]; ++m)
+            for (int a = 0; a < tp.n1[t]; ++a) {
+                const int j = tp.site_major[t] ? tp.seg_off[t] + m * tp.n1[t] + a : tp.seg_off[t] + a * tp.cap[t] + m;
+                a_res[j] = t; a_mol[j] = m; a_q[j] = charges[(size_t)t * max_atom + a];
+            }
+
+    auto fail = [&](int code) { mgpu_engine_destroy(e); return code; };
+#define HIP_TRY_E(expr)                                                                                          \
+    do {                                                                                                         \
+        hipError_t err__ = (expr);                                                                               \
+        if (err__ != hipSuccess)                                                                                 \
+            return fail(set_error(MGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(err__)));          \
+    } while (0)
+    HIP_TRY_E(hipSetDevice(device));
+    HIP_TRY_E(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    const size_t ncap = tp.n_cap_atoms, R = n_replicas;
+    const int ktot = e->kmax[0] + e->kmax[1] + e->kmax[2] + 3;
+    HIP_TRY_E(hipMalloc(&e->d_pos, R * 3 * ncap * sizeof(double)));
+    HIP_TRY_E(hipMemset(e->d_pos, 0, R * 3 * ncap * sizeof(double)));
+    HIP_TRY_E(hipMalloc(&e->d_nmol, R * n_res * sizeof(int)));
+    HIP_TRY_E(hipMemset(e->d_nmol, 0, R * n_res * sizeof(int)));
+    HIP_TRY_E(hipMalloc(&e->d_A, R * e->nk * sizeof(double2)));
+    HIP_TRY_E(hipMemset(e->d_A, 0, R * e->nk * sizeof(double2)));
+    HIP_TRY_E(hipMalloc(&e->d_kpack, e->nk * sizeof(int)));
+    HIP_TRY_E(hipMalloc(&e->d_kw, e->nk * sizeof(double)));
+    HIP_TRY_E(hipMalloc(&e->d_pair_tab, ptab.size() * sizeof(double2)));
+    HIP_TRY_E(hipMalloc(&e->d_res_q, e->charges.size() * sizeof(double)));
+    HIP_TRY_E(hipMalloc(&e->d_res_atype, atype0.size() * sizeof(int)));
+    HIP_TRY_E(hipMalloc(&e->d_atom_res, ncap * sizeof(int)));
+    HIP_TRY_E(hipMalloc(&e->d_atom_mol, ncap * sizeof(int)));
+    HIP_TRY_E(hipMalloc(&e->d_atom_q, ncap * sizeof(double)));
+    HIP_TRY_E(hipMalloc(&e->d_phase_tab, (size_t)ktot * ncap * sizeof(double2)));
+    HIP_TRY_E(hipMalloc(&e->d_S, e->nk * sizeof(double2)));
+    HIP_TRY_E(hipMemcpy(e->d_kpack, kpack.data(), e->nk * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY_E(hipMemcpy(e->d_kw, kw.data(), e->nk * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY_E(hipMemcpy(e->d_pair_tab, ptab.data(), ptab.size() * sizeof(double2), hipMemcpyHostToDevice));
+    HIP_TRY_E(hipMemcpy(e->d_res_q, e->charges.data(), e->charges.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY_E(hipMemcpy(e->d_res_atype, atype0.data(), atype0.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY_E(hipMemcpy(e->d_atom_res, a_res.data(), ncap * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY_E(hipMemcpy(e->d_atom_mol, a_mol.data(), ncap * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY_E(hipMemcpy(e->d_atom_q, a_q.data(), ncap * sizeof(double), hipMemcpyHostToDevice));
+#undef HIP_TRY_E
+    *out = e;
+    return MGPU_OK;
+}
+
+int mgpu_engine_destroy(mgpu_engine *e) {
+    if (!e) return MGPU_OK;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (void *p : {(void *)e->d_pos, (void *)e->d_nmol, (void *)e->d_A, (void *)e->d_kpack, (void *)e->d_kw,
+                    (void *)e->d_pair_tab, (void *)e->d_res_q, (void *)e->d_res_atype, (void *)e->d_atom_res,
+                    (void *)e->d_atom_mol, (void *)e->d_atom_q, (void *)e->d_phase_tab, (void *)e->d_S})
+        if (p) (void)hipFree(p);
+    e->d_items.release(); e->d_items2.release(); e->d_sites.release(); e->d_partials.release(); e->d_out.release();
+    e->h_stage.release(); e->h_out.release();
+    for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return MGPU_OK;
+}
+
+int mgpu_engine_get_ewald(const mgpu_engine *e, double *alpha, double *rc, double *tol, int kmax[3], int *nk,
+                          double *volume, int *box_type) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    if (alpha) *alpha = e->alpha;
+    if (rc) *rc = e->rc;
+    if (tol) *tol = e->tol;
+    if (kmax) { kmax[0] = e->kmax[0]; kmax[1] = e->kmax[1]; kmax[2] = e->kmax[2]; }
+    if (nk) *nk = e->nk;
+    if (volume) *volume = e->volume;
+    if (box_type) *box_type = e->box_type;
+    return MGPU_OK;
+}
+
+int mgpu_engine_get_kvectors(const mgpu_engine *e, int *kx, int *ky, int *kz, double *k2mag, double *ff, double *w) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    if (kx) std::memcpy(kx, e->kx.data(), e->nk * sizeof(int));
+    if (ky) std::memcpy(ky, e->ky.data(), e->nk * sizeof(int));
+    if (kz) std::memcpy(kz, e->kz.data(), e->nk * sizeof(int));
+    if (k2mag) std::memcpy(k2mag, e->k2mag.data(), e->nk * sizeof(double));
+    if (ff) std::memcpy(ff, e->form_factor.data(), e->nk * sizeof(double));
+    if (w) std::memcpy(w, e->weights.data(), e->nk * sizeof(double));
+    return MGPU_OK;
+}
+
+// ---- replica state ---------------------------------------------------------------------------
+
+static int check_replica_t(const mgpu_engine *e, int replica, int t) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    if (replica < 0 || replica >= e->n_replicas) return set_error(MGPU_ERR_INVALID_ARG, "replica out of range");
+    if (t < 0 || t >= e->tp.n_res) return set_error(MGPU_ERR_INVALID_ARG, "residue type out of range");
+    return MGPU_OK;
+}
+
+int mgpu_replica_set_molecules(mgpu_engine *e, int replica, int t, int n_mol, const double *sites) {
+    int rc = check_replica_t(e, replica, t);
+    if (rc) return rc;
+    if (n_mol < 0 || n_mol > e->tp.cap[t]) return set_error(MGPU_ERR_CAPACITY, "n_mol exceeds the residue type's mol_capacity");
+    if (n_mol > 0 && !sites) return set_error(MGPU_ERR_INVALID_ARG, "null sites");
+    if ((rc = use_device(e))) return rc;
+    const Topo &tp = e->tp;
+    const int n1 = tp.n1[t], cap = tp.cap[t];
+    const size_t seg = (size_t)n1 * cap;
+    rc = e->h_stage.reserve(3 * seg * sizeof(double));
+    if (rc) return rc;
+    double *st = (double *)e->h_stage.p;
+    std::memset(st, 0, 3 * seg * sizeof(double));
+    for (int m = 0; m < n_mol; ++m)
+        for (int a = 0; a < n1; ++a) {
+            const size_t j = tp.site_major[t] ? (size_t)m * n1 + a : (size_t)a * cap + m;
+            for (int d = 0; d < 3; ++d) st[d * seg + j] = sites[((size_t)m * n1 + a) * 3 + d];
+        }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int d = 0; d < 3; ++d)
+        HIP_TRY(hipMemcpy(e->d_pos + ((size_t)replica * 3 + d) * tp.n_cap_atoms + tp.seg_off[t], st + d * seg,
+                          seg * sizeof(double), hipMemcpyHostToDevice));
+    e->h_nmol[replica * tp.n_res + t] = n_mol;
+    HIP_TRY(hipMemcpy(e->d_nmol + replica * tp.n_res + t, &n_mol, sizeof(int), hipMemcpyHostToDevice));
+    return MGPU_OK;
+}
+
+int mgpu_replica_get_molecules(mgpu_engine *e, int replica, int t, int *n_mol, double *sites) {
+    int rc = check_replica_t(e, replica, t);
+    if (rc) return rc;
+    if ((rc = use_device(e))) return rc;
+    const Topo &tp = e->tp;
+    const int n1 = tp.n1[t], cap = tp.cap[t], nm = e->h_nmol[replica * tp.n_res + t];
+    if (n_mol) *n_mol = nm;
+    if (!sites || nm == 0) return MGPU_OK;
+    const size_t seg = (size_t)n1 * cap;
+    rc = e->h_stage.reserve(3 * seg * sizeof(double));
+    if (rc) return rc;
+    double *st = (double *)e->h_stage.p;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int d = 0; d < 3; ++d)
+        HIP_TRY(hipMemcpy(st + d * seg, e->d_pos + ((size_t)replica * 3 + d) * tp.n_cap_atoms + tp.seg_off[t],
+                          seg * sizeof(double), hipMemcpyDeviceToHost));
+    for (int m = 0; m < nm; ++m)
+        for (int a = 0; a < n1; ++a) {
+            const size_t j = tp.site_major[t] ? (size_t)m * n1 + a : (size_t)a * cap + m;
+            for (int d = 0; d < 3; ++d) sites[((size_t)m * n1 + a) * 3 + d] = st[d * seg + j];
+        }
+    return MGPU_OK;
+}
+
+int mgpu_replica_num_molecules(const mgpu_engine *e, int replica, int t, int *n_mol) {
+    int rc = check_replica_t(e, replica, t);
+    if (rc) return rc;
+    if (!n_mol) return set_error(MGPU_ERR_INVALID_ARG, "null n_mol");
+    *n_mol = e->h_nmol[replica * e->tp.n_res + t];
+    return MGPU_OK;
+}
+
+int mgpu_replica_set_num_molecules(mgpu_engine *e, int replica, int t, int n_mol) {
+    int rc = check_replica_t(e, replica, t);
+    if (rc) return rc;
+    if (n_mol < 0 || n_mol > e->tp.cap[t]) return set_error(MGPU_ERR_CAPACITY, "n_mol exceeds mol_capacity");
+    if ((rc = use_device(e))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->h_nmol[replica * e->tp.n_res + t] = n_mol;
+    HIP_TRY(hipMemcpy(e->d_nmol + replica * e->tp.n_res + t, &n_mol, sizeof(int), hipMemcpyHostToDevice));
+    return MGPU_OK;
+}
+
+int mgpu_replica_copy(mgpu_engine *e, int dst, int src) {
+    int rc = check_replica_t(e, dst, 0);
+    if (rc) return rc;
+    if ((rc = check_replica_t(e, src, 0))) return rc;
+    if (dst == src) return MGPU_OK;
+    if ((rc = use_device(e))) return rc;
+    const Topo &tp = e->tp;
+    HIP_TRY(hipMemcpyAsync(e->d_pos + (size_t)dst * 3 * tp.n_cap_atoms, e->d_pos + (size_t)src * 3 * tp.n_cap_atoms,
+                           (size_t)3 * tp.n_cap_atoms * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_nmol + dst * tp.n_res, e->d_nmol + src * tp.n_res, tp.n_res * sizeof(int),
+                           hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_A + (size_t)dst * e->nk, e->d_A + (size_t)src * e->nk, e->nk * sizeof(double2),
+                           hipMemcpyDeviceToDevice, e->stream));
+    for (int t = 0; t < tp.n_res; ++t) e->h_nmol[dst * tp.n_res + t] = e->h_nmol[src * tp.n_res + t];
+    return sync_stream(e);
+}
+
+int mgpu_replica_replace_molecule(mgpu_engine *e, int replica, int t, int m_dst, int m_src) {
+    int rc = check_replica_t(e, replica, t);
+    if (rc) return rc;
+    const Topo &tp = e->tp;
+    if (m_dst < 0 || m_src < 0 || m_dst >= tp.cap[t] || m_src >= tp.cap[t])
+        return set_error(MGPU_ERR_INVALID_ARG, "molecule slot out of range");
+    if (m_dst == m_src) return MGPU_OK;
+    if ((rc = use_device(e))) return rc;
+    const int n1 = tp.n1[t];
+    for (int d = 0; d < 3; ++d) {
+        double *base = e->d_pos + ((size_t)replica * 3 + d) * tp.n_cap_atoms + tp.seg_off[t];
+        if (tp.site_major[t]) {
+            HIP_TRY(hipMemcpyAsync(base + (size_t)m_dst * n1, base + (size_t)m_src * n1, n1 * sizeof(double),
+                                   hipMemcpyDeviceToDevice, e->stream));
+        } else {
+            HIP_TRY(hipMemcpy2DAsync(base + m_dst, tp.cap[t] * sizeof(double), base + m_src, tp.cap[t] * sizeof(double),
+                                     sizeof(double), n1, hipMemcpyDeviceToDevice, e->stream));
+        }
+    }
+    return sync_stream(e);
+}
+
+// ---- structure factor ------------------------------------------------------------------------
+
+int mgpu_init_structure_factor(mgpu_engine *e, int replica, int mode) {
+    int rc = check_replica_t(e, replica, 0);
+    if (rc) return rc;
+    if ((rc = use_device(e))) return rc;
+    double2 *A = e->d_A + (size_t)replica * e->nk;
+    if (mode == 0) {
+        HIP_TRY(hipMemsetAsync(A, 0, e->nk * sizeof(double2), e->stream));
+    } else {
+        if ((rc = launch_sfactor(e, replica, A))) return rc;
+    }
+    return sync_stream(e);
+}
+
+int mgpu_get_structure_factor(mgpu_engine *e, int replica, double *a) {
+    int rc = check_replica_t(e, replica, 0);
+    if (rc) return rc;
+    if (!a) return set_error(MGPU_ERR_INVALID_ARG, "null buffer");
+    if ((rc = use_device(e))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(a, e->d_A + (size_t)replica * e->nk, e->nk * sizeof(double2), hipMemcpyDeviceToHost));
+    return MGPU_OK;
+}
+
+int mgpu_set_structure_factor(mgpu_engine *e, int replica, const double *a) {
+    int rc = check_replica_t(e, replica, 0);
+    if (rc) return rc;
+    if (!a) return set_error(MGPU_ERR_INVALID_ARG, "null buffer");
+    if ((rc = use_device(e))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->d_A + (size_t)replica * e->nk, a, e->nk * sizeof(double2), hipMemcpyHostToDevice));
+    return MGPU_OK;
+}
+
+// ---- batched candidates ----------------------------------------------------------------------
+
+int mgpu_pair_energy_candidates(mgpu_engine *e, int n, const int *replica, const int *t, const int *m,
+                                const int *use_resident, const double *sites, int site_stride, double *e_nc,
+                                double *e_c) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    if (n == 0) return MGPU_OK;
+    if (n < 0 || !replica || !t || !m || !e_nc || !e_c) return set_error(MGPU_ERR_INVALID_ARG, "pair_energy_candidates: bad argument");
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::vector<PairItem> items(n);
+    bool any_sites = false;
+    for (int c = 0; c < n; ++c) {
+        const bool res = use_resident && use_resident[c];
+        if ((rc = check_candidate(e, c, replica[c], t[c], m[c], res))) return rc;
+        if (!res) {
+            any_sites = true;
+            if (e->tp.n1[t[c]] > site_stride) return set_error(MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res");
+        }
+        items[c] = PairItem{replica[c], t[c], m[c], res ? -1 : c, 0};
+    }
+    if (any_sites && !sites) return set_error(MGPU_ERR_INVALID_ARG, "pair_energy_candidates: sites is null");
+    if ((rc = e->d_items.reserve(n * sizeof(PairItem)))) return rc;
+    if ((rc = e->d_out.reserve((size_t)2 * n * sizeof(double)))) return rc;
+    if ((rc = e->h_out.reserve((size_t)2 * n * sizeof(double)))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->d_items.p, items.data(), n * sizeof(PairItem), hipMemcpyHostToDevice, e->stream));
+    if (any_sites && (rc = upload_sites(e, sites, n, site_stride))) return rc;
+    double *d_lj = (double *)e->d_out.p, *d_c = d_lj + n;
+    const int nsplit = choose_nsplit(e, n, replica[0]);
+    if ((rc = launch_pair(e, (const PairItem *)e->d_items.p, n, site_stride, nsplit, d_lj, d_c))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_out.p, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if ((rc = sync_stream(e))) return rc;
+    std::memcpy(e_nc, e->h_out.p, n * sizeof(double));
+    std::memcpy(e_c, (double *)e->h_out.p + n, n * sizeof(double));
+    return MGPU_OK;
+}
+
+int mgpu_recip_energy_candidates(mgpu_engine *e, int n, const int *replica, const int *t, const int *m, const int *kind,
+                                 const double *sites, int site_stride, double *u) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    if (n == 0) return MGPU_OK;
+    if (n < 0 || !replica || !t || !m || !kind || !u) return set_error(MGPU_ERR_INVALID_ARG, "recip_energy_candidates: bad argument");
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::vector<RecipItem> items(n);
+    bool any_sites = false;
+    int n1_max = 1;
+    for (int c = 0; c < n; ++c) {
+        if (kind[c] < MGPU_MOVE || kind[c] > MGPU_NONE) return set_error(MGPU_ERR_INVALID_ARG, "unknown candidate kind");
+        const bool need_old = (kind[c] == MGPU_MOVE || kind[c] == MGPU_DELETION);
+        const bool need_new = (kind[c] == MGPU_MOVE || kind[c] == MGPU_CREATION);
+        if ((rc = check_candidate(e, c, replica[c], t[c], m[c], need_old))) return rc;
+        if (need_new) {
+            any_sites = true;
+            if (e->tp.n1[t[c]] > site_stride) return set_error(MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res");
+        }
+        n1_max = std::max(n1_max, e->tp.n1[t[c]]);
+        items[c] = RecipItem{replica[c], t[c], m[c], kind[c], need_new ? c : -1, 0};
+    }
+    if (any_sites && !sites) return set_error(MGPU_ERR_INVALID_ARG, "recip_energy_candidates: sites is null");
+    if ((rc = e->d_items2.reserve(n * sizeof(RecipItem)))) return rc;
+    if ((rc = e->d_out.reserve((size_t)n * sizeof(double)))) return rc;
+    if ((rc = e->h_out.reserve((size_t)n * sizeof(double)))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->d_items2.p, items.data(), n * sizeof(RecipItem), hipMemcpyHostToDevice, e->stream));
+    if (any_sites && (rc = upload_sites(e, sites, n, site_stride))) return rc;
+    if ((rc = launch_recip(e, (const RecipItem *)e->d_items2.p, n, n1_max, site_stride, false, e->d_A, (double *)e->d_out.p)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if ((rc = sync_stream(e))) return rc;
+    std::memcpy(u, e->h_out.p, n * sizeof(double));
+    return MGPU_OK;
+}
+
+int mgpu_self_energy(const mgpu_engine *e, int t, double *e_self) {
+    if (!e || !e_self) return set_error(MGPU_ERR_INVALID_ARG, "mgpu_self_energy: null argument");
+    if (t < 0 || t >= e->tp.n_res) return set_error(MGPU_ERR_INVALID_ARG, "residue type out of range");
+    *e_self = self_energy_host(e, t);
+    return MGPU_OK;
+}
+
+int mgpu_intra_energy_candidates(mgpu_engine *e, int n, const int *replica, const int *t, const int *m,
+                                 const int *use_resident, const double *sites, int site_stride, double *u) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    if (n == 0) return MGPU_OK;
+    if (n < 0 || !replica || !t || !m || !u) return set_error(MGPU_ERR_INVALID_ARG, "intra_energy_candidates: bad argument");
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::vector<PairItem> items(n);
+    bool any_sites = false;
+    for (int c = 0; c < n; ++c) {
+        const bool res = use_resident && use_resident[c];
+        if ((rc = check_candidate(e, c, replica[c], t[c], m[c], res))) return rc;
+        if (!res) {
+            any_sites = true;
+            if (e->tp.n1[t[c]] > site_stride) return set_error(MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res");
+        }
+        items[c] = PairItem{replica[c], t[c], m[c], res ? -1 : c, 0};
+    }
+    if (any_sites && !sites) return set_error(MGPU_ERR_INVALID_ARG, "intra_energy_candidates: sites is null");
+    if ((rc = e->d_items.reserve(n * sizeof(PairItem)))) return rc;
+    if ((rc = e->d_out.reserve((size_t)n * sizeof(double)))) return rc;
+    if ((rc = e->h_out.reserve((size_t)n * sizeof(double)))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->d_items.p, items.data(), n * sizeof(PairItem), hipMemcpyHostToDevice, e->stream));
+    if (any_sites && (rc = upload_sites(e, sites, n, site_stride))) return rc;
+    hipLaunchKernelGGL(intra_kernel, dim3((n + 63) / 64), dim3(64), 0, e->stream, e->tp, e->bx, e->d_pos, e->d_res_q,
+                       (const PairItem *)e->d_items.p, n, (const double *)e->d_sites.p, site_stride, (double *)e->d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if ((rc = sync_stream(e))) return rc;
+    std::memcpy(u, e->h_out.p, n * sizeof(double));
+    return MGPU_OK;
+}
+
+int mgpu_trial_energy_candidates(mgpu_engine *e, int n, const int *replica, const int *t, const int *m,
+                                 const double *sites, int site_stride, double *old_energy, double *new_energy) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    if (n == 0) return MGPU_OK;
+    if (n < 0 || !replica || !t || !m || !sites || !old_energy || !new_energy)
+        return set_error(MGPU_ERR_INVALID_ARG, "trial_energy_candidates: bad argument");
+    int rc = use_device(e);
+    if (rc) return rc;
+    // items [0, n): old state (resident sites, A unchanged); items [n, 2n): new state
+    std::vector<PairItem> pit(2 * (size_t)n);
+    std::vector<RecipItem> rit(2 * (size_t)n);
+    int n1_max = 1;
+    for (int c = 0; c < n; ++c) {
+        if ((rc = check_candidate(e, c, replica[c], t[c], m[c], true))) return rc;
+        if (e->tp.n1[t[c]] > site_stride) return set_error(MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res");
+        n1_max = std::max(n1_max, e->tp.n1[t[c]]);
+        pit[c] = PairItem{replica[c], t[c], m[c], -1, 0};
+        pit[n + c] = PairItem{replica[c], t[c], m[c], c, 0};
+        rit[c] = RecipItem{replica[c], t[c], m[c], MGPU_NONE, -1, 0};
+        rit[n + c] = RecipItem{replica[c], t[c], m[c], MGPU_MOVE, c, 0};
+    }
+    const size_t n2 = 2 * (size_t)n;
+    if ((rc = e->d_items.reserve(n2 * sizeof(PairItem)))) return rc;
+    if ((rc = e->d_items2.reserve(n2 * sizeof(RecipItem)))) return rc;
+    if ((rc = e->d_out.reserve(3 * n2 * sizeof(double)))) return rc;
+    if ((rc = e->h_out.reserve(3 * n2 * sizeof(double)))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->d_items.p, pit.data(), n2 * sizeof(PairItem), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_items2.p, rit.data(), n2 * sizeof(RecipItem), hipMemcpyHostToDevice, e->stream));
+    if ((rc = upload_sites(e, sites, n, site_stride))) return rc;
+    double *d_lj = (double *)e->d_out.p, *d_c = d_lj + n2, *d_u = d_c + n2;
+    const int nsplit = choose_nsplit(e, (int)n2, replica[0]);
+    if ((rc = launch_pair(e, (const PairItem *)e->d_items.p, (int)n2, site_stride, nsplit, d_lj, d_c))) return rc;
+    if ((rc = launch_recip(e, (const RecipItem *)e->d_items2.p, (int)n2, n1_max, site_stride, false, e->d_A, d_u))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_out.p, 3 * n2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if ((rc = sync_stream(e))) return rc;
+    const double *h = (const double *)e->h_out.p;
+    for (int c = 0; c < n; ++c) {
+        old_energy[3 * c + 0] = h[c];          old_energy[3 * c + 1] = h[n2 + c];     old_energy[3 * c + 2] = h[2 * n2 + c];
+        new_energy[3 * c + 0] = h[n + c];      new_energy[3 * c + 1] = h[n2 + n + c]; new_energy[3 * c + 2] = h[2 * n2 + n + c];
+    }
+    return MGPU_OK;
+}
+
+int mgpu_commit_candidates(mgpu_engine *e, int n, const int *replica, const int *t, const int *m, const int *kind,
+                           const double *sites, int site_stride, const int *accept) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    if (n == 0) return MGPU_OK;
+    if (n < 0 || !replica || !t || !m || !kind || !accept) return set_error(MGPU_ERR_INVALID_ARG, "commit_candidates: bad argument");
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::vector<RecipItem> items;
+    std::vector<char> seen(e->n_replicas, 0);
+    std::vector<int> new_counts;  // (index into h_nmol, value) pairs applied after validation
+    bool any_sites = false;
+    int n1_max = 1;
+    for (int c = 0; c < n; ++c) {
+        if (!accept[c]) continue;
+        if (kind[c] < MGPU_MOVE || kind[c] > MGPU_DELETION) return set_error(MGPU_ERR_INVALID_ARG, "commit: unknown candidate kind");
+        if (replica[c] < 0 || replica[c] >= e->n_replicas) return set_error(MGPU_ERR_INVALID_ARG, "commit: replica out of range");
+        if (seen[replica[c]]) return set_error(MGPU_ERR_INVALID_ARG, "commit: more than one accepted candidate for a replica");
+        seen[replica[c]] = 1;
+        if (t[c] < 0 || t[c] >= e->tp.n_res) return set_error(MGPU_ERR_INVALID_ARG, "commit: residue type out of range");
+        const int idx = replica[c] * e->tp.n_res + t[c], nm = e->h_nmol[idx];
+        RecipItem it{replica[c], t[c], m[c], kind[c], -1, nm};
+        if (kind[c] == MGPU_CREATION) {
+            if (nm >= e->tp.cap[t[c]]) return set_error(MGPU_ERR_CAPACITY, "commit: residue type is at mol_capacity");
+            it.m = nm;  // appended at the first free slot, create_molecule.f90:64 / monte_carlo.f90 (num_residues + 1)
+            it.aux = nm + 1;
+        } else {
+            if ((rc = check_candidate(e, c, replica[c], t[c], m[c], true))) return rc;
+            if (kind[c] == MGPU_DELETION) it.aux = nm - 1;
+        }
+        if (kind[c] != MGPU_DELETION) {
+            any_sites = true;
+            it.src = c;
+            if (e->tp.n1[t[c]] > site_stride) return set_error(MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res");
+        }
+        n1_max = std::max(n1_max, e->tp.n1[t[c]]);
+        if (kind[c] != MGPU_MOVE) { new_counts.push_back(idx); new_counts.push_back(it.aux); }
+        items.push_back(it);
+    }
+    if (items.empty()) return MGPU_OK;
+    if (any_sites && !sites) return set_error(MGPU_ERR_INVALID_ARG, "commit_candidates: sites is null");
+    if ((rc = e->d_items2.reserve(items.size() * sizeof(RecipItem)))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->d_items2.p, items.data(), items.size() * sizeof(RecipItem), hipMemcpyHostToDevice, e->stream));
+    if (any_sites && (rc = upload_sites(e, sites, n, site_stride))) return rc;
+    if ((rc = launch_recip(e, (const RecipItem *)e->d_items2.p, (int)items.size(), n1_max, site_stride, true, e->d_A, nullptr)))
+        return rc;
+    if ((rc = sync_stream(e))) return rc;
+    for (size_t i = 0; i < new_counts.size(); i += 2) e->h_nmol[new_counts[i]] = new_counts[i + 1];
+    return MGPU_OK;
+}
+
+// ---- static energy ---------------------------------------------------------------------------
+
+int mgpu_system_energy(mgpu_engine *e, int replica, double out[6]) {
+    int rc = check_replica_t(e, replica, 0);
+    if (rc) return rc;
+    if (!out) return set_error(MGPU_ERR_INVALID_ARG, "null out");
+    if ((rc = use_device(e))) return rc;
+    const Topo &tp = e->tp;
+    // ComputePairwiseEnergy (energy_utils.f90:83-115): one ordered item per molecule, results
+    // accumulated on the host in the reference's (type, molecule) order.
+    std::vector<PairItem> items;
+    for (int t = 0; t < tp.n_res; ++t)
+        for (int m = 0; m < e->h_nmol[replica * tp.n_res + t]; ++m) items.push_back(PairItem{replica, t, m, -1, 1});
+    const int n = (int)items.size();
+    double e_nc = 0.0, e_c = 0.0, e_intra = 0.0, e_recip = 0.0;
+    std::vector<double> h_lj(n), h_c(n), h_intra(n);
+    if ((rc = e->d_out.reserve(((size_t)3 * n + 1) * sizeof(double)))) return rc;
+    if (n > 0) {
+        if ((rc = e->d_items.reserve(n * sizeof(PairItem)))) return rc;
+        HIP_TRY(hipMemcpyAsync(e->d_items.p, items.data(), n * sizeof(PairItem), hipMemcpyHostToDevice, e->stream));
+        double *d_lj = (double *)e->d_out.p, *d_c = d_lj + n, *d_in = d_c + n;
+        const int nsplit = choose_nsplit(e, n, replica);
+        if ((rc = launch_pair(e, (const PairItem *)e->d_items.p, n, 1, nsplit, d_lj, d_c))) return rc;
+        hipLaunchKernelGGL(intra_kernel, dim3((n + 63) / 64), dim3(64), 0, e->stream, e->tp, e->bx, e->d_pos, e->d_res_q,
+                           (const PairItem *)e->d_items.p, n, (const double *)nullptr, 1, d_in);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_lj.data(), d_lj, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(h_c.data(), d_c, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(h_intra.data(), d_in, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    }
+    // ComputeEwaldRecip (energy_utils.f90:270-286): S(k) into scratch, then sum ff W |S|^2
+    if ((rc = launch_sfactor(e, replica, e->d_S))) return rc;
+    RecipItem rit{0, 0, -1, MGPU_NONE, -1, 0};
+    if ((rc = e->d_items2.reserve(sizeof(RecipItem)))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->d_items2.p, &rit, sizeof(RecipItem), hipMemcpyHostToDevice, e->stream));
+    double *d_u = (double *)e->d_out.p + (size_t)3 * n;
+    if ((rc = launch_recip(e, (const RecipItem *)e->d_items2.p, 1, 1, 1, false, e->d_S, d_u))) return rc;
+    HIP_TRY(hipMemcpyAsync(&e_recip, d_u, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if ((rc = sync_stream(e))) return rc;
+    int i = 0;
+    for (int t = 0; t < tp.n_res; ++t)
+        for (int m = 0; m < e->h_nmol[replica * tp.n_res + t]; ++m, ++i) {
+            e_nc = e_nc + h_lj[i];
+            e_c = e_c + h_c[i];
+            // ComputeTotalIntraResidueCoulombEnergy (energy_utils.f90:55-81): active types only
+            if (e->is_active[t] == 1) e_intra = e_intra + h_intra[i];
+        }
+    // ComputeEwaldSelf (energy_utils.f90:307-330)
+    double e_self = 0.0;
+    for (int t = 0; t < tp.n_res; ++t) {
+        double s = self_energy_host(e, t);
+        s = s * (double)e->h_nmol[replica * tp.n_res + t];
+        e_self = e_self + s;
+    }
+    out[0] = e_nc; out[1] = e_c; out[2] = e_recip; out[3] = e_self; out[4] = e_intra;
+    out[5] = e_recip + e_nc + e_c + e_self + e_intra;  // energy_utils.f90:32-33
+    return MGPU_OK;
+}
+
+// ---- measurement -----------------------------------------------------------------------------
+
+int mgpu_synchronize(mgpu_engine *e) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    int rc = use_device(e);
+    if (rc) return rc;
+    return sync_stream(e);
+}
+
+int mgpu_profile_enable(mgpu_engine *e, int on) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    int rc = mgpu_synchronize(e);
+    if (rc) return rc;
+    e->profiling = on != 0;
+    return MGPU_OK;
+}
+
+int mgpu_profile_reset(mgpu_engine *e) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    int rc = mgpu_synchronize(e);
+    if (rc) return rc;
+    for (auto &p : e->prof) p = ProfileSlot{};
+    return MGPU_OK;
+}
+
+int mgpu_profile_get(mgpu_engine *e, int kernel, long long *launches, double *total_ms) {
+    if (!e || kernel < 0 || kernel >= MGPU_KERNEL_COUNT) return set_error(MGPU_ERR_INVALID_ARG, "profile_get: bad argument");
+    int rc = mgpu_synchronize(e);
+    if (rc) return rc;
+    if (launches) *launches = e->prof[kernel].launches;
+    if (total_ms) *total_ms = e->prof[kernel].total_ms;
+    return MGPU_OK;
+}
+
+}  // extern "C"

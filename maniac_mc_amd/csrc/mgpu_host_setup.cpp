@@ -1,0 +1,144 @@
+// Host-side setup arithmetic of the energy engine: box products, Ewald parameters and the
+// half-space k-vector table.  Pure C++ (no HIP), so it also builds with g++ for CPU tests.
+//
+// Replaces, for the hot path only, the setup half of the reference:
+//   PrepareSimulationBox      /root/reference/src/geometry_utils.f90:20-57
+//   SetupEwald                /root/reference/src/prepare_utils.f90:103-214
+//   PrecomputeValidReciprocalVectors / ComputeReciprocalWeights
+//                             /root/reference/src/ewald_kvectors.f90:44-87, :225-246
+// The arithmetic keeps the reference's association order so that alpha, kmax, Nk, |k|^2 and
+// W(k) come out identical to the Fortran on the same inputs (checked in tests/).
+#include <cmath>
+#include <cstring>
+
+#include "../../include/maniac_gpu.h"
+#include "mgpu_internal.h"
+
+namespace mgpu {
+
+static inline void cross3(const double a[3], const double b[3], double c[3]) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+static inline double dot3(const double a[3], const double b[3]) {
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+
+int box_prepare(const double m[9], int *box_type, double *volume, double rcp[9], double metrics[9]) {
+    if (!m || !box_type || !volume || !rcp || !metrics) return set_error(MGPU_ERR_INVALID_ARG, "box_prepare: null argument");
+    // box symmetry, geometry_utils.f90:68-94
+    const double od[6] = {m[1], m[2], m[3], m[5], m[6], m[7]};
+    double mx = 0.0;
+    for (double v : od) mx = std::fmax(mx, std::fabs(v));
+    if (mx > kErrorTol) *box_type = 3;
+    else if (std::fabs(m[0] - m[4]) > kErrorTol || std::fabs(m[0] - m[8]) > kErrorTol) *box_type = 2;
+    else *box_type = 1;
+    // cell properties, geometry_utils.f90:110-154 (cell vectors are the COLUMNS of the matrix)
+    double a[3] = {m[0], m[3], m[6]}, b[3] = {m[1], m[4], m[7]}, c[3] = {m[2], m[5], m[8]};
+    double axb[3], bxc[3], cxa[3];
+    metrics[0] = std::sqrt(dot3(a, a));
+    metrics[1] = std::sqrt(dot3(b, b));
+    metrics[2] = std::sqrt(dot3(c, c));
+    metrics[3] = dot3(a, b) / (metrics[0] * metrics[1]);
+    metrics[4] = dot3(a, c) / (metrics[0] * metrics[2]);
+    metrics[5] = dot3(b, c) / (metrics[1] * metrics[2]);
+    cross3(a, b, axb);
+    cross3(b, c, bxc);
+    cross3(c, a, cxa);
+    *volume = std::fabs(dot3(a, bxc));
+    metrics[6] = *volume / std::sqrt(dot3(bxc, bxc));
+    metrics[7] = *volume / std::sqrt(dot3(cxa, cxa));
+    metrics[8] = *volume / std::sqrt(dot3(axb, axb));
+    // "reciprocal", geometry_utils.f90:277-331: adjugate columns b x c, c x a, a x b over det
+    double adj[3][3];
+    for (int i = 0; i < 3; ++i) { adj[i][0] = bxc[i]; adj[i][1] = cxa[i]; adj[i][2] = axb[i]; }
+    const double det = a[0] * adj[0][0] + a[1] * adj[1][0] + a[2] * adj[2][0];
+    if (std::fabs(det) < 1.0) return set_error(MGPU_ERR_INVALID_ARG, "box_prepare: |det(box)| < 1 (reference aborts, geometry_utils.f90:310)");
+    const double r = 1.0 / det;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) rcp[i * 3 + j] = r * adj[i][j];
+    return MGPU_OK;
+}
+
+static inline double normalized_k2(int kx, int ky, int kz, const int kmax[3]) {
+    const double x = double(kx) / double(kmax[0]), y = double(ky) / double(kmax[1]), z = double(kz) / double(kmax[2]);
+    return x * x + y * y + z * z;
+}
+static inline bool valid_k(double k2) { return std::fabs(k2) >= kErrorTol && k2 <= 1.0; }
+
+int ewald_setup(const double metrics[9], double *rc, double *tol, double *alpha, double *screening,
+                double *fourier_precision, int kmax[3], int *nk) {
+    if (!metrics || !rc || !tol || !alpha || !screening || !fourier_precision || !kmax || !nk)
+        return set_error(MGPU_ERR_INVALID_ARG, "ewald_setup: null argument");
+    if (!(*rc > 0.0)) return set_error(MGPU_ERR_INVALID_ARG, "ewald_setup: real_space_cutoff must be positive");
+    // AdjustRealSpaceCutoff, prepare_utils.f90:134-151
+    if (*rc > metrics[0] || *rc > metrics[1] || *rc > metrics[2])
+        *rc = std::fmin(metrics[0], std::fmin(metrics[1], metrics[2])) / 2.0;
+    // ClampTolerance, prepare_utils.f90:157-160
+    *tol = std::fmin(std::fabs(*tol), 0.5);
+    // ComputeEwaldParameters, prepare_utils.f90:169-180
+    *screening = std::sqrt(std::fabs(std::log(*tol * *rc)));
+    *alpha = std::sqrt(std::fabs(std::log(*tol * *rc * *screening))) / *rc;
+    const double t = 2.0 * *screening * *alpha;
+    *fourier_precision = std::sqrt(-std::log(*tol * *rc * (t * t)));
+    // ComputeFourierIndices, prepare_utils.f90:187-214 (nint = round half away from zero)
+    for (int d = 0; d < 3; ++d) kmax[d] = int(std::lround(0.25 + metrics[d] * *alpha * *fourier_precision / kPi));
+    if (kmax[0] < 1 || kmax[1] < 1 || kmax[2] < 1) return set_error(MGPU_ERR_INVALID_ARG, "ewald_setup: kmax < 1");
+    int count = 0;
+    for (int kx = 0; kx <= kmax[0]; ++kx)
+        for (int ky = -kmax[1]; ky <= kmax[1]; ++ky)
+            for (int kz = -kmax[2]; kz <= kmax[2]; ++kz) {
+                if (kx == 0 && ky == 0 && kz == 0) continue;
+                if (valid_k(normalized_k2(kx, ky, kz, kmax))) ++count;
+            }
+    *nk = count;
+    return MGPU_OK;
+}
+
+int ewald_kvectors(const double rcp[9], double alpha, const int kmax[3], int nk, int *kx_o, int *ky_o,
+                   int *kz_o, double *k2mag, double *ff, double *w) {
+    if (!rcp || !kmax || !kx_o || !ky_o || !kz_o || !k2mag || !ff || !w)
+        return set_error(MGPU_ERR_INVALID_ARG, "ewald_kvectors: null argument");
+    double km[9];
+    for (int i = 0; i < 9; ++i) km[i] = kTwoPi * rcp[i];
+    int c = 0;
+    for (int kx = 0; kx <= kmax[0]; ++kx)
+        for (int ky = -kmax[1]; ky <= kmax[1]; ++ky)
+            for (int kz = -kmax[2]; kz <= kmax[2]; ++kz) {
+                if (kx == 0 && ky == 0 && kz == 0) continue;
+                if (!valid_k(normalized_k2(kx, ky, kz, kmax))) continue;
+                if (c >= nk) return set_error(MGPU_ERR_INVALID_ARG, "ewald_kvectors: n_kvectors too small");
+                double kv[3];
+                for (int i = 0; i < 3; ++i)
+                    kv[i] = double(kx) * km[i * 3 + 0] + double(ky) * km[i * 3 + 1] + double(kz) * km[i * 3 + 2];
+                kx_o[c] = kx; ky_o[c] = ky; kz_o[c] = kz;
+                k2mag[c] = dot3(kv, kv);
+                ff[c] = (kx == 0) ? 1.0 : 2.0;  // ComputeSymmetryFormFactor, ewald_kvectors.f90:167-180
+                ++c;
+            }
+    if (c != nk) return set_error(MGPU_ERR_INVALID_ARG, "ewald_kvectors: n_kvectors does not match the k list");
+    const double a2 = alpha * alpha;
+    for (int i = 0; i < nk; ++i) w[i] = std::exp(-k2mag[i] / (4.0 * a2)) / k2mag[i];
+    return MGPU_OK;
+}
+
+}  // namespace mgpu
+
+extern "C" {
+
+int mgpu_box_prepare(const double box_matrix[9], int *box_type, double *volume, double reciprocal[9], double metrics[9]) {
+    return mgpu::box_prepare(box_matrix, box_type, volume, reciprocal, metrics);
+}
+
+int mgpu_ewald_setup(const double metrics[9], double *rc, double *tol, double *alpha, double *screening_factor,
+                     double *fourier_precision, int kmax[3], int *n_kvectors) {
+    return mgpu::ewald_setup(metrics, rc, tol, alpha, screening_factor, fourier_precision, kmax, n_kvectors);
+}
+
+int mgpu_ewald_kvectors(const double reciprocal[9], double alpha, const int kmax[3], int n_kvectors, int *kx, int *ky,
+                        int *kz, double *k2mag, double *form_factor, double *weights) {
+    return mgpu::ewald_kvectors(reciprocal, alpha, kmax, n_kvectors, kx, ky, kz, k2mag, form_factor, weights);
+}
+
+}  // extern "C"

@@ -1,0 +1,27 @@
+// Internal declarations shared by the host-setup and engine translation units.
+#ifndef MGPU_INTERNAL_H
+#define MGPU_INTERNAL_H
+
+#include <string>
+
+namespace mgpu {
+
+// /root/reference/src/constants.f90:7-20 -- same decimal literals, so bit-identical doubles
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kTwoPi = 2.0 * kPi;
+constexpr double kEps0InvEvA = 14.40198;
+constexpr double kKbEvK = 8.6173852e-5;
+constexpr double kErrorTol = 1.0e-10;
+
+// records `msg` as the calling thread's last error and returns `code`
+int set_error(int code, const std::string &msg);
+
+int box_prepare(const double m[9], int *box_type, double *volume, double rcp[9], double metrics[9]);
+int ewald_setup(const double metrics[9], double *rc, double *tol, double *alpha, double *screening,
+                double *fourier_precision, int kmax[3], int *nk);
+int ewald_kvectors(const double rcp[9], double alpha, const int kmax[3], int nk, int *kx, int *ky, int *kz,
+                   double *k2mag, double *ff, double *w);
+
+}  // namespace mgpu
+
+#endif

@@ -1,0 +1,464 @@
+// HIP kernels of the GCMC energy engine, written for gfx950 (CDNA4, wave64) only.
+//
+// Data layout in HBM (per engine; R replicas):
+//   pos      [R][3][Ncap]   fp64   x / y / z planes of every replica's atom slots
+//   nmol     [R][n_res]     int32  live molecule count per residue type
+//   A        [R][Nk]        fp64x2 ewald%recip_amplitude of every replica
+//   kpack    [Nk]           int32  kx | (ky+128)<<8 | (kz+128)<<16
+//   kw       [Nk]           fp64   form_factor(k) * W(k)
+//   pair_tab [nt][nt]       fp64x2 {4 epsilon, sigma^2} per atom-type pair
+//   res_q / res_atype [n_res][max_atom]   site templates (charge, 0-based atom type)
+// Atom slot index inside a replica, residue type t with n1 sites and `cap` molecule slots:
+//   plane-major (many small molecules):  seg_off[t] + a * cap + m   -> a wave sweeps 64 molecules of
+//                                        ONE site index, so charge / atom type / LJ pair are
+//                                        wave-uniform and whole LJ or Coulomb halves are skipped
+//                                        by a scalar branch (SPC/E: LJ for 1 of 9 site pairs);
+//   site-major  (n1 >= 64, frameworks):  seg_off[t] + m * n1 + a     -> a wave sweeps 64 sites of
+//                                        one molecule, per-lane charge / type.
+// All arithmetic is IEEE fp64.  Reductions use a fixed tree (wave butterfly -> LDS -> ordered
+// sum over waves -> ordered sum over splits): results are bitwise reproducible run to run.
+#ifndef MGPU_KERNELS_H
+#define MGPU_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+#include "mgpu_internal.h"
+
+namespace mgpu {
+
+constexpr int kMaxRes = 8;        // residue types per engine
+constexpr int kBlock = 256;       // threads per workgroup = 4 waves, one per SIMD
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kSiteChunk = 64;    // candidate sites staged in LDS per pass
+constexpr int kMaxTypes = 16;     // atom types (LDS pair table 16 x 16 x 16 B = 4 KiB)
+
+struct Topo {
+    int n_res;
+    int n_types;
+    int n_cap_atoms;              // atom slots per replica
+    int max_atom;
+    int n1[kMaxRes];              // nb%atom_in_residue
+    int cap[kMaxRes];             // molecule slots
+    int seg_off[kMaxRes];         // first atom slot of the residue type
+    int site_major[kMaxRes];
+};
+
+struct BoxDev {
+    double L[3], invL[3];         // orthorhombic edge lengths box%matrix(d,d)
+    double rcp[9];                // box%reciprocal, row-major
+    double rc2;                   // real_space_cutoff^2
+    double alpha;
+    double volume;
+    int kmax[3];
+    int nk;
+};
+
+struct PairItem {
+    int replica, t, m;            // m < 0: nothing excluded
+    int src;                      // < 0: sites are the resident slot m; else row of cand_sites
+    int ordered;                  // 1: SingleMolPairwiseEnergy semantics (energy_utils.f90:153-158)
+};
+
+struct RecipItem {
+    int replica, t, m, kind;
+    int src;                      // row of cand_sites holding the new sites (< 0: none)
+    int aux;                      // commit: new molecule count of (replica, t) after the move
+};
+
+__device__ __forceinline__ int atom_slot(const Topo &tp, int t, int m, int a) {
+    return tp.site_major[t] ? tp.seg_off[t] + m * tp.n1[t] + a : tp.seg_off[t] + a * tp.cap[t] + m;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Minimum-image separation for cubic / orthorhombic boxes.  The reference folds with
+// modulo(d + L/2, L) - L/2 (geometry_utils.f90:388-391); d - L*rint(d/L) returns the same
+// image (|d'| <= L/2) and differs only in the last bits of d'.
+__device__ __forceinline__ double min_image(double d, double L, double invL) {
+    return fma(-L, rint(d * invL), d);
+}
+
+// One site-atom pair: Lennard-Jones inside the cutoff (energy_utils.f90:417-424) and
+// erfc(alpha r)/r for every distance (energy_utils.f90:427-432).
+__device__ __forceinline__ void pair_term(double dx, double dy, double dz, const BoxDev &bx, double qq,
+                                          double eps4, double sig2, bool do_lj, bool do_c, bool guard_r0,
+                                          double &elj, double &ec) {
+    dx = min_image(dx, bx.L[0], bx.invL[0]);
+    dy = min_image(dy, bx.L[1], bx.invL[1]);
+    dz = min_image(dz, bx.L[2], bx.invL[2]);
+    const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
+    const double rinv = rsqrt(r2);
+    if (do_lj && r2 < bx.rc2) {
+        const double s2 = sig2 * (rinv * rinv);
+        const double s6 = s2 * s2 * s2;
+        elj += eps4 * fma(s6, s6, -s6);
+    }
+    if (do_c) {
+        const double r = r2 * rinv;
+        double term = qq * (erfc(bx.alpha * r) * rinv);
+        if (guard_r0 && r < kErrorTol) term = 0.0;  // CoulombEnergy, energy_utils.f90:244
+        ec += term;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pair sweep: ComputePairInteractionEnergy_singlemol (energy_utils.f90:374-442) and, with
+// item.ordered, SingleMolPairwiseEnergy (energy_utils.f90:121-187) for a batch of items.
+// grid = n_items * nsplit workgroups; workgroup (item, split) sweeps every nsplit-th unit of
+// 64 atoms of the item's replica and writes one partial {e_lj, e_coul}.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void pair_sweep_kernel(
+    Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
+    const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
+    const PairItem *__restrict__ items, const double *__restrict__ cand_sites, int site_stride, int nsplit,
+    double2 *__restrict__ partials) {
+    __shared__ double s_x[kSiteChunk], s_y[kSiteChunk], s_z[kSiteChunk], s_q[kSiteChunk];
+    __shared__ int s_ty[kSiteChunk];
+    __shared__ double2 s_pair[kMaxTypes * kMaxTypes];
+    __shared__ double s_red[2 * kWavesPerBlock];
+
+    const int item_id = blockIdx.x / nsplit, split = blockIdx.x - item_id * nsplit;
+    const PairItem it = items[item_id];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gw = split * kWavesPerBlock + wave, gstride = nsplit * kWavesPerBlock;
+    const int nt = tp.n_types;
+    const double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
+    const double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
+    const int *nm_r = nmol + it.replica * tp.n_res;
+    const int n1 = tp.n1[it.t];
+    const bool ordered = it.ordered != 0;
+
+    for (int i = threadIdx.x; i < nt * nt; i += kBlock) s_pair[i] = pair_tab[i];
+
+    double elj = 0.0, ec = 0.0;
+    for (int sb = 0; sb < n1; sb += kSiteChunk) {
+        const int ns = min(kSiteChunk, n1 - sb);
+        __syncthreads();
+        if (threadIdx.x < ns) {
+            const int a = sb + threadIdx.x;
+            if (it.src < 0) {
+                const int j = atom_slot(tp, it.t, it.m, a);
+                s_x[threadIdx.x] = px[j]; s_y[threadIdx.x] = py[j]; s_z[threadIdx.x] = pz[j];
+            } else {
+                const double *c = cand_sites + ((size_t)it.src * site_stride + a) * 3;
+                s_x[threadIdx.x] = c[0]; s_y[threadIdx.x] = c[1]; s_z[threadIdx.x] = c[2];
+            }
+            s_q[threadIdx.x] = res_q[it.t * tp.max_atom + a];
+            s_ty[threadIdx.x] = res_atype[it.t * tp.max_atom + a];
+        }
+        __syncthreads();
+
+        for (int t2 = 0; t2 < tp.n_res; ++t2) {
+            if (ordered && t2 < it.t) continue;
+            const int nm = nm_r[t2], n2 = tp.n1[t2];
+            if (nm == 0) continue;
+            const bool same_t = (t2 == it.t) && (it.m >= 0);
+            if (!tp.site_major[t2]) {
+                // plane-major: unit = (site index a2, 64 consecutive molecules)
+                const int cpp = (nm + 63) >> 6, units = n2 * cpp;
+                for (int u = gw; u < units; u += gstride) {
+                    const int a2 = u / cpp, m2 = (u - a2 * cpp) * 64 + lane;
+                    bool valid = m2 < nm;
+                    if (same_t) valid = valid && (ordered ? (m2 > it.m) : (m2 != it.m));
+                    const double qj = res_q[t2 * tp.max_atom + a2];
+                    const int tyj = res_atype[t2 * tp.max_atom + a2];
+                    const bool qj_on = fabs(qj) >= kErrorTol;
+                    double xj = 0.0, yj = 0.0, zj = 0.0;
+                    if (valid) {
+                        const int j = tp.seg_off[t2] + a2 * tp.cap[t2] + m2;
+                        xj = px[j]; yj = py[j]; zj = pz[j];
+                    }
+                    for (int s = 0; s < ns; ++s) {
+                        const double qs = s_q[s];
+                        const double2 pt = s_pair[s_ty[s] * nt + tyj];
+                        const bool do_c = qj_on && (fabs(qs) >= kErrorTol);   // energy_utils.f90:430
+                        const bool do_lj = pt.x != 0.0;                        // epsilon = 0 contributes 0
+                        if (!(do_c || do_lj)) continue;                       // wave-uniform
+                        if (valid)
+                            pair_term(xj - s_x[s], yj - s_y[s], zj - s_z[s], bx, qs * qj, pt.x, pt.y, do_lj, do_c,
+                                      ordered, elj, ec);
+                    }
+                }
+            } else {
+                // site-major: unit = (molecule m2, 64 consecutive sites)
+                const int cpp = (n2 + 63) >> 6, units = nm * cpp;
+                for (int u = gw; u < units; u += gstride) {
+                    const int m2 = u / cpp, a2 = (u - m2 * cpp) * 64 + lane;
+                    if (same_t && (ordered ? (m2 <= it.m) : (m2 == it.m))) continue;
+                    if (a2 >= n2) continue;
+                    const int j = tp.seg_off[t2] + m2 * n2 + a2;
+                    const double xj = px[j], yj = py[j], zj = pz[j];
+                    const double qj = res_q[t2 * tp.max_atom + a2];
+                    const int tyj = res_atype[t2 * tp.max_atom + a2];
+                    const bool qj_on = fabs(qj) >= kErrorTol;
+                    for (int s = 0; s < ns; ++s) {
+                        const double qs = s_q[s];
+                        const double2 pt = s_pair[s_ty[s] * nt + tyj];
+                        const bool do_c = qj_on && (fabs(qs) >= kErrorTol);
+                        pair_term(xj - s_x[s], yj - s_y[s], zj - s_z[s], bx, qs * qj, pt.x, pt.y, pt.x != 0.0, do_c,
+                                  ordered, elj, ec);
+                    }
+                }
+            }
+        }
+    }
+    elj = wave_sum(elj);
+    ec = wave_sum(ec);
+    if (lane == 0) { s_red[2 * wave] = elj; s_red[2 * wave + 1] = ec; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < kWavesPerBlock; ++w) { a += s_red[2 * w]; b += s_red[2 * w + 1]; }
+        partials[blockIdx.x] = make_double2(a, b);
+    }
+}
+
+// Ordered sum of the split partials; Coulomb rescale e_coulomb * EPS0_INV_eVA / KB_eVK
+// (energy_utils.f90:440).
+__global__ void pair_finalize_kernel(const double2 *__restrict__ partials, int n_items, int nsplit,
+                                     double *__restrict__ e_lj, double *__restrict__ e_coul) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < nsplit; ++s) { const double2 p = partials[(size_t)i * nsplit + s]; a += p.x; b += p.y; }
+    e_lj[i] = a;
+    e_coul[i] = b * kEps0InvEvA / kKbEvK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Reciprocal-space update.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x));
+}
+
+// theta = 2 pi * reciprocal^T r (ComputeAtomPhase, ewald_phase.f90:41-64)
+__device__ __forceinline__ double atom_phase(const BoxDev &bx, int axis, double x, double y, double z) {
+    double acc = 0.0;
+    acc = acc + bx.rcp[0 * 3 + axis] * x;
+    acc = acc + bx.rcp[1 * 3 + axis] * y;
+    acc = acc + bx.rcp[2 * 3 + axis] * z;
+    return kTwoPi * acc;
+}
+
+// exp(i k theta) by direct cos / sin of k*theta, as ComputePhaseFactors1D does (ewald_phase.f90:100-109)
+__device__ __forceinline__ double2 phase_entry(double theta, int k) {
+    double s, c;
+    sincos((double)k * theta, &s, &c);
+    return make_double2(c, s);
+}
+
+// SingleMolFourierTerms + ComputeRecipEnergySingleMol (ewald_phase.f90:383-420,
+// ewald_energy.f90:191-274) for one item per workgroup.
+// COMMIT = false: u[item] = prefactor * sum_k ff W |A + delta|^2, A untouched.
+// COMMIT = true : A <- A + delta, then the replica's coordinates / molecule count are updated.
+// Dynamic LDS: two table sets (new, old) of n1 * ktot complex entries,
+// ktot = (kmax_x + 1) + (kmax_y + 1) + (kmax_z + 1); entry (a, axis, k >= 0).
+template <bool COMMIT>
+__global__ __launch_bounds__(kBlock) void recip_kernel(
+    Topo tp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
+    const int *__restrict__ kpack, const double *__restrict__ kw, double2 *__restrict__ A_base,
+    const RecipItem *__restrict__ items, const double *__restrict__ cand_sites, int site_stride,
+    double *__restrict__ u_out) {
+    extern __shared__ double2 s_tab[];
+    __shared__ double s_red[kWavesPerBlock];
+
+    const RecipItem it = items[blockIdx.x];
+    const int n1 = tp.n1[it.t];
+    const int kofs[3] = {0, bx.kmax[0] + 1, bx.kmax[0] + bx.kmax[1] + 2};
+    const int ktot = bx.kmax[0] + bx.kmax[1] + bx.kmax[2] + 3;
+    double2 *tab_new = s_tab, *tab_old = s_tab + n1 * ktot;
+    double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
+    double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
+    const bool use_new = (it.kind == 0 /*MOVE*/ || it.kind == 1 /*CREATION*/);
+    const bool use_old = (it.kind == 0 /*MOVE*/ || it.kind == 2 /*DELETION*/);
+
+    for (int e = threadIdx.x; e < 2 * n1 * ktot; e += kBlock) {
+        const int set = e / (n1 * ktot), r = e - set * n1 * ktot;
+        const int a = r / ktot, kk = r - a * ktot;
+        const int axis = (kk >= kofs[2]) ? 2 : (kk >= kofs[1] ? 1 : 0);
+        const int k = kk - kofs[axis];
+        if ((set == 0 && !use_new) || (set == 1 && !use_old)) continue;
+        double x, y, z;
+        if (set == 0) {
+            const double *c = cand_sites + ((size_t)it.src * site_stride + a) * 3;
+            x = c[0]; y = c[1]; z = c[2];
+        } else {
+            const int j = atom_slot(tp, it.t, it.m, a);
+            x = px[j]; y = py[j]; z = pz[j];
+        }
+        s_tab[e] = phase_entry(atom_phase(bx, axis, x, y, z), k);
+    }
+    __syncthreads();
+
+    double2 *A = A_base + (size_t)it.replica * bx.nk;
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < bx.nk; k += kBlock) {
+        const int kp = kpack[k];
+        const int kx = kp & 0xff, ky = ((kp >> 8) & 0xff) - 128, kz = ((kp >> 16) & 0xff) - 128;
+        const int aky = ky < 0 ? -ky : ky, akz = kz < 0 ? -kz : kz;
+        double dre = 0.0, dim = 0.0;
+        for (int a = 0; a < n1; ++a) {
+            const double q = res_q[it.t * tp.max_atom + a];
+            double2 pn = make_double2(0.0, 0.0), po = make_double2(0.0, 0.0);
+            if (use_new) {
+                const double2 *t = tab_new + a * ktot;
+                double2 Y = t[kofs[1] + aky], Z = t[kofs[2] + akz];
+                if (ky < 0) Y.y = -Y.y;
+                if (kz < 0) Z.y = -Z.y;
+                pn = cmul(cmul(t[kx], Y), Z);
+            }
+            if (use_old) {
+                const double2 *t = tab_old + a * ktot;
+                double2 Y = t[kofs[1] + aky], Z = t[kofs[2] + akz];
+                if (ky < 0) Y.y = -Y.y;
+                if (kz < 0) Z.y = -Z.y;
+                po = cmul(cmul(t[kx], Y), Z);
+            }
+            // ewald_energy.f90:241-256
+            dre += q * (pn.x - po.x);
+            dim += q * (pn.y - po.y);
+        }
+        double2 Ak = A[k];
+        Ak.x += dre;
+        Ak.y += dim;
+        if (COMMIT) A[k] = Ak;
+        else acc += kw[k] * fma(Ak.x, Ak.x, Ak.y * Ak.y);   // ewald_energy.f90:259-266
+    }
+
+    if (!COMMIT) {
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double u = 0.0;
+            for (int w = 0; w < kWavesPerBlock; ++w) u += s_red[w];
+            u_out[blockIdx.x] = u * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;   // ewald_energy.f90:272
+        }
+    } else {
+        // every read of the old coordinates happened before the barrier above
+        if (it.kind == 0 || it.kind == 1) {
+            if (threadIdx.x < n1) {
+                const double *c = cand_sites + ((size_t)it.src * site_stride + threadIdx.x) * 3;
+                const int j = atom_slot(tp, it.t, it.m, threadIdx.x);
+                px[j] = c[0]; py[j] = c[1]; pz[j] = c[2];
+            }
+        } else if (it.kind == 2) {
+            // swap-with-last, delete_molecule.f90:107-114: slot m <- slot (new count)
+            const int last = it.aux;
+            if (threadIdx.x < n1 && last != it.m) {
+                const int j = atom_slot(tp, it.t, it.m, threadIdx.x), jl = atom_slot(tp, it.t, last, threadIdx.x);
+                px[j] = px[jl]; py[j] = py[jl]; pz[j] = pz[jl];
+            }
+        }
+        if (threadIdx.x == 0 && it.kind != 0) nmol[it.replica * tp.n_res + it.t] = it.aux;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Full structure factor S(k) (ComputeAllFourierTerms + ComputeRecipAmplitude,
+// ewald_phase.f90:340-360, ewald_energy.f90:40-77).
+// Step 1: per-atom 1-D phase tables, tab[axis][k][slot]; dead slots are skipped.
+// ------------------------------------------------------------------------------------------
+__global__ void phase_table_kernel(Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
+                                   const int *__restrict__ atom_res, const int *__restrict__ atom_mol, int replica,
+                                   double2 *__restrict__ tab) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= tp.n_cap_atoms) return;
+    const int t = atom_res[j];
+    if (atom_mol[j] >= nmol[replica * tp.n_res + t]) return;
+    const double *px = pos + (size_t)replica * 3 * tp.n_cap_atoms;
+    const double x = px[j], y = px[tp.n_cap_atoms + j], z = px[2 * tp.n_cap_atoms + j];
+    int row = 0;
+    for (int axis = 0; axis < 3; ++axis) {
+        const double th = atom_phase(bx, axis, x, y, z);
+        for (int k = 0; k <= bx.kmax[axis]; ++k, ++row) tab[(size_t)row * tp.n_cap_atoms + j] = phase_entry(th, k);
+    }
+}
+
+// Step 2: one workgroup per k-vector sums q_j X_j(kx) Y_j(ky) Z_j(kz) over the live atoms.
+__global__ __launch_bounds__(kBlock) void sfactor_kernel(Topo tp, BoxDev bx, const int *__restrict__ nmol,
+                                                         const int *__restrict__ atom_res,
+                                                         const int *__restrict__ atom_mol,
+                                                         const double *__restrict__ atom_q,
+                                                         const int *__restrict__ kpack, int replica,
+                                                         const double2 *__restrict__ tab, double2 *__restrict__ S) {
+    __shared__ double s_red[2 * kWavesPerBlock];
+    const int k = blockIdx.x;
+    const int kp = kpack[k];
+    const int kx = kp & 0xff, ky = ((kp >> 8) & 0xff) - 128, kz = ((kp >> 16) & 0xff) - 128;
+    const int aky = ky < 0 ? -ky : ky, akz = kz < 0 ? -kz : kz;
+    const size_t nc = tp.n_cap_atoms;
+    const double2 *tx = tab + (size_t)kx * nc;
+    const double2 *ty = tab + (size_t)(bx.kmax[0] + 1 + aky) * nc;
+    const double2 *tz = tab + (size_t)(bx.kmax[0] + bx.kmax[1] + 2 + akz) * nc;
+    double re = 0.0, im = 0.0;
+    for (int j = threadIdx.x; j < tp.n_cap_atoms; j += kBlock) {
+        if (atom_mol[j] >= nmol[replica * tp.n_res + atom_res[j]]) continue;
+        double2 Y = ty[j], Z = tz[j];
+        if (ky < 0) Y.y = -Y.y;
+        if (kz < 0) Z.y = -Z.y;
+        const double2 p = cmul(cmul(tx[j], Y), Z);
+        const double q = atom_q[j];
+        re += q * p.x;
+        im += q * p.y;
+    }
+    re = wave_sum(re);
+    im = wave_sum(im);
+    if ((threadIdx.x & 63) == 0) { s_red[2 * (threadIdx.x >> 6)] = re; s_red[2 * (threadIdx.x >> 6) + 1] = im; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < kWavesPerBlock; ++w) { a += s_red[2 * w]; b += s_red[2 * w + 1]; }
+        S[k] = make_double2(a, b);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// ComputeIntraResidueRealCoulombEnergySingleMol (ewald_energy.f90:371-411): one thread per item,
+// pairs visited in the reference's order.
+// ------------------------------------------------------------------------------------------
+__global__ void intra_kernel(Topo tp, BoxDev bx, const double *__restrict__ pos, const double *__restrict__ res_q,
+                             const PairItem *__restrict__ items, int n_items, const double *__restrict__ cand_sites,
+                             int site_stride, double *__restrict__ u_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    const PairItem it = items[i];
+    const int n1 = tp.n1[it.t];
+    const double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
+    const double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
+    auto site = [&](int a, double &x, double &y, double &z) {
+        if (it.src < 0) {
+            const int j = atom_slot(tp, it.t, it.m, a);
+            x = px[j]; y = py[j]; z = pz[j];
+        } else {
+            const double *c = cand_sites + ((size_t)it.src * site_stride + a) * 3;
+            x = c[0]; y = c[1]; z = c[2];
+        }
+    };
+    double u = 0.0;
+    for (int a1 = 0; a1 < n1 - 1; ++a1) {
+        const double q1 = res_q[it.t * tp.max_atom + a1];
+        double x1, y1, z1;
+        site(a1, x1, y1, z1);
+        for (int a2 = a1 + 1; a2 < n1; ++a2) {
+            const double q2 = res_q[it.t * tp.max_atom + a2];
+            double x2, y2, z2;
+            site(a2, x2, y2, z2);
+            const double dx = min_image(x2 - x1, bx.L[0], bx.invL[0]);
+            const double dy = min_image(y2 - y1, bx.L[1], bx.invL[1]);
+            const double dz = min_image(z2 - z1, bx.L[2], bx.invL[2]);
+            const double r = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
+            if (r > kErrorTol) u = u + q1 * q2 * (erfc(bx.alpha * r) - 1.0) / r;
+        }
+    }
+    u_out[i] = u * kEps0InvEvA / kKbEvK;
+}
+
+}  // namespace mgpu
+
+#endif

@@ -1,0 +1,326 @@
+"""GPU parity tests: every call goes through the C ABI of libmaniac_hip.so (HIP, gfx950) and is
+compared with (1) the golden vectors generated from the reference Fortran, (2) the C restatement
+oracle/refcpu.c on seeded inputs, and (3) size-independent properties at the benchmark size.
+
+Tolerance: BASELINE.json north_star -- every energy component within 1e-10 kcal/mol
+(= 5.03e-8 K in the reference's internal unit) of the reference; components whose magnitude
+exceeds ~1e8 K (static self / intra totals) get 16 ulp instead (tests/util.py::tol_for).
+"""
+import numpy as np
+import pytest
+
+from maniac_mc_amd import _lib, synth
+from maniac_mc_amd.engine import Engine
+from maniac_mc_amd._lib import MGPU_CREATION, MGPU_DELETION, MGPU_MOVE, MGPU_NONE
+from tests.util import GOLDEN_FULL, TOL_K, golden_system, tol_for
+
+pytestmark = pytest.mark.gpu
+
+E_KEYS = ("non_coulomb", "coulomb", "recip_coulomb", "ewald_self", "intra_coulomb", "total")
+
+
+def close(a, b, what=""):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    tol = tol_for(*np.ravel(b), *np.ravel(a)) if a.size else TOL_K
+    err = np.max(np.abs(a - b)) if a.size else 0.0
+    assert err <= tol, f"{what}: |diff| = {err:.3e} K > tol {tol:.3e} K\n got {a}\n ref {b}"
+
+
+def amp_close(a, b, what=""):
+    err = np.max(np.abs(np.asarray(a) - np.asarray(b)))
+    assert err <= 1e-10, f"{what}: max |dA| = {err:.3e}"
+
+
+@pytest.mark.parametrize("name", GOLDEN_FULL + ["spce1000_scalars", "spce3375_scalars"])
+def test_engine_vs_golden(name):
+    g, s = golden_system(name)
+    eng = Engine.from_system(s, n_replicas=2)
+    assert eng.alpha == float(g["alpha"]) and eng.nk == int(g["nk"]) and eng.rc == float(g["rc_eff"])
+    # --- static energies (a3, a9, a12)
+    e = eng.system_energy(0)
+    for i, k in enumerate(E_KEYS):
+        close(e[k], g["system_energy"][i], f"{name} system {k}")
+    # --- S(k)
+    eng.init_structure_factor(0, full=True)
+    eng.replica_copy(1, 0)
+    A0 = eng.structure_factor(0)
+    na = g["A_full"].shape[0]
+    amp_close(A0[:na], g["A_full"], f"{name} S(k)")
+    # --- translation / rotation trials (a1, a6, a7)
+    nmv = len(g["mv_t"])
+    t = g["mv_t"].astype(np.int32); m = g["mv_m"].astype(np.int32)
+    old, new = eng.trial_energy_candidates(np.zeros(nmv, np.int32), t, m, g["mv_sites"])
+    for i in range(nmv):
+        close(old[i], g["mv_old"][i][:3], f"{name} move {i} old")
+        close(new[i], g["mv_new"][i][:3], f"{name} move {i} new")
+        close(old[i].sum(), g["mv_old"][i][5], f"{name} move {i} old total")
+        close(new[i].sum(), g["mv_new"][i][5], f"{name} move {i} new total")
+        # the per-call seams give the same numbers
+        nc, c = eng.ComputePairInteractionEnergy_singlemol(int(t[i]), int(m[i]), g["mv_sites"][i])
+        close([nc, c], g["mv_new"][i][:2], f"{name} move {i} pair seam")
+        u = eng.ComputeRecipEnergySingleMol(int(t[i]), int(m[i]), g["mv_sites"][i])
+        close(u, g["mv_new"][i][2], f"{name} move {i} recip seam")
+        close(eng.ComputeIntraResidueRealCoulombEnergySingleMol(int(t[i]), int(m[i]), g["mv_sites"][i]),
+              g["mv_intra"][i], f"{name} move {i} intra")
+        # commit on replica 1 (fresh copy each time), compare A(k) with the reference's mutated A
+        eng.replica_copy(1, 0)
+        eng.commit_candidates([1], [t[i]], [m[i]], [MGPU_MOVE], g["mv_sites"][i][None], [1])
+        amp_close(eng.structure_factor(1)[:na], g["mv_A_after"][i][:na], f"{name} move {i} A after commit")
+        n1 = int(s.topo.atoms_in_res[t[i]])
+        assert np.array_equal(eng.get_molecules(1, int(t[i]))[m[i]], g["mv_sites"][i][:n1])
+        # after the commit the "old" energy of that molecule is the former "new" energy
+        nc2, c2 = eng.ComputePairInteractionEnergy_singlemol(int(t[i]), int(m[i]), None, replica=1)
+        close([nc2, c2], g["mv_new"][i][:2], f"{name} move {i} pair after commit")
+        close(eng.ComputeRecipEnergySingleMol(int(t[i]), int(m[i]), None, replica=1), g["mv_new"][i][2],
+              f"{name} move {i} recip after commit")
+    # --- creation (a1, a6, a7, a12)
+    tc = int(g["cr_t"])
+    n0 = eng.num_molecules(0, tc)
+    cs = g["cr_sites"][None]
+    nc, c = eng.pair_energy_candidates([0], [tc], [-1], cs)
+    u = eng.recip_energy_candidates([0], [tc], [-1], [MGPU_CREATION], cs)
+    intra = eng.intra_energy_candidates([0], [tc], [-1], cs)
+    close([nc[0], c[0], u[0], eng.self_energy(tc), intra[0]], g["cr_new"][:5], f"{name} creation new")
+    close(eng.recip_energy_candidates([0], [tc], [-1], [MGPU_NONE])[0], g["cr_old"][2], f"{name} creation old recip")
+    eng.replica_copy(1, 0)
+    eng.commit_candidates([1], [tc], [-1], [MGPU_CREATION], cs, [1])
+    assert eng.num_molecules(1, tc) == n0 + 1 and eng.num_molecules(0, tc) == n0
+    amp_close(eng.structure_factor(1)[:na], g["cr_A_after"][:na], f"{name} creation A")
+    assert np.array_equal(eng.get_molecules(1, tc)[n0], g["cr_sites"])
+    # the inserted molecule now sees the same pair energy as the candidate did
+    nc2, c2 = eng.ComputePairInteractionEnergy_singlemol(tc, n0, None, replica=1)
+    close([nc2, c2], g["cr_new"][:2], f"{name} creation pair after commit")
+    # --- deletion
+    td, md = int(g["dl_t"]), int(g["dl_m"])
+    nc, c = eng.ComputePairInteractionEnergy_singlemol(td, md)
+    close([nc, c, eng.self_energy(td), eng.ComputeIntraResidueRealCoulombEnergySingleMol(td, md)],
+          [g["dl_old"][0], g["dl_old"][1], g["dl_old"][3], g["dl_old"][4]], f"{name} deletion old")
+    close(eng.ComputeRecipEnergySingleMol(td, md, is_deletion=True), g["dl_recip_new"], f"{name} deletion recip")
+    eng.replica_copy(1, 0)
+    before = eng.get_molecules(1, td)
+    eng.commit_candidates([1], [td], [md], [MGPU_DELETION], None, [1])
+    assert eng.num_molecules(1, td) == n0 - 1
+    amp_close(eng.structure_factor(1)[:na], g["dl_A_after"][:na], f"{name} deletion A")
+    after = eng.get_molecules(1, td)
+    if md != n0 - 1:
+        assert np.array_equal(after[md], before[n0 - 1])      # swap-with-last, delete_molecule.f90:107-114
+    eng.close()
+
+
+@pytest.mark.parametrize("maker,nrep", [(lambda: synth.spce_box(6, seed=21), 4), (lambda: synth.mixture_box(seed=5), 3),
+                                        (lambda: synth.co2_box(16, seed=2), 2),
+                                        (lambda: synth.framework_water_box(n_water=10, n_frame=260, L=23.0, seed=9), 2)])
+def test_batched_candidates_vs_refcpu(maker, nrep, refcpu_mod):
+    """Many candidates per launch, on replicas holding DIFFERENT configurations."""
+    rng = np.random.default_rng(7)
+    base = maker()
+    systems = []
+    for r in range(nrep):
+        s = base.copy()
+        for t in range(s.topo.n_res):
+            if s.topo.is_active[t]:
+                s.com[t] = s.com[t] + rng.uniform(-0.15, 0.15, s.com[t].shape) * (r > 0)
+        systems.append(s)
+    eng = Engine.from_system(base, n_replicas=nrep)
+    oracles = []
+    for r, s in enumerate(systems):
+        eng.load_system(s, r)
+        eng.init_structure_factor(r, True)
+        P = refcpu_mod.RefCPU(s)
+        P.system_energy(); P.init_amplitude(True)
+        oracles.append(P)
+        amp_close(eng.structure_factor(r), P.amplitude(), f"replica {r} S(k)")
+    active = [t for t in range(base.topo.n_res) if base.topo.is_active[t]]
+    B = 48
+    rep = rng.integers(0, nrep, B).astype(np.int32)
+    t = rng.choice(active, B).astype(np.int32)
+    m = np.array([rng.integers(0, base.n_mol[tt]) for tt in t], dtype=np.int32)
+    sites = np.zeros((B, base.topo.max_atom if base.topo.max_atom < 64 else int(max(base.topo.atoms_in_res[a] for a in active)), 3))
+    exp_old, exp_new = np.zeros((B, 3)), np.zeros((B, 3))
+    for c in range(B):
+        P = oracles[rep[c]]
+        A0 = P.amplitude()
+        com, off = P.get_molecule(int(t[c]), int(m[c]))
+        P.save_fourier(int(t[c]), int(m[c]))
+        exp_old[c] = P.old_energy(int(t[c]), int(m[c]), 0)[:3]
+        ncom = P.apply_pbc(com + rng.uniform(-0.4, 0.4, 3))
+        noff = off @ P.rotation_matrix(int(rng.integers(1, 4)), float(rng.uniform(-0.4, 0.4))).T
+        n1 = off.shape[0]
+        sites[c, :n1] = ncom[None, :] + noff
+        # feed the oracle the same rounded absolute sites the engine receives
+        P.set_molecule(int(t[c]), int(m[c]), sites[c, 0], sites[c, :n1] - sites[c, 0][None, :])
+        if not np.array_equal(sites[c, 0][None, :] + (sites[c, :n1] - sites[c, 0][None, :]), sites[c, :n1]):
+            pass  # re-splitting may flip a last bit; covered by the tolerance
+        exp_new[c] = P.new_energy(int(t[c]), int(m[c]), 0)[:3]
+        P.set_molecule(int(t[c]), int(m[c]), com, off)
+        P.restore_fourier(int(t[c]), int(m[c]))
+        assert np.array_equal(P.amplitude(), A0)
+    old, new = eng.trial_energy_candidates(rep, t, m, sites)
+    close(old, exp_old, "batched old")
+    close(new, exp_new, "batched new")
+    # same numbers from the separate entry points, and bitwise reproducible run to run
+    nc, cc = eng.pair_energy_candidates(rep, t, m, sites)
+    close(np.stack([nc, cc], 1), exp_new[:, :2], "batched pair")
+    u = eng.recip_energy_candidates(rep, t, m, np.full(B, MGPU_MOVE), sites)
+    close(u, exp_new[:, 2], "batched recip")
+    old2, new2 = eng.trial_energy_candidates(rep, t, m, sites)
+    assert np.array_equal(old, old2) and np.array_equal(new, new2)
+    eng.close()
+
+
+def test_markov_chain_of_commits_tracks_oracle(refcpu_mod):
+    """A short sequential chain (moves, insertions, deletions) committed on the GPU and replayed in
+    the oracle: energies and A(k) must agree at every step, and A(k) must not drift from S(k)."""
+    rng = np.random.default_rng(11)
+    s = synth.co2_box(14, seed=3)
+    eng = Engine.from_system(s, n_replicas=1, mol_capacity=[40])
+    P = refcpu_mod.RefCPU(s, mol_capacity=40)
+    P.system_energy(); P.init_amplitude(True)
+    eng.init_structure_factor(0, True)
+    t = 0
+    tmpl = s.offsets[0][0]
+    for step in range(60):
+        n = eng.num_molecules(0, t)
+        assert n == P.num_residues(t)
+        kind = rng.choice([MGPU_MOVE, MGPU_MOVE, MGPU_CREATION, MGPU_DELETION])
+        if kind == MGPU_MOVE and n > 0:
+            m = int(rng.integers(0, n))
+            com, off = P.get_molecule(t, m)
+            sites = (P.apply_pbc(com + rng.uniform(-0.5, 0.5, 3))[None, :] +
+                     off @ P.rotation_matrix(int(rng.integers(1, 4)), float(rng.uniform(-0.5, 0.5))).T)
+            old, new = eng.trial_energy_candidates([0], [t], [m], sites[None])
+            P.save_fourier(t, m)
+            eo = P.old_energy(t, m, 0)
+            P.set_molecule(t, m, sites[0], sites - sites[0][None, :])
+            en = P.new_energy(t, m, 0)
+            close(old[0], eo[:3], f"step {step} old"); close(new[0], en[:3], f"step {step} new")
+            if rng.uniform() < 0.6:
+                eng.commit_candidates([0], [t], [m], [MGPU_MOVE], sites[None], [1])
+            else:
+                P.set_molecule(t, m, com, off)
+                P.restore_fourier(t, m)
+        elif kind == MGPU_CREATION and n < 39:
+            sites = (s.bounds_lo + rng.uniform(0, 1, 3) * 50.0)[None, :] + tmpl @ P.rotation_matrix(2, float(rng.uniform(0, 6))).T
+            nc, c = eng.pair_energy_candidates([0], [t], [-1], sites[None])
+            u = eng.recip_energy_candidates([0], [t], [-1], [MGPU_CREATION], sites[None])
+            P.set_num_residues(t, n + 1)
+            P.save_fourier(t, n)
+            P.set_molecule(t, n, sites[0], sites - sites[0][None, :])
+            en = P.new_energy(t, n, 1)
+            close([nc[0], c[0], u[0]], en[:3], f"step {step} creation")
+            eng.commit_candidates([0], [t], [-1], [MGPU_CREATION], sites[None], [1])
+        elif kind == MGPU_DELETION and n > 1:
+            m = int(rng.integers(0, n))
+            u = eng.recip_energy_candidates([0], [t], [m], [MGPU_DELETION])
+            P.save_fourier(t, m)
+            ud = P.recip_singlemol(t, m, 2)      # intended physics: A - S_mol
+            close(u[0], ud, f"step {step} deletion recip")
+            eng.commit_candidates([0], [t], [m], [MGPU_DELETION], None, [1])
+            # oracle bookkeeping: RemoveMolecule + ReplaceFourierTermsSingleMol (delete_molecule.f90:99-116)
+            lcom, loff = P.get_molecule(t, n - 1)
+            P.set_molecule(t, m, lcom, loff)
+            P.replace_fourier(t, m, n - 1)
+            P.set_num_residues(t, n - 1)
+        amp_close(eng.structure_factor(0), P.amplitude(), f"step {step} A")
+    # no drift: A(k) accumulated over the chain equals a fresh S(k) of the final configuration
+    A_chain = eng.structure_factor(0)
+    eng.init_structure_factor(0, True)
+    amp_close(A_chain, eng.structure_factor(0), "A(k) drift after chain")
+    n = eng.num_molecules(0, t)
+    got = eng.get_molecules(0, t)
+    for m in range(n):
+        com, off = P.get_molecule(t, m)
+        assert np.allclose(got[m], com[None, :] + off, rtol=0, atol=1e-12)
+    eng.close()
+
+
+def test_properties_at_benchmark_size():
+    """N = 10125 (3375 SPC/E, Nk = 2242): size-independent identities, no oracle involved."""
+    s = synth.spce_box(15)
+    R = 3
+    eng = Engine.from_system(s, n_replicas=R)
+    for r in range(R):
+        eng.init_structure_factor(r, True)
+    e = eng.system_energy(0)
+    n = int(s.n_mol[0])
+    # (1) checksum of checksums: sum over molecules of the per-molecule pair energy counts every
+    #     pair twice (energy_utils.f90:374-442 vs the ordered total :121-187)
+    m = np.arange(n, dtype=np.int32)
+    nc, c = eng.pair_energy_candidates(np.zeros(n, np.int32), np.zeros(n, np.int32), m)
+    assert abs(nc.sum() - 2 * e["non_coulomb"]) < 1e-6
+    assert abs(c.sum() - 2 * e["coulomb"]) < 1e-5
+    # (2) zero displacement: old == new; recip(NONE) == system recip energy
+    rng = np.random.default_rng(5)
+    pick = rng.choice(n, 256, replace=False).astype(np.int32)
+    allsites = s.all_sites(0)
+    old, new = eng.trial_energy_candidates(np.zeros(256, np.int32), np.zeros(256, np.int32), pick, allsites[pick])
+    assert np.max(np.abs(old - new)) < TOL_K
+    assert np.max(np.abs(old[:, 2] - e["recip_coulomb"])) < TOL_K
+    # (3) periodic image invariance: shifting a candidate by a lattice vector changes nothing
+    shifted = allsites[pick] + np.array([46.56, -46.56, 2 * 46.56])[None, None, :]
+    _, new_s = eng.trial_energy_candidates(np.zeros(256, np.int32), np.zeros(256, np.int32), pick, shifted)
+    assert np.max(np.abs(new_s - new)) < 1e-6
+    # (4) commit + reverse commit restores A(k); A(k) after commits == fresh S(k)
+    A0 = eng.structure_factor(1)
+    moved = allsites[pick[:1]] + 0.2
+    eng.commit_candidates([1], [0], [pick[0]], [MGPU_MOVE], moved, [1])
+    u_after = eng.recip_energy_candidates([1], [0], [pick[0]], [MGPU_NONE])[0]
+    u_pred = eng.recip_energy_candidates([0], [0], [pick[0]], [MGPU_MOVE], moved)[0]
+    assert abs(u_after - u_pred) < TOL_K
+    A1 = eng.structure_factor(1)
+    eng.init_structure_factor(1, True)
+    assert np.max(np.abs(A1 - eng.structure_factor(1))) < 1e-10
+    eng.commit_candidates([1], [0], [pick[0]], [MGPU_MOVE], allsites[pick[:1]], [1])
+    assert np.max(np.abs(eng.structure_factor(1) - A0)) < 1e-10
+    # (5) Delta E of a trial equals the difference of two full system energies
+    eng.replica_copy(2, 0)
+    old1, new1 = eng.trial_energy_candidates([2], [0], [pick[1]], allsites[pick[1:2]] + 0.15)
+    eng.commit_candidates([2], [0], [pick[1]], [MGPU_MOVE], allsites[pick[1:2]] + 0.15, [1])
+    e2 = eng.system_energy(2)
+    de_trial = (new1[0] - old1[0]).sum()
+    de_full = (e2["non_coulomb"] + e2["coulomb"] + e2["recip_coulomb"]) - (e["non_coulomb"] + e["coulomb"] + e["recip_coulomb"])
+    assert abs(de_trial - de_full) < 1e-6
+    # (6) determinism: identical launches give identical bits
+    o2, n2 = eng.trial_energy_candidates(np.zeros(256, np.int32), np.zeros(256, np.int32), pick, allsites[pick])
+    assert np.array_equal(o2, old) and np.array_equal(n2, new)
+    eng.close()
+
+
+def test_edge_cases_and_errors():
+    s = synth.mixture_box(n_a=1, n_b=0, seed=2)
+    eng = Engine.from_system(s, n_replicas=2, mol_capacity=[4, 4])
+    # a lone molecule has no pair partner; residue type 1 is empty
+    assert eng.ComputePairInteractionEnergy_singlemol(0, 0) == (0.0, 0.0)
+    assert eng.num_molecules(0, 1) == 0
+    e = eng.system_energy(0)
+    assert e["non_coulomb"] == 0.0 and e["coulomb"] == 0.0
+    # empty batch is a no-op
+    out = eng.pair_energy_candidates(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert out[0].shape == (0,)
+    # insertion into the empty residue type, up to capacity, then a capacity error
+    eng.init_structure_factor(1, True)
+    site = np.array([[[0.3, 0.1, -0.2], [1.5, 0.1, -0.2]]])
+    for k in range(4):
+        eng.commit_candidates([1], [1], [-1], [MGPU_CREATION], site + 2.0 * k, [1])
+    assert eng.num_molecules(1, 1) == 4
+    with pytest.raises(_lib.MgpuError) as ei:
+        eng.commit_candidates([1], [1], [-1], [MGPU_CREATION], site, [1])
+    assert ei.value.code == 3
+    # deleting down to zero works and leaves A(k) equal to the S(k) of what remains
+    for k in range(4):
+        eng.commit_candidates([1], [1], [0], [MGPU_DELETION], None, [1])
+    assert eng.num_molecules(1, 1) == 0
+    A = eng.structure_factor(1)
+    eng.init_structure_factor(1, True)
+    assert np.max(np.abs(A - eng.structure_factor(1))) < 1e-11
+    # argument errors are status codes, not crashes
+    for bad in (dict(replica=[5], t=[0], m=[0]), dict(replica=[0], t=[3], m=[0]), dict(replica=[0], t=[0], m=[2]),
+                dict(replica=[0], t=[1], m=[0])):
+        with pytest.raises(_lib.MgpuError) as ei:
+            eng.pair_energy_candidates(bad["replica"], bad["t"], bad["m"])
+        assert ei.value.code == 1
+    with pytest.raises(_lib.MgpuError):     # two accepted candidates for one replica
+        eng.commit_candidates([0, 0], [0, 0], [0, 0], [MGPU_MOVE, MGPU_MOVE], np.zeros((2, 3, 3)), [1, 1])
+    with pytest.raises(_lib.MgpuError):     # triclinic box is rejected explicitly
+        Engine.from_system(synth.mixture_box(tilt=(1.0, 0.5, 0.2)))
+    eng.close()

@@ -1,0 +1,89 @@
+"""CPU-only checks of the product library: it loads, exports every symbol include/maniac_gpu.h
+declares, and its host-side setup arithmetic (box products, SetupEwald, k table) reproduces the
+reference's values bit for bit.  No compute entry point is called here (there is no GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from maniac_mc_amd import _lib
+from tests.util import GOLDEN_FULL, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hiplib():
+    _lib.build()
+    return _lib.lib()
+
+
+def test_exports_match_header(hiplib):
+    header = open(os.path.join(ROOT, "include", "maniac_gpu.h")).read()
+    declared = set(re.findall(r"\b(mgpu_[a-z_0-9]+)\s*\(", header))
+    declared.discard("mgpu_engine")
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(hiplib, name), name
+    assert hiplib.mgpu_abi_version() == 1
+
+
+@pytest.mark.parametrize("name", GOLDEN_FULL + ["spce1000_scalars", "spce3375_scalars"])
+def test_host_setup_bitwise_vs_reference(name, hiplib):
+    from maniac_mc_amd import engine
+    g = load_golden(name)
+    if "box_matrix" in g:
+        bm = g["box_matrix"]
+    else:
+        L = float(g["metrics"][0])
+        bm = np.diag([L, L, L])
+    bt, vol, rcp, met = engine.box_prepare(bm)
+    assert bt == int(g["box_type"]) and vol == float(g["volume"])
+    assert np.array_equal(rcp, g["reciprocal"]) and np.array_equal(met, g["metrics"])
+    ew = engine.ewald_setup(met, float(g["rc_in"]), float(g["tol_in"]))
+    assert ew["alpha"] == float(g["alpha"]) and ew["rc"] == float(g["rc_eff"]) and ew["tol"] == float(g["tol_eff"])
+    assert np.array_equal(ew["kmax"], g["kmax"]) and ew["nk"] == int(g["nk"])
+    kv = engine.ewald_kvectors(rcp, ew["alpha"], ew["kmax"], ew["nk"])
+    for k in ("kx", "ky", "kz", "k2mag", "form_factor", "weights"):
+        assert np.array_equal(kv[k], g["k_" + k]), k
+
+
+def test_setup_edge_cases(hiplib):
+    from maniac_mc_amd import engine
+    # cutoff larger than the box is halved to min(L)/2 (prepare_utils.f90:141-150)
+    bt, vol, rcp, met = engine.box_prepare(np.diag([10.0, 12.0, 14.0]))
+    assert bt == 2
+    ew = engine.ewald_setup(met, 11.0, 1e-5)
+    assert ew["rc"] == 5.0
+    # tolerance is clamped to |tol| <= 0.5 (prepare_utils.f90:157-160)
+    assert engine.ewald_setup(met, 4.0, -0.9)["tol"] == 0.5
+    # triclinic boxes are recognised (type 3)
+    assert engine.box_prepare(np.array([[10.0, 0, 0], [1.0, 10.0, 0], [0, 0, 10.0]]))[0] == 3
+    # degenerate box: error code, not a crash
+    with pytest.raises(_lib.MgpuError):
+        engine.box_prepare(np.diag([0.5, 0.5, 0.5]))
+    with pytest.raises(_lib.MgpuError):
+        engine.ewald_kvectors(rcp, ew["alpha"], ew["kmax"], ew["nk"] - 1)
+
+
+def test_engine_create_fails_loudly_without_gpu(hiplib):
+    """On a box without a HIP device the product path must raise, never fall back."""
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("GPU present")
+    from maniac_mc_amd import engine, synth
+    with pytest.raises(_lib.MgpuError) as ei:
+        engine.Engine.from_system(synth.argon_box())
+    assert ei.value.code in (2, 4)
+
+
+def test_product_path_does_not_import_oracle():
+    """maniac_mc_amd/ must never import, link or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "maniac_mc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".f90")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("# oracle-free", ""), os.path.join(dirpath, f)
