@@ -86,8 +86,18 @@ def make(name, s, moves, store_coords=True, n_amp_store=None):
     old_c = R.old_energy(t, n, 1)
     _, off1 = R.get_molecule(t, 0)
     L = np.diag(s.box_matrix)
-    ccom = s.bounds_lo + rng.uniform(0.1, 0.9, 3) * L
     coff = off1 @ rot(2, 1.234).T @ rot(0, 0.5).T
+    # insertion point: the roomiest of 400 random positions (an overlapping insertion gives
+    # ~1e9 K of LJ repulsion, where fp64 cannot resolve the absolute 1e-10 kcal/mol bar)
+    allsites = np.concatenate([s.all_sites(tt).reshape(-1, 3) for tt in range(s.topo.n_res)])
+    best, ccom = -1.0, None
+    for _ in range(400):
+        c = s.bounds_lo + rng.uniform(0.0, 1.0, 3) * L
+        d = (allsites[None, :, :] - (c[None, :] + coff)[:, None, :])
+        d -= L * np.rint(d / L)
+        dmin = np.sqrt(np.min(np.einsum("sai,sai->sa", d, d)))
+        if dmin > best:
+            best, ccom = dmin, c
     R.set_num_residues(t, n + 1)
     R.save_fourier(t, n)
     R.set_molecule(t, n, ccom, coff)
