@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-move Delta-E hot path on MI355X (contract: see the task statement).
+
+Workload (BASELINE.json metric: "MC moves/sec ... 10k-atom LJ+Ewald"): the 10 125-atom SPC/E box
+of SURVEY.md section 8(d) -- 3375 rigid molecules, L = 46.56 A, lj/cut/coul/long, rc = 12 A,
+ewald_tolerance 1e-5 -> alpha = 0.2346, kmax = 10, Nk = 2242 -- 50 % translation / 50 % rotation,
+steps 0.3 A / 0.3 rad, T = 300 K.  Synthetic coordinates (seeded lattice + jitter), no files read.
+
+A "step" = one Metropolis trial in each of the R replicas a GPU holds: R candidates x (old + new)
+= 2R Delta-E evaluations (pair sweep + k sweep each) in one batched launch, the acceptance test on
+the host, and one commit launch for the accepted candidates.  Nothing is cached or skipped: both
+halves of ComputeOldEnergy / ComputeNewEnergy are computed for every trial.
+value = accepted MC moves per second over all GPUs (replicas are independent chains; weak scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(system, translation_step, rotation_step, budget_s=15.0, seed=3):
+    """The reference itself (oracle/_ref, amdflang -O2, 1 thread) -- or, if that build is not on
+    this box, the C restatement -- running the same Metropolis trial sequentially for a bounded
+    number of moves.  Reported beside the GPU number; it is a baseline, not the target."""
+    from oracle import reflib, refcpu
+    kind = "reference" if reflib.available() else "port"
+    X = reflib.Reference(system) if kind == "reference" else refcpu.RefCPU(system)
+    X.all_fourier_terms()
+    X.init_amplitude(True)
+    rng = np.random.default_rng(seed)
+    n = int(system.n_mol[0])
+    T = system.temperature
+    trials = accepted = 0
+    t0 = time.perf_counter()
+    while True:
+        m = int(rng.integers(0, n))
+        com, off = X.get_molecule(0, m)
+        X.save_fourier(0, m)
+        old = X.old_energy(0, m, 0)
+        if rng.random() <= 0.5:
+            X.set_molecule(0, m, X.apply_pbc(com + (rng.random(3) - 0.5) * translation_step), off)
+        else:
+            rot = X.rotation_matrix(int(rng.random() * 3) + 1, (rng.random() - 0.5) * rotation_step)
+            X.set_molecule(0, m, com, off @ rot.T)
+        new = X.new_energy(0, m, 0)
+        trials += 1
+        if rng.random() <= min(1.0, np.exp(-(new[5] - old[5]) / T)):
+            accepted += 1
+        else:
+            X.set_molecule(0, m, com, off)
+            X.restore_fourier(0, m)
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    return {"value": accepted / el, "unit": "accepted MC moves/s", "cores": 1, "kind": kind,
+            "sample": f"{trials} sequential translation/rotation trials ({2 * trials} Delta-E evaluations) of the same "
+                      f"{system.n_atoms}-atom box in {el:.1f} s",
+            "trial_moves_per_s": trials / el, "ns_per_dE_eval": el / (2 * trials) * 1e9,
+            "acceptance": accepted / max(1, trials)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--replicas", type=int, default=1024, help="independent chains per GPU")
+    ap.add_argument("--n-side", type=int, default=15, help="SPC/E lattice side (15 -> 10 125 atoms)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from maniac_mc_amd import _lib, synth
+    from maniac_mc_amd.farm import ReplicaFarm
+
+    system = synth.spce_box(args.n_side)
+    t_step, r_step = 0.3, 0.3
+    farm = ReplicaFarm(system, args.replicas, device=local_rank, seed=1000 + rank,
+                       translation_step=t_step, rotation_step=r_step, p_translation=0.5)
+    eng = farm.eng
+    N, Nk, R = system.n_atoms, eng.nk, args.replicas
+
+    for _ in range(args.warmup):
+        farm.step()
+    eng.profile_enable(True)
+    eng.profile_reset()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    accepted = farm.run(args.steps)
+    # the path's one real exchange step: per-block gather of each rank's counters
+    stats = torch.tensor([float(accepted), float(args.steps * R)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        gathered = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(gathered, stats)
+        stats = torch.stack(gathered).sum(0)
+    fence()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    tot_acc, tot_trials = float(stats[0].item()), float(stats[1].item())
+
+    n_pair, ms_pair = eng.profile_get(_lib.KERNEL_PAIR)
+    n_rec, ms_rec = eng.profile_get(_lib.KERNEL_RECIP)
+    n_com, ms_com = eng.profile_get(_lib.KERNEL_COMMIT)
+    eng.profile_enable(False)
+
+    if rank == 0:
+        # algorithmic bytes per Delta-E evaluation: 36 N + 52 Nk; the pair sweep owns
+        # the 36 N part (x, y, z, q fp64 + int32 type per atom), the k sweep the 52 Nk part.
+        bytes_pair_eval = 36.0 * N
+        bytes_eval = 36.0 * N + 52.0 * Nk
+        evals_per_launch = 2 * R
+        avg_pair_s = ms_pair / max(1, n_pair) * 1e-3
+        achieved = bytes_pair_eval * evals_per_launch / avg_pair_s / 1e9 if n_pair else 0.0
+        evals_total = 2.0 * tot_trials
+        out = {
+            "metric": "MC moves/sec", "value": tot_acc / elapsed, "unit": "accepted MC moves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"spce_{system.n_mol[0]}mol_{N}atoms_lj_cut_coul_long_ewald_Nk{Nk}",
+                       "replicas_per_gpu": R, "moves": "50% translation / 50% rotation, 0.3 A / 0.3 rad, 300 K",
+                       "trials_per_step": R * world, "dE_evals_per_step": 2 * R * world, "parallelism": f"replicas x{world}"},
+            "trial_moves_per_s": tot_trials / elapsed,
+            "acceptance": tot_acc / max(1.0, tot_trials),
+            "ns_per_dE_eval": elapsed / evals_total * 1e9 * world,
+            "ns_per_dE_eval_note": "wall time per Delta-E evaluation per GPU (pair sweep + k sweep), host loop included",
+            "roofline": {"bound": "hbm", "kernel": "pair_sweep_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_pair_eval * evals_per_launch,
+                         "avg_launch_us": avg_pair_s * 1e6, "launches": n_pair,
+                         "job_frac": (evals_total / world / elapsed) * bytes_eval / 1e9 / HBM_PEAK_GBS,
+                         "recip_avg_launch_us": ms_rec / max(1, n_rec) * 1e3, "commit_avg_launch_us": ms_com / max(1, n_com) * 1e3},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(system, t_step, r_step, budget_s=args.cpu_budget)
+        print(json.dumps(out))
+    farm.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
