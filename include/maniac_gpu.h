@@ -88,6 +88,11 @@ int mgpu_ewald_kvectors(const double reciprocal[9], double alpha, const int kmax
                         int *kx, int *ky, int *kz, double *k2mag, double *form_factor,
                         double *weights);
 
+/* The pair sweep reads erfc from an LDS-resident table of piecewise degree-7 polynomials
+ * (maniac_mc_amd/csrc/mgpu_erfc_table.h) instead of calling libm's erfc (energy_utils.f90:432).
+ * This evaluates the same table with the same arithmetic on the host, for accuracy checks. */
+int mgpu_erfc_table_eval(int n, const double *x, double *out);
+
 /* ------------------------------------------------------------------------------------------
  * Engine life cycle
  * ---------------------------------------------------------------------------------------- */

@@ -92,6 +92,8 @@ struct mgpu_engine {
     int *d_kpack = nullptr;
     double *d_kw = nullptr;
     double2 *d_pair_tab = nullptr;
+    double *d_erfc_tab = nullptr;    // piecewise-polynomial erfc table (mgpu_erfc_table.h)
+    int n_cu = 256;                  // compute units of the device
     double *d_res_q = nullptr;
     int *d_res_atype = nullptr;
     int *d_atom_res = nullptr, *d_atom_mol = nullptr;
@@ -177,10 +179,11 @@ int replica_units(const mgpu_engine *e, int replica) {
 }
 
 int choose_nsplit(const mgpu_engine *e, int n_items, int replica_hint) {
-    // fill the chip (256 CUs x 8 resident workgroups) without giving a wave less than one unit
+    // one wave per (item, split).  Aim at >= 4 work units per resident wave slot (n_cu x 32) for
+    // balance, but never give a wave fewer than ~8 sweep units of 64 atoms.
     const int units = std::max(1, replica_units(e, replica_hint));
-    const int max_split = std::max(1, units / kWavesPerBlock);
-    const int want = (2048 + n_items - 1) / std::max(1, n_items);
+    const int max_split = std::max(1, units / 8);
+    const int want = (4 * e->n_cu * 32 + n_items - 1) / std::max(1, n_items);
     return std::max(1, std::min(want, max_split));
 }
 
@@ -193,23 +196,53 @@ int upload_sites(mgpu_engine *e, const double *sites, int n_rows, int site_strid
     return MGPU_OK;
 }
 
-// launch the pair sweep + finalize for items already on the device; results land in d_lj / d_c
-int launch_pair(mgpu_engine *e, const PairItem *d_items, int n_items, int site_stride, int nsplit, double *d_lj,
-                double *d_c) {
-    int rc = e->d_partials.reserve((size_t)n_items * nsplit * sizeof(double2));
+// launch the pair sweep + finalize for items already on the device; results land in d_lj / d_c.
+// common_n1 = number of sites when every item has the same count (register path for <= 4), else 0.
+int launch_pair(mgpu_engine *e, const PairItem *d_items, int n_items, int common_n1, int site_stride, int nsplit,
+                double *d_lj, double *d_c, bool ordered = false) {
+    const int n_work = n_items * nsplit;
+    int rc = e->d_partials.reserve((size_t)n_work * sizeof(double2));
     if (rc) return rc;
+    // persistent waves: at most 3 workgroups of 8 waves per CU (LDS: 3 x ~31 KiB), never more
+    // workgroups than there is work for
+    const int grid = std::max(1, std::min((n_work + kPairWaves - 1) / kPairWaves, e->n_cu * 3));
     hipEvent_t a = nullptr, b = nullptr;
     rc = prof_begin(e, MGPU_KERNEL_PAIR, &a, &b);
     if (rc) return rc;
-    hipLaunchKernelGGL(pair_sweep_kernel, dim3(n_items * nsplit), dim3(kBlock), 0, e->stream, e->tp, e->bx, e->d_pos,
-                       e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, d_items, (const double *)e->d_sites.p,
-                       site_stride, nsplit, (double2 *)e->d_partials.p);
+#define MGPU_LAUNCH_PAIR(NS, ORD)                                                                                       \
+    hipLaunchKernelGGL((pair_sweep_kernel<NS, ORD>), dim3(grid), dim3(kPairBlock), 0, e->stream, e->tp, e->bx,          \
+                       e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_erfc_tab, d_items,          \
+                       (const double *)e->d_sites.p, site_stride, nsplit, n_work, (double2 *)e->d_partials.p)
+    if (ordered) {
+        MGPU_LAUNCH_PAIR(0, true);
+    } else {
+        switch (common_n1) {
+            case 1: MGPU_LAUNCH_PAIR(1, false); break;
+            case 2: MGPU_LAUNCH_PAIR(2, false); break;
+            case 3: MGPU_LAUNCH_PAIR(3, false); break;
+            case 4: MGPU_LAUNCH_PAIR(4, false); break;
+            default: MGPU_LAUNCH_PAIR(0, false); break;
+        }
+    }
+#undef MGPU_LAUNCH_PAIR
     rc = prof_end(e, MGPU_KERNEL_PAIR, a, b);
     if (rc) return rc;
     hipLaunchKernelGGL(pair_finalize_kernel, dim3((n_items + 255) / 256), dim3(256), 0, e->stream,
                        (const double2 *)e->d_partials.p, n_items, nsplit, d_lj, d_c);
     HIP_TRY(hipGetLastError());
     return MGPU_OK;
+}
+
+// sites per item if all items agree, else 0
+template <class Item>
+int common_site_count(const mgpu_engine *e, const std::vector<Item> &items) {
+    int n1 = 0;
+    for (const auto &it : items) {
+        const int v = e->tp.n1[it.t];
+        if (n1 == 0) n1 = v;
+        else if (n1 != v) return 0;
+    }
+    return n1;
 }
 
 size_t recip_lds_bytes(const mgpu_engine *e, int n1_max) {
@@ -369,6 +402,7 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     std::memcpy(bx.rcp, e->reciprocal, sizeof(double) * 9);
     bx.rc2 = e->rc * e->rc;
     bx.alpha = e->alpha;
+    bx.alpha32 = e->alpha * (double)kErfcInvH;
     bx.volume = e->volume;
     bx.nk = e->nk;
 
@@ -413,6 +447,13 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     HIP_TRY_E(hipMalloc(&e->d_kpack, e->nk * sizeof(int)));
     HIP_TRY_E(hipMalloc(&e->d_kw, e->nk * sizeof(double)));
     HIP_TRY_E(hipMalloc(&e->d_pair_tab, ptab.size() * sizeof(double2)));
+    HIP_TRY_E(hipMalloc(&e->d_erfc_tab, sizeof(kErfcTable)));
+    HIP_TRY_E(hipMemcpy(e->d_erfc_tab, kErfcTable, sizeof(kErfcTable), hipMemcpyHostToDevice));
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY_E(hipGetDeviceProperties(&prop, device));
+        e->n_cu = std::max(1, prop.multiProcessorCount);
+    }
     HIP_TRY_E(hipMalloc(&e->d_res_q, e->charges.size() * sizeof(double)));
     HIP_TRY_E(hipMalloc(&e->d_res_atype, atype0.size() * sizeof(int)));
     HIP_TRY_E(hipMalloc(&e->d_atom_res, ncap * sizeof(int)));
@@ -438,7 +479,7 @@ int mgpu_engine_destroy(mgpu_engine *e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (void *p : {(void *)e->d_pos, (void *)e->d_nmol, (void *)e->d_A, (void *)e->d_kpack, (void *)e->d_kw,
-                    (void *)e->d_pair_tab, (void *)e->d_res_q, (void *)e->d_res_atype, (void *)e->d_atom_res,
+                    (void *)e->d_pair_tab, (void *)e->d_erfc_tab, (void *)e->d_res_q, (void *)e->d_res_atype, (void *)e->d_atom_res,
                     (void *)e->d_atom_mol, (void *)e->d_atom_q, (void *)e->d_phase_tab, (void *)e->d_S})
         if (p) (void)hipFree(p);
     e->d_items.release(); e->d_items2.release(); e->d_sites.release(); e->d_partials.release(); e->d_out.release();
@@ -656,7 +697,7 @@ int mgpu_pair_energy_candidates(mgpu_engine *e, int n, const int *replica, const
     if (any_sites && (rc = upload_sites(e, sites, n, site_stride))) return rc;
     double *d_lj = (double *)e->d_out.p, *d_c = d_lj + n;
     const int nsplit = choose_nsplit(e, n, replica[0]);
-    if ((rc = launch_pair(e, (const PairItem *)e->d_items.p, n, site_stride, nsplit, d_lj, d_c))) return rc;
+    if ((rc = launch_pair(e, (const PairItem *)e->d_items.p, n, common_site_count(e, items), site_stride, nsplit, d_lj, d_c))) return rc;
     HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_out.p, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     if ((rc = sync_stream(e))) return rc;
     std::memcpy(e_nc, e->h_out.p, n * sizeof(double));
@@ -771,7 +812,7 @@ int mgpu_trial_energy_candidates(mgpu_engine *e, int n, const int *replica, cons
     if ((rc = upload_sites(e, sites, n, site_stride))) return rc;
     double *d_lj = (double *)e->d_out.p, *d_c = d_lj + n2, *d_u = d_c + n2;
     const int nsplit = choose_nsplit(e, (int)n2, replica[0]);
-    if ((rc = launch_pair(e, (const PairItem *)e->d_items.p, (int)n2, site_stride, nsplit, d_lj, d_c))) return rc;
+    if ((rc = launch_pair(e, (const PairItem *)e->d_items.p, (int)n2, common_site_count(e, pit), site_stride, nsplit, d_lj, d_c))) return rc;
     if ((rc = launch_recip(e, (const RecipItem *)e->d_items2.p, (int)n2, n1_max, site_stride, false, e->d_A, d_u))) return rc;
     HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_out.p, 3 * n2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     if ((rc = sync_stream(e))) return rc;
@@ -855,7 +896,7 @@ int mgpu_system_energy(mgpu_engine *e, int replica, double out[6]) {
         HIP_TRY(hipMemcpyAsync(e->d_items.p, items.data(), n * sizeof(PairItem), hipMemcpyHostToDevice, e->stream));
         double *d_lj = (double *)e->d_out.p, *d_c = d_lj + n, *d_in = d_c + n;
         const int nsplit = choose_nsplit(e, n, replica);
-        if ((rc = launch_pair(e, (const PairItem *)e->d_items.p, n, 1, nsplit, d_lj, d_c))) return rc;
+        if ((rc = launch_pair(e, (const PairItem *)e->d_items.p, n, 0, 1, nsplit, d_lj, d_c, true))) return rc;
         hipLaunchKernelGGL(intra_kernel, dim3((n + 63) / 64), dim3(64), 0, e->stream, e->tp, e->bx, e->d_pos, e->d_res_q,
                            (const PairItem *)e->d_items.p, n, (const double *)nullptr, 1, d_in);
         HIP_TRY(hipGetLastError());

@@ -12,6 +12,7 @@
 #include <cstring>
 
 #include "../../include/maniac_gpu.h"
+#include "mgpu_erfc_table.h"
 #include "mgpu_internal.h"
 
 namespace mgpu {
@@ -134,6 +135,23 @@ int mgpu_box_prepare(const double box_matrix[9], int *box_type, double *volume, 
 int mgpu_ewald_setup(const double metrics[9], double *rc, double *tol, double *alpha, double *screening_factor,
                      double *fourier_precision, int kmax[3], int *n_kvectors) {
     return mgpu::ewald_setup(metrics, rc, tol, alpha, screening_factor, fourier_precision, kmax, n_kvectors);
+}
+
+// Host evaluation of the erfc table the pair sweep reads from LDS (same rows, same Horner/FMA order
+// as erfc_lds() in mgpu_kernels.h), so its accuracy can be checked without a GPU.
+int mgpu_erfc_table_eval(int n, const double *x, double *out) {
+    if (n < 0 || (n > 0 && (!x || !out))) return mgpu::set_error(MGPU_ERR_INVALID_ARG, "mgpu_erfc_table_eval: bad argument");
+    for (int k = 0; k < n; ++k) {
+        if (!(x[k] >= 0.0)) return mgpu::set_error(MGPU_ERR_INVALID_ARG, "mgpu_erfc_table_eval: x must be >= 0");
+        const double x32 = x[k] * (double)mgpu::kErfcInvH;
+        const int i = x32 >= (double)(mgpu::kErfcRows - 1) ? mgpu::kErfcRows - 1 : (int)x32;
+        const double t = x32 - (double)i;
+        const double *c = mgpu::kErfcTable + (size_t)i * mgpu::kErfcStride;
+        double p = c[7];
+        for (int j = 6; j >= 0; --j) p = std::fma(p, t, c[j]);
+        out[k] = p;
+    }
+    return MGPU_OK;
 }
 
 int mgpu_ewald_kvectors(const double reciprocal[9], double alpha, const int kmax[3], int n_kvectors, int *kx, int *ky,

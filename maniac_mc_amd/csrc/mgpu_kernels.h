@@ -22,6 +22,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "mgpu_erfc_table.h"
 #include "mgpu_internal.h"
 
 namespace mgpu {
@@ -29,7 +30,9 @@ namespace mgpu {
 constexpr int kMaxRes = 8;        // residue types per engine
 constexpr int kBlock = 256;       // threads per workgroup = 4 waves, one per SIMD
 constexpr int kWavesPerBlock = kBlock / 64;
-constexpr int kSiteChunk = 64;    // candidate sites staged in LDS per pass
+constexpr int kSiteChunk = 32;    // candidate sites staged in LDS per pass (generic path)
+constexpr int kPairBlock = 512;   // pair sweep: 8 persistent waves share one LDS erfc table
+constexpr int kPairWaves = kPairBlock / 64;
 constexpr int kMaxTypes = 16;     // atom types (LDS pair table 16 x 16 x 16 B = 4 KiB)
 
 struct Topo {
@@ -48,6 +51,7 @@ struct BoxDev {
     double rcp[9];                // box%reciprocal, row-major
     double rc2;                   // real_space_cutoff^2
     double alpha;
+    double alpha32;               // alpha * 32: distance -> erfc table coordinate
     double volume;
     int kmax[3];
     int nk;
@@ -82,25 +86,56 @@ __device__ __forceinline__ double min_image(double d, double L, double invL) {
     return fma(-L, rint(d * invL), d);
 }
 
+// 1/sqrt(x): v_rsq_f64 (2^-24 relative) + one Newton step with its second-order term; measured
+// max relative error 1.4e-16 on gfx950 (tools/probe_math.hip), the same as ocml's rsqrt.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
+}
+
+// erfc(x) from the LDS-resident table of degree-7 polynomials on intervals of width 1/32
+// (mgpu_erfc_table.h, generated in 60-digit arithmetic).  x32 = 32 x >= 0.  Each lane gathers its
+// own row with four ds_read_b128 (80-byte row stride spreads rows over all bank groups); no exp,
+// no division, no lane-divergent branch.
+__device__ __forceinline__ double erfc_lds(double x32, const double *__restrict__ tab) {
+    const int i = min((int)x32, kErfcRows - 1);        // row 384 is all zeros: erfc(x >= 12) -> 0
+    const double t = x32 - (double)i;                  // exact: local coordinate in [0, 1)
+    const double2 *row = reinterpret_cast<const double2 *>(tab + i * kErfcStride);
+    const double2 c01 = row[0], c23 = row[1], c45 = row[2], c67 = row[3];
+    double p = c67.y;
+    p = fma(p, t, c67.x);
+    p = fma(p, t, c45.y);
+    p = fma(p, t, c45.x);
+    p = fma(p, t, c23.y);
+    p = fma(p, t, c23.x);
+    p = fma(p, t, c01.y);
+    p = fma(p, t, c01.x);
+    return p;
+}
+
 // One site-atom pair: Lennard-Jones inside the cutoff (energy_utils.f90:417-424) and
-// erfc(alpha r)/r for every distance (energy_utils.f90:427-432).
+// erfc(alpha r)/r for every distance (energy_utils.f90:427-432).  do_lj / do_c are wave-uniform
+// in the plane-major sweep (scalar branches), per-lane in the site-major sweep.
+template <bool GUARD_R0>
 __device__ __forceinline__ void pair_term(double dx, double dy, double dz, const BoxDev &bx, double qq,
-                                          double eps4, double sig2, bool do_lj, bool do_c, bool guard_r0,
-                                          double &elj, double &ec) {
+                                          double eps4, double sig2, bool do_lj, bool do_c,
+                                          const double *__restrict__ erfc_tab, double &elj, double &ec) {
     dx = min_image(dx, bx.L[0], bx.invL[0]);
     dy = min_image(dy, bx.L[1], bx.invL[1]);
     dz = min_image(dz, bx.L[2], bx.invL[2]);
     const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
-    const double rinv = rsqrt(r2);
-    if (do_lj && r2 < bx.rc2) {
+    const double rinv = fast_rsqrt(r2);
+    if (do_lj) {
         const double s2 = sig2 * (rinv * rinv);
         const double s6 = s2 * s2 * s2;
-        elj += eps4 * fma(s6, s6, -s6);
+        const double e = eps4 * fma(s6, s6, -s6);
+        elj += (r2 < bx.rc2) ? e : 0.0;
     }
     if (do_c) {
         const double r = r2 * rinv;
-        double term = qq * (erfc(bx.alpha * r) * rinv);
-        if (guard_r0 && r < kErrorTol) term = 0.0;  // CoulombEnergy, energy_utils.f90:244
+        double term = qq * (erfc_lds(r * bx.alpha32, erfc_tab) * rinv);
+        if (GUARD_R0) term = (r < kErrorTol) ? 0.0 : term;  // CoulombEnergy, energy_utils.f90:244
         ec += term;
     }
 }
@@ -108,112 +143,249 @@ __device__ __forceinline__ void pair_term(double dx, double dy, double dz, const
 // ------------------------------------------------------------------------------------------
 // Pair sweep: ComputePairInteractionEnergy_singlemol (energy_utils.f90:374-442) and, with
 // item.ordered, SingleMolPairwiseEnergy (energy_utils.f90:121-187) for a batch of items.
-// grid = n_items * nsplit workgroups; workgroup (item, split) sweeps every nsplit-th unit of
-// 64 atoms of the item's replica and writes one partial {e_lj, e_coul}.
+//
+// Work unit = (item, split): ONE WAVE sweeps every nsplit-th unit of 64 atoms of the item's
+// replica and writes one partial {e_lj, e_coul}.  Waves are persistent: the grid is sized to the
+// chip and each wave strides over the n_items * nsplit work units, so the 24 KiB erfc table is
+// staged into LDS once per workgroup and no workgroup barrier sits inside the sweep.
+// NS > 0: every item has exactly NS sites, held in registers; NS = 0: any count, staged through a
+// per-wave LDS slab in chunks of kSiteChunk.  ORDERED selects SingleMolPairwiseEnergy semantics
+// (only molecules after the item's, plus CoulombEnergy's r < 1e-10 guard) for the static total.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void pair_sweep_kernel(
+template <int NS, bool ORDERED>
+__global__ __launch_bounds__(kPairBlock) void pair_sweep_kernel(
     Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
-    const PairItem *__restrict__ items, const double *__restrict__ cand_sites, int site_stride, int nsplit,
-    double2 *__restrict__ partials) {
-    __shared__ double s_x[kSiteChunk], s_y[kSiteChunk], s_z[kSiteChunk], s_q[kSiteChunk];
-    __shared__ int s_ty[kSiteChunk];
+    const double *__restrict__ erfc_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
+    int site_stride, int nsplit, int n_work, double2 *__restrict__ partials) {
+    constexpr int NREG = NS > 0 ? NS : 1;                 // register-resident sites
+    constexpr int NSLAB = NS > 0 ? 1 : kPairWaves * kSiteChunk;
+    __shared__ __attribute__((aligned(16))) double s_erfc[kErfcRows * kErfcStride];
     __shared__ double2 s_pair[kMaxTypes * kMaxTypes];
-    __shared__ double s_red[2 * kWavesPerBlock];
+    __shared__ double s_site[NSLAB * 4];
+    __shared__ int s_sty[NSLAB];
 
-    const int item_id = blockIdx.x / nsplit, split = blockIdx.x - item_id * nsplit;
-    const PairItem it = items[item_id];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gw = split * kWavesPerBlock + wave, gstride = nsplit * kWavesPerBlock;
+    for (int i = threadIdx.x; i < kErfcRows * kErfcStride / 2; i += kPairBlock)
+        reinterpret_cast<double2 *>(s_erfc)[i] = reinterpret_cast<const double2 *>(erfc_tab_g)[i];
     const int nt = tp.n_types;
-    const double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
-    const double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
-    const int *nm_r = nmol + it.replica * tp.n_res;
-    const int n1 = tp.n1[it.t];
-    const bool ordered = it.ordered != 0;
+    for (int i = threadIdx.x; i < nt * nt; i += kPairBlock) s_pair[i] = pair_tab[i];
+    __syncthreads();
 
-    for (int i = threadIdx.x; i < nt * nt; i += kBlock) s_pair[i] = pair_tab[i];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_waves = gridDim.x * kPairWaves;
+    double *w_site = s_site + (NS > 0 ? 0 : wave * kSiteChunk * 4);
+    int *w_sty = s_sty + (NS > 0 ? 0 : wave * kSiteChunk);
 
-    double elj = 0.0, ec = 0.0;
-    for (int sb = 0; sb < n1; sb += kSiteChunk) {
-        const int ns = min(kSiteChunk, n1 - sb);
-        __syncthreads();
-        if (threadIdx.x < ns) {
-            const int a = sb + threadIdx.x;
+    for (int w = blockIdx.x * kPairWaves + wave; w < n_work; w += n_waves) {
+        const int item_id = w / nsplit, split = w - item_id * nsplit;
+        const PairItem it = items[item_id];
+        const double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
+        const double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
+        const int *nm_r = nmol + it.replica * tp.n_res;
+        const int n1 = NS > 0 ? NS : tp.n1[it.t];
+        constexpr bool ordered = ORDERED;   // the host puts only one kind of item in a launch
+
+        auto load_site = [&](int a, double &x, double &y, double &z) {
             if (it.src < 0) {
                 const int j = atom_slot(tp, it.t, it.m, a);
-                s_x[threadIdx.x] = px[j]; s_y[threadIdx.x] = py[j]; s_z[threadIdx.x] = pz[j];
+                x = px[j]; y = py[j]; z = pz[j];
             } else {
                 const double *c = cand_sites + ((size_t)it.src * site_stride + a) * 3;
-                s_x[threadIdx.x] = c[0]; s_y[threadIdx.x] = c[1]; s_z[threadIdx.x] = c[2];
+                x = c[0]; y = c[1]; z = c[2];
             }
-            s_q[threadIdx.x] = res_q[it.t * tp.max_atom + a];
-            s_ty[threadIdx.x] = res_atype[it.t * tp.max_atom + a];
+        };
+        double rx[NREG], ry[NREG], rz[NREG], rq[NREG];
+        int rty[NREG];
+        if constexpr (NS > 0) {
+#pragma unroll
+            for (int a = 0; a < NREG; ++a) {
+                load_site(a, rx[a], ry[a], rz[a]);
+                rq[a] = res_q[it.t * tp.max_atom + a];
+                rty[a] = res_atype[it.t * tp.max_atom + a];
+            }
         }
-        __syncthreads();
 
-        for (int t2 = 0; t2 < tp.n_res; ++t2) {
-            if (ordered && t2 < it.t) continue;
-            const int nm = nm_r[t2], n2 = tp.n1[t2];
-            if (nm == 0) continue;
-            const bool same_t = (t2 == it.t) && (it.m >= 0);
-            if (!tp.site_major[t2]) {
-                // plane-major: unit = (site index a2, 64 consecutive molecules)
-                const int cpp = (nm + 63) >> 6, units = n2 * cpp;
-                for (int u = gw; u < units; u += gstride) {
-                    const int a2 = u / cpp, m2 = (u - a2 * cpp) * 64 + lane;
-                    bool valid = m2 < nm;
-                    if (same_t) valid = valid && (ordered ? (m2 > it.m) : (m2 != it.m));
-                    const double qj = res_q[t2 * tp.max_atom + a2];
-                    const int tyj = res_atype[t2 * tp.max_atom + a2];
-                    const bool qj_on = fabs(qj) >= kErrorTol;
-                    double xj = 0.0, yj = 0.0, zj = 0.0;
-                    if (valid) {
-                        const int j = tp.seg_off[t2] + a2 * tp.cap[t2] + m2;
-                        xj = px[j]; yj = py[j]; zj = pz[j];
-                    }
-                    for (int s = 0; s < ns; ++s) {
-                        const double qs = s_q[s];
-                        const double2 pt = s_pair[s_ty[s] * nt + tyj];
-                        const bool do_c = qj_on && (fabs(qs) >= kErrorTol);   // energy_utils.f90:430
-                        const bool do_lj = pt.x != 0.0;                        // epsilon = 0 contributes 0
-                        if (!(do_c || do_lj)) continue;                       // wave-uniform
-                        if (valid)
-                            pair_term(xj - s_x[s], yj - s_y[s], zj - s_z[s], bx, qs * qj, pt.x, pt.y, do_lj, do_c,
-                                      ordered, elj, ec);
-                    }
+        double elj = 0.0, ec = 0.0;
+        for (int sb = 0; sb < n1; sb += kSiteChunk) {
+            const int ns = NS > 0 ? NS : min(kSiteChunk, n1 - sb);
+            if constexpr (NS == 0) {
+                // stage this chunk of sites in the wave's own LDS slab (no workgroup barrier needed)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane < ns) {
+                    double x, y, z;
+                    load_site(sb + lane, x, y, z);
+                    w_site[lane * 4 + 0] = x; w_site[lane * 4 + 1] = y; w_site[lane * 4 + 2] = z;
+                    w_site[lane * 4 + 3] = res_q[it.t * tp.max_atom + sb + lane];
+                    w_sty[lane] = res_atype[it.t * tp.max_atom + sb + lane];
                 }
-            } else {
-                // site-major: unit = (molecule m2, 64 consecutive sites)
-                const int cpp = (n2 + 63) >> 6, units = nm * cpp;
-                for (int u = gw; u < units; u += gstride) {
-                    const int m2 = u / cpp, a2 = (u - m2 * cpp) * 64 + lane;
-                    if (same_t && (ordered ? (m2 <= it.m) : (m2 == it.m))) continue;
-                    if (a2 >= n2) continue;
-                    const int j = tp.seg_off[t2] + m2 * n2 + a2;
-                    const double xj = px[j], yj = py[j], zj = pz[j];
-                    const double qj = res_q[t2 * tp.max_atom + a2];
-                    const int tyj = res_atype[t2 * tp.max_atom + a2];
-                    const bool qj_on = fabs(qj) >= kErrorTol;
-                    for (int s = 0; s < ns; ++s) {
-                        const double qs = s_q[s];
-                        const double2 pt = s_pair[s_ty[s] * nt + tyj];
-                        const bool do_c = qj_on && (fabs(qs) >= kErrorTol);
-                        pair_term(xj - s_x[s], yj - s_y[s], zj - s_z[s], bx, qs * qj, pt.x, pt.y, pt.x != 0.0, do_c,
-                                  ordered, elj, ec);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            for (int t2 = 0, plane_base = 0; t2 < tp.n_res; plane_base += tp.n1[t2], ++t2) {
+                if (ordered && t2 < it.t) continue;
+                const int nm = nm_r[t2], n2 = tp.n1[t2];
+                if (nm == 0) continue;
+                const bool same_t = (t2 == it.t) && (it.m >= 0);
+                if (!tp.site_major[t2]) {
+                    // plane-major: unit = (site index a2, 64 consecutive molecules); q / type uniform
+                    const int cpp = (nm + 63) >> 6;
+                    if constexpr (NS > 0) {
+                        // ---- hot path: branch-free per unit, NS independent dependency chains,
+                        //      next unit's coordinates prefetched while this one computes ----
+                        const int cap2 = tp.cap[t2], seg2 = tp.seg_off[t2];
+                        int dummy_m = 0;   // a live, never-excluded molecule for masked-off lanes to read
+                        if (same_t) {
+                            if (ORDERED) { if (it.m + 1 >= nm) continue; dummy_m = nm - 1; }
+                            else { if (nm == 1) continue; dummy_m = (it.m == 0) ? 1 : 0; }
+                        }
+                        for (int a2 = 0; a2 < n2; ++a2) {
+                            const double qj = res_q[t2 * tp.max_atom + a2];
+                            const int tyj = res_atype[t2 * tp.max_atom + a2];
+                            const bool qj_on = fabs(qj) >= kErrorTol;
+                            double e4[NREG], sg2[NREG], qq[NREG];
+                            bool lj[NREG], c_on[NREG];
+                            bool any_c = false, all_c = true, any_lj = false;
+#pragma unroll
+                            for (int s = 0; s < NREG; ++s) {
+                                const double2 pt = pair_tab[rty[s] * nt + tyj];     // scalar load
+                                e4[s] = pt.x; sg2[s] = pt.y;
+                                lj[s] = pt.x != 0.0;                               // epsilon = 0 contributes 0
+                                c_on[s] = qj_on && (fabs(rq[s]) >= kErrorTol);      // energy_utils.f90:430
+                                qq[s] = c_on[s] ? rq[s] * qj : 0.0;
+                                any_c = any_c || c_on[s]; all_c = all_c && c_on[s]; any_lj = any_lj || lj[s];
+                            }
+                            if (!(any_c || any_lj)) continue;
+                            int c = split - ((plane_base + a2) * cpp) % nsplit;    // units are dealt round-robin
+                            if (c < 0) c += nsplit;
+                            if (c >= cpp) continue;
+                            auto fetch = [&](int cc, double &x, double &y, double &z, bool &ok) {
+                                const int m2 = cc * 64 + lane;
+                                ok = m2 < nm;
+                                if (same_t) ok = ok && (ORDERED ? (m2 > it.m) : (m2 != it.m));
+                                const int j = seg2 + a2 * cap2 + (ok ? m2 : dummy_m);
+                                x = px[j]; y = py[j]; z = pz[j];
+                            };
+                            double acc[NREG];
+#pragma unroll
+                            for (int s = 0; s < NREG; ++s) acc[s] = 0.0;
+                            double xj, yj, zj;
+                            bool valid;
+                            fetch(c, xj, yj, zj, valid);
+                            for (; c < cpp; c += nsplit) {
+                                double xn = xj, yn = yj, zn = zj;
+                                bool vn = false;
+                                if (c + nsplit < cpp) fetch(c + nsplit, xn, yn, zn, vn);
+                                const double wgt = valid ? 1.0 : 0.0;
+                                const double rc2l = valid ? bx.rc2 : -1.0;
+                                double r2[NREG], rinv[NREG];
+#pragma unroll
+                                for (int s = 0; s < NREG; ++s) {
+                                    const double dx = min_image(xj - rx[s], bx.L[0], bx.invL[0]);
+                                    const double dy = min_image(yj - ry[s], bx.L[1], bx.invL[1]);
+                                    const double dz = min_image(zj - rz[s], bx.L[2], bx.invL[2]);
+                                    r2[s] = fma(dz, dz, fma(dy, dy, dx * dx));
+                                    rinv[s] = fast_rsqrt(r2[s]);
+                                }
+                                if (all_c) {
+#pragma unroll
+                                    for (int s = 0; s < NREG; ++s) {
+                                        const double r = r2[s] * rinv[s];
+                                        double e = erfc_lds(r * bx.alpha32, s_erfc) * rinv[s];
+                                        if (ORDERED) e = (r < kErrorTol) ? 0.0 : e;   // energy_utils.f90:244
+                                        acc[s] = fma(wgt, e, acc[s]);
+                                    }
+                                } else if (any_c) {
+#pragma unroll
+                                    for (int s = 0; s < NREG; ++s) {
+                                        if (!c_on[s]) continue;
+                                        const double r = r2[s] * rinv[s];
+                                        double e = erfc_lds(r * bx.alpha32, s_erfc) * rinv[s];
+                                        if (ORDERED) e = (r < kErrorTol) ? 0.0 : e;
+                                        acc[s] = fma(wgt, e, acc[s]);
+                                    }
+                                }
+                                if (any_lj) {
+#pragma unroll
+                                    for (int s = 0; s < NREG; ++s) {
+                                        if (!lj[s]) continue;
+                                        const double s2 = sg2[s] * (rinv[s] * rinv[s]);
+                                        const double s6 = s2 * s2 * s2;
+                                        const double e = e4[s] * fma(s6, s6, -s6);  // energy_utils.f90:421-423
+                                        elj += (r2[s] < rc2l) ? e : 0.0;            // energy_utils.f90:417
+                                    }
+                                }
+                                xj = xn; yj = yn; zj = zn; valid = vn;
+                            }
+#pragma unroll
+                            for (int s = 0; s < NREG; ++s) ec = fma(qq[s], acc[s], ec);
+                        }
+                    } else {
+                        const int units = n2 * cpp;
+                        for (int u = split; u < units; u += nsplit) {
+                            const int a2 = u / cpp, m2 = (u - a2 * cpp) * 64 + lane;
+                            bool valid = m2 < nm;
+                            if (same_t) valid = valid && (ordered ? (m2 > it.m) : (m2 != it.m));
+                            const double qj = res_q[t2 * tp.max_atom + a2];
+                            const int tyj = res_atype[t2 * tp.max_atom + a2];
+                            const bool qj_on = fabs(qj) >= kErrorTol;
+                            double xj = 0.0, yj = 0.0, zj = 0.0;
+                            if (valid) {
+                                const int j = tp.seg_off[t2] + a2 * tp.cap[t2] + m2;
+                                xj = px[j]; yj = py[j]; zj = pz[j];
+                            }
+                            for (int s = 0; s < ns; ++s) {
+                                const double qs = w_site[s * 4 + 3];
+                                const double2 pt = pair_tab[w_sty[s] * nt + tyj];
+                                const bool do_c = qj_on && (fabs(qs) >= kErrorTol);   // energy_utils.f90:430
+                                const bool do_lj = pt.x != 0.0;                        // epsilon = 0 contributes 0
+                                if ((do_c || do_lj) && valid)
+                                    pair_term<ORDERED>(xj - w_site[s * 4 + 0], yj - w_site[s * 4 + 1], zj - w_site[s * 4 + 2],
+                                                       bx, qs * qj, pt.x, pt.y, do_lj, do_c, s_erfc, elj, ec);
+                            }
+                        }
+                    }
+                } else {
+                    // site-major: unit = (molecule m2, 64 consecutive sites); per-lane q / type
+                    const int cpp = (n2 + 63) >> 6, units = nm * cpp;
+                    for (int u = split; u < units; u += nsplit) {
+                        const int m2 = u / cpp, a2 = (u - m2 * cpp) * 64 + lane;
+                        if (same_t && (ordered ? (m2 <= it.m) : (m2 == it.m))) continue;
+                        const bool valid = a2 < n2;
+                        double xj = 0.0, yj = 0.0, zj = 0.0, qj = 0.0;
+                        int tyj = 0;
+                        if (valid) {
+                            const int j = tp.seg_off[t2] + m2 * n2 + a2;
+                            xj = px[j]; yj = py[j]; zj = pz[j];
+                            qj = res_q[t2 * tp.max_atom + a2];
+                            tyj = res_atype[t2 * tp.max_atom + a2];
+                        }
+                        const bool qj_on = fabs(qj) >= kErrorTol;
+                        auto one_site = [&](double sx, double sy, double sz, double qs, int tys) {
+                            const double2 pt = s_pair[tys * nt + tyj];
+                            const bool do_c = qj_on && (fabs(qs) >= kErrorTol);
+                            if (valid) {
+                                double e1 = 0.0, e2 = 0.0;
+                                pair_term<ORDERED>(xj - sx, yj - sy, zj - sz, bx, qs * qj, pt.x, pt.y, true, true, s_erfc, e1, e2);
+                                elj += (pt.x != 0.0) ? e1 : 0.0;
+                                ec += do_c ? e2 : 0.0;
+                            }
+                        };
+                        if constexpr (NS > 0) {
+#pragma unroll
+                            for (int s = 0; s < NREG; ++s) one_site(rx[s], ry[s], rz[s], rq[s], rty[s]);
+                        } else {
+                            for (int s = 0; s < ns; ++s)
+                                one_site(w_site[s * 4 + 0], w_site[s * 4 + 1], w_site[s * 4 + 2], w_site[s * 4 + 3], w_sty[s]);
+                        }
                     }
                 }
             }
         }
-    }
-    elj = wave_sum(elj);
-    ec = wave_sum(ec);
-    if (lane == 0) { s_red[2 * wave] = elj; s_red[2 * wave + 1] = ec; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double a = 0.0, b = 0.0;
-        for (int w = 0; w < kWavesPerBlock; ++w) { a += s_red[2 * w]; b += s_red[2 * w + 1]; }
-        partials[blockIdx.x] = make_double2(a, b);
+        elj = wave_sum(elj);
+        ec = wave_sum(ec);
+        if (lane == 0) partials[w] = make_double2(elj, ec);
     }
 }
 
