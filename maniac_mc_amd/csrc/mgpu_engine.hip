@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -94,6 +95,7 @@ struct mgpu_engine {
     double2 *d_pair_tab = nullptr;
     double *d_erfc_tab = nullptr;    // piecewise-polynomial erfc table (mgpu_erfc_table.h)
     int n_cu = 256;                  // compute units of the device
+    int pair_blocks_per_cu = 2;      // resident pair-sweep workgroups per CU (VGPR / LDS bound)
     double *d_res_q = nullptr;
     int *d_res_atype = nullptr;
     int *d_atom_res = nullptr, *d_atom_mol = nullptr;
@@ -179,11 +181,13 @@ int replica_units(const mgpu_engine *e, int replica) {
 }
 
 int choose_nsplit(const mgpu_engine *e, int n_items, int replica_hint) {
-    // one wave per (item, split).  Aim at >= 4 work units per resident wave slot (n_cu x 32) for
-    // balance, but never give a wave fewer than ~8 sweep units of 64 atoms.
+    // one wave per (item, split).  Aim at ~2 work units per resident wave (n_cu x 16): fewer, longer
+    // sweeps amortise the per-plane setup (measured: nsplit 2-4 beats 8-32 at 2048 items), but never
+    // give a wave fewer than ~8 sweep units of 64 atoms.
     const int units = std::max(1, replica_units(e, replica_hint));
     const int max_split = std::max(1, units / 8);
-    const int want = (4 * e->n_cu * 32 + n_items - 1) / std::max(1, n_items);
+    const int want = (2 * e->n_cu * 16 + n_items - 1) / std::max(1, n_items);
+    if (const char *ov = std::getenv("MGPU_PAIR_NSPLIT")) return std::max(1, std::min(std::atoi(ov), std::max(1, units)));
     return std::max(1, std::min(want, max_split));
 }
 
@@ -205,7 +209,9 @@ int launch_pair(mgpu_engine *e, const PairItem *d_items, int n_items, int common
     if (rc) return rc;
     // persistent waves: at most 3 workgroups of 8 waves per CU (LDS: 3 x ~31 KiB), never more
     // workgroups than there is work for
-    const int grid = std::max(1, std::min((n_work + kPairWaves - 1) / kPairWaves, e->n_cu * 3));
+    int per_cu = e->pair_blocks_per_cu;
+    if (const char *ov = std::getenv("MGPU_PAIR_BLOCKS_PER_CU")) per_cu = std::max(1, std::atoi(ov));
+    const int grid = std::max(1, std::min((n_work + kPairWaves - 1) / kPairWaves, e->n_cu * per_cu));
     hipEvent_t a = nullptr, b = nullptr;
     rc = prof_begin(e, MGPU_KERNEL_PAIR, &a, &b);
     if (rc) return rc;

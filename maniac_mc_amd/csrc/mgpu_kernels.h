@@ -22,6 +22,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "mgpu_erfc_table.h"
 #include "mgpu_internal.h"
 
@@ -31,7 +33,13 @@ constexpr int kMaxRes = 8;        // residue types per engine
 constexpr int kBlock = 256;       // threads per workgroup = 4 waves, one per SIMD
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kSiteChunk = 32;    // candidate sites staged in LDS per pass (generic path)
-constexpr int kPairBlock = 512;   // pair sweep: 8 persistent waves share one LDS erfc table
+#ifndef MGPU_PAIR_BLOCK
+#define MGPU_PAIR_BLOCK 512
+#endif
+#ifndef MGPU_PAIR_MINWAVES
+#define MGPU_PAIR_MINWAVES 4   // <= 128 VGPRs: two 8-wave workgroups per CU (measured best, tools/bench_kernels.py)
+#endif
+constexpr int kPairBlock = MGPU_PAIR_BLOCK;   // pair sweep: persistent waves share one LDS erfc table
 constexpr int kPairWaves = kPairBlock / 64;
 constexpr int kMaxTypes = 16;     // atom types (LDS pair table 16 x 16 x 16 B = 4 KiB)
 
@@ -101,7 +109,7 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 __device__ __forceinline__ double erfc_lds(double x32, const double *__restrict__ tab) {
     const int i = min((int)x32, kErfcRows - 1);        // row 384 is all zeros: erfc(x >= 12) -> 0
     const double t = x32 - (double)i;                  // exact: local coordinate in [0, 1)
-    const double2 *row = reinterpret_cast<const double2 *>(tab + i * kErfcStride);
+    const double2 *row = reinterpret_cast<const double2 *>(tab + __umul24(i, kErfcStride));
     const double2 c01 = row[0], c23 = row[1], c45 = row[2], c67 = row[3];
     double p = c67.y;
     p = fma(p, t, c67.x);
@@ -153,7 +161,7 @@ __device__ __forceinline__ void pair_term(double dx, double dy, double dz, const
 // (only molecules after the item's, plus CoulombEnergy's r < 1e-10 guard) for the static total.
 // ------------------------------------------------------------------------------------------
 template <int NS, bool ORDERED>
-__global__ __launch_bounds__(kPairBlock) void pair_sweep_kernel(
+__global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_kernel(
     Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
     const double *__restrict__ erfc_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
@@ -270,54 +278,50 @@ __global__ __launch_bounds__(kPairBlock) void pair_sweep_kernel(
                             double acc[NREG];
 #pragma unroll
                             for (int s = 0; s < NREG; ++s) acc[s] = 0.0;
-                            double xj, yj, zj;
-                            bool valid;
-                            fetch(c, xj, yj, zj, valid);
-                            for (; c < cpp; c += nsplit) {
-                                double xn = xj, yn = yj, zn = zj;
-                                bool vn = false;
-                                if (c + nsplit < cpp) fetch(c + nsplit, xn, yn, zn, vn);
-                                const double wgt = valid ? 1.0 : 0.0;
-                                const double rc2l = valid ? bx.rc2 : -1.0;
-                                double r2[NREG], rinv[NREG];
-#pragma unroll
-                                for (int s = 0; s < NREG; ++s) {
-                                    const double dx = min_image(xj - rx[s], bx.L[0], bx.invL[0]);
-                                    const double dy = min_image(yj - ry[s], bx.L[1], bx.invL[1]);
-                                    const double dz = min_image(zj - rz[s], bx.L[2], bx.invL[2]);
-                                    r2[s] = fma(dz, dz, fma(dy, dy, dx * dx));
-                                    rinv[s] = fast_rsqrt(r2[s]);
-                                }
-                                if (all_c) {
+                            // ALL_C: every site is charged -> the NS Coulomb chains form one basic block
+                            auto sweep_plane = [&](auto all_tag) {
+                                constexpr bool ALL_C = decltype(all_tag)::value;
+                                double xj, yj, zj;
+                                bool valid;
+                                fetch(c, xj, yj, zj, valid);
+                                for (; c < cpp; c += nsplit) {
+                                    double xn = xj, yn = yj, zn = zj;
+                                    bool vn = false;
+                                    if (c + nsplit < cpp) fetch(c + nsplit, xn, yn, zn, vn);
+                                    const double wgt = valid ? 1.0 : 0.0;
+                                    const double rc2l = valid ? bx.rc2 : -1.0;
+                                    double r2[NREG], rinv[NREG];
 #pragma unroll
                                     for (int s = 0; s < NREG; ++s) {
+                                        const double dx = min_image(xj - rx[s], bx.L[0], bx.invL[0]);
+                                        const double dy = min_image(yj - ry[s], bx.L[1], bx.invL[1]);
+                                        const double dz = min_image(zj - rz[s], bx.L[2], bx.invL[2]);
+                                        r2[s] = fma(dz, dz, fma(dy, dy, dx * dx));
+                                        rinv[s] = fast_rsqrt(r2[s]);
+                                    }
+#pragma unroll
+                                    for (int s = 0; s < NREG; ++s) {
+                                        if (!ALL_C && !c_on[s]) continue;
                                         const double r = r2[s] * rinv[s];
                                         double e = erfc_lds(r * bx.alpha32, s_erfc) * rinv[s];
                                         if (ORDERED) e = (r < kErrorTol) ? 0.0 : e;   // energy_utils.f90:244
                                         acc[s] = fma(wgt, e, acc[s]);
                                     }
-                                } else if (any_c) {
+                                    if (any_lj) {
 #pragma unroll
-                                    for (int s = 0; s < NREG; ++s) {
-                                        if (!c_on[s]) continue;
-                                        const double r = r2[s] * rinv[s];
-                                        double e = erfc_lds(r * bx.alpha32, s_erfc) * rinv[s];
-                                        if (ORDERED) e = (r < kErrorTol) ? 0.0 : e;
-                                        acc[s] = fma(wgt, e, acc[s]);
+                                        for (int s = 0; s < NREG; ++s) {
+                                            if (!lj[s]) continue;
+                                            const double s2 = sg2[s] * (rinv[s] * rinv[s]);
+                                            const double s6 = s2 * s2 * s2;
+                                            const double e = e4[s] * fma(s6, s6, -s6);  // energy_utils.f90:421-423
+                                            elj += (r2[s] < rc2l) ? e : 0.0;            // energy_utils.f90:417
+                                        }
                                     }
+                                    xj = xn; yj = yn; zj = zn; valid = vn;
                                 }
-                                if (any_lj) {
-#pragma unroll
-                                    for (int s = 0; s < NREG; ++s) {
-                                        if (!lj[s]) continue;
-                                        const double s2 = sg2[s] * (rinv[s] * rinv[s]);
-                                        const double s6 = s2 * s2 * s2;
-                                        const double e = e4[s] * fma(s6, s6, -s6);  // energy_utils.f90:421-423
-                                        elj += (r2[s] < rc2l) ? e : 0.0;            // energy_utils.f90:417
-                                    }
-                                }
-                                xj = xn; yj = yn; zj = zn; valid = vn;
-                            }
+                            };
+                            if (all_c) sweep_plane(std::true_type{});
+                            else sweep_plane(std::false_type{});
 #pragma unroll
                             for (int s = 0; s < NREG; ++s) ec = fma(qq[s], acc[s], ec);
                         }
