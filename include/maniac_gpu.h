@@ -204,6 +204,19 @@ int mgpu_commit_candidates(mgpu_engine *e, int n_candidates, const int *replica,
                            const int *m, const int *kind, const double *sites, int site_stride,
                            const int *accept);
 
+/* Asynchronous forms of the two calls above, so that the host's Metropolis work on one group of
+ * replicas overlaps the GPU's evaluation of another.  The engine has MGPU_LANES submission lanes,
+ * each a HIP stream with private scratch; work on different lanes may run concurrently and must
+ * touch disjoint replicas.  submit returns once copies and kernels are queued; wait blocks for the
+ * lane and returns the energies; a commit is ordered before any later submit on the same lane. */
+#define MGPU_LANES 2
+int mgpu_trial_submit(mgpu_engine *e, int lane, int n_candidates, const int *replica, const int *t,
+                      const int *m, const double *sites, int site_stride);
+int mgpu_trial_wait(mgpu_engine *e, int lane, double *old_energy, double *new_energy);
+int mgpu_commit_submit(mgpu_engine *e, int lane, int n_candidates, const int *replica, const int *t,
+                       const int *m, const int *kind, const double *sites, int site_stride,
+                       const int *accept);
+
 /* ReplaceFourierTermsSingleMol + the coordinate copy of RemoveMolecule (ewald_phase.f90:276-322,
  * delete_molecule.f90:99-116): slot m_dst <- slot m_src. */
 int mgpu_replica_replace_molecule(mgpu_engine *e, int replica, int t, int m_dst, int m_src);

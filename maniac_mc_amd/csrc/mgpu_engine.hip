@@ -67,6 +67,22 @@ struct ProfileSlot {
     double total_ms = 0.0;
 };
 
+// One submission lane: a HIP stream with its own scratch, so that work queued on one lane (for
+// one group of replicas) overlaps the host's processing of the other lane's results.
+struct Lane {
+    hipStream_t stream = nullptr;
+    DevBuf d_items, d_items2, d_sites, d_partials, d_out;
+    HostBuf h_in, h_commit, h_out;   // pinned staging: trial inputs, commit inputs, results
+    struct Pending { int kernel; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    int n_submitted = 0;          // candidates of the trial in flight (0 = none)
+    void release() {
+        d_items.release(); d_items2.release(); d_sites.release(); d_partials.release(); d_out.release();
+        h_in.release(); h_commit.release(); h_out.release();
+    }
+};
+constexpr int kLanes = 2;
+
 }  // namespace mgpu
 
 using namespace mgpu;
@@ -74,7 +90,7 @@ using namespace mgpu;
 struct mgpu_engine {
     int device = 0;
     int n_replicas = 0;
-    hipStream_t stream = nullptr;
+    Lane lanes[kLanes];
     Topo tp{};
     BoxDev bx{};
     // host copies
@@ -102,15 +118,16 @@ struct mgpu_engine {
     double *d_atom_q = nullptr;
     double2 *d_phase_tab = nullptr;  // [ktot][Ncap] scratch for S(k)
     double2 *d_S = nullptr;          // [Nk] scratch
-    // scratch
-    DevBuf d_items, d_items2, d_sites, d_partials, d_out;
-    HostBuf h_stage, h_out;
+    // lane 0 doubles as the synchronous path's stream and scratch
+    hipStream_t &stream = lanes[0].stream;
+    DevBuf &d_items = lanes[0].d_items, &d_items2 = lanes[0].d_items2, &d_sites = lanes[0].d_sites,
+           &d_partials = lanes[0].d_partials, &d_out = lanes[0].d_out;
+    HostBuf &h_out = lanes[0].h_out;
+    HostBuf h_stage;
     // profiling
     bool profiling = false;
     ProfileSlot prof[MGPU_KERNEL_COUNT];
     std::vector<hipEvent_t> ev_pool;
-    struct Pending { int kernel; hipEvent_t a, b; };
-    std::vector<Pending> pending;
 };
 
 namespace {
@@ -120,25 +137,25 @@ int use_device(const mgpu_engine *e) {
     return MGPU_OK;
 }
 
-int prof_begin(mgpu_engine *e, int kernel, hipEvent_t *a, hipEvent_t *b) {
+int prof_begin(mgpu_engine *e, Lane &ln, int kernel, hipEvent_t *a, hipEvent_t *b) {
     if (!e->profiling) return MGPU_OK;
     for (hipEvent_t *ev : {a, b}) {
         if (!e->ev_pool.empty()) { *ev = e->ev_pool.back(); e->ev_pool.pop_back(); }
         else HIP_TRY(hipEventCreate(ev));
     }
-    HIP_TRY(hipEventRecord(*a, e->stream));
+    HIP_TRY(hipEventRecord(*a, ln.stream));
     (void)kernel;
     return MGPU_OK;
 }
-int prof_end(mgpu_engine *e, int kernel, hipEvent_t a, hipEvent_t b) {
+int prof_end(mgpu_engine *e, Lane &ln, int kernel, hipEvent_t a, hipEvent_t b) {
     if (!e->profiling) return MGPU_OK;
-    HIP_TRY(hipEventRecord(b, e->stream));
-    e->pending.push_back({kernel, a, b});
+    HIP_TRY(hipEventRecord(b, ln.stream));
+    ln.pending.push_back({kernel, a, b});
     return MGPU_OK;
 }
 // after a stream synchronise: fold the recorded event pairs into the per-kernel totals
-int prof_collect(mgpu_engine *e) {
-    for (auto &p : e->pending) {
+int prof_collect(mgpu_engine *e, Lane &ln) {
+    for (auto &p : ln.pending) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
         e->prof[p.kernel].launches += 1;
@@ -146,14 +163,15 @@ int prof_collect(mgpu_engine *e) {
         e->ev_pool.push_back(p.a);
         e->ev_pool.push_back(p.b);
     }
-    e->pending.clear();
+    ln.pending.clear();
     return MGPU_OK;
 }
 
-int sync_stream(mgpu_engine *e) {
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    return prof_collect(e);
+int sync_lane(mgpu_engine *e, Lane &ln) {
+    HIP_TRY(hipStreamSynchronize(ln.stream));
+    return prof_collect(e, ln);
 }
+int sync_stream(mgpu_engine *e) { return sync_lane(e, e->lanes[0]); }
 
 int check_candidate(const mgpu_engine *e, int c, int replica, int t, int m, bool need_resident) {
     if (replica < 0 || replica >= e->n_replicas)
@@ -191,21 +209,24 @@ int choose_nsplit(const mgpu_engine *e, int n_items, int replica_hint) {
     return std::max(1, std::min(want, max_split));
 }
 
-int upload_sites(mgpu_engine *e, const double *sites, int n_rows, int site_stride) {
+int upload_sites(Lane &ln, const double *sites, int n_rows, int site_stride) {
     if (!sites || n_rows == 0) return MGPU_OK;
     const size_t bytes = (size_t)n_rows * site_stride * 3 * sizeof(double);
-    int rc = e->d_sites.reserve(bytes);
+    int rc = ln.d_sites.reserve(bytes);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(e->d_sites.p, sites, bytes, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(ln.d_sites.p, sites, bytes, hipMemcpyHostToDevice, ln.stream));
     return MGPU_OK;
+}
+int upload_sites(mgpu_engine *e, const double *sites, int n_rows, int site_stride) {
+    return upload_sites(e->lanes[0], sites, n_rows, site_stride);
 }
 
 // launch the pair sweep + finalize for items already on the device; results land in d_lj / d_c.
 // common_n1 = number of sites when every item has the same count (register path for <= 4), else 0.
-int launch_pair(mgpu_engine *e, const PairItem *d_items, int n_items, int common_n1, int site_stride, int nsplit,
-                double *d_lj, double *d_c, bool ordered = false) {
+int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, int common_n1, int site_stride,
+                int nsplit, double *d_lj, double *d_c, bool ordered = false) {
     const int n_work = n_items * nsplit;
-    int rc = e->d_partials.reserve((size_t)n_work * sizeof(double2));
+    int rc = ln.d_partials.reserve((size_t)n_work * sizeof(double2));
     if (rc) return rc;
     // persistent waves: at most 3 workgroups of 8 waves per CU (LDS: 3 x ~31 KiB), never more
     // workgroups than there is work for
@@ -213,12 +234,12 @@ int launch_pair(mgpu_engine *e, const PairItem *d_items, int n_items, int common
     if (const char *ov = std::getenv("MGPU_PAIR_BLOCKS_PER_CU")) per_cu = std::max(1, std::atoi(ov));
     const int grid = std::max(1, std::min((n_work + kPairWaves - 1) / kPairWaves, e->n_cu * per_cu));
     hipEvent_t a = nullptr, b = nullptr;
-    rc = prof_begin(e, MGPU_KERNEL_PAIR, &a, &b);
+    rc = prof_begin(e, ln, MGPU_KERNEL_PAIR, &a, &b);
     if (rc) return rc;
 #define MGPU_LAUNCH_PAIR(NS, ORD)                                                                                       \
-    hipLaunchKernelGGL((pair_sweep_kernel<NS, ORD>), dim3(grid), dim3(kPairBlock), 0, e->stream, e->tp, e->bx,          \
+    hipLaunchKernelGGL((pair_sweep_kernel<NS, ORD>), dim3(grid), dim3(kPairBlock), 0, ln.stream, e->tp, e->bx,          \
                        e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_erfc_tab, d_items,          \
-                       (const double *)e->d_sites.p, site_stride, nsplit, n_work, (double2 *)e->d_partials.p)
+                       (const double *)ln.d_sites.p, site_stride, nsplit, n_work, (double2 *)ln.d_partials.p)
     if (ordered) {
         MGPU_LAUNCH_PAIR(0, true);
     } else {
@@ -231,10 +252,10 @@ int launch_pair(mgpu_engine *e, const PairItem *d_items, int n_items, int common
         }
     }
 #undef MGPU_LAUNCH_PAIR
-    rc = prof_end(e, MGPU_KERNEL_PAIR, a, b);
+    rc = prof_end(e, ln, MGPU_KERNEL_PAIR, a, b);
     if (rc) return rc;
-    hipLaunchKernelGGL(pair_finalize_kernel, dim3((n_items + 255) / 256), dim3(256), 0, e->stream,
-                       (const double2 *)e->d_partials.p, n_items, nsplit, d_lj, d_c);
+    hipLaunchKernelGGL(pair_finalize_kernel, dim3((n_items + 255) / 256), dim3(256), 0, ln.stream,
+                       (const double2 *)ln.d_partials.p, n_items, nsplit, d_lj, d_c);
     HIP_TRY(hipGetLastError());
     return MGPU_OK;
 }
@@ -256,25 +277,25 @@ size_t recip_lds_bytes(const mgpu_engine *e, int n1_max) {
     return (size_t)2 * n1_max * ktot * sizeof(double2);
 }
 
-int launch_recip(mgpu_engine *e, const RecipItem *d_items, int n_items, int n1_max, int site_stride, bool commit,
-                 double2 *A_base, double *d_u) {
+int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items, int n1_max, int site_stride,
+                 bool commit, double2 *A_base, double *d_u) {
     const size_t lds = recip_lds_bytes(e, n1_max);
     if (lds > 64 * 1024)
         return set_error(MGPU_ERR_CAPACITY, "reciprocal update: molecule too large for the LDS phase tables (" +
                                                 std::to_string(lds) + " B > 64 KiB)");
     hipEvent_t a = nullptr, b = nullptr;
     const int slot = commit ? MGPU_KERNEL_COMMIT : MGPU_KERNEL_RECIP;
-    int rc = prof_begin(e, slot, &a, &b);
+    int rc = prof_begin(e, ln, slot, &a, &b);
     if (rc) return rc;
     if (commit)
-        hipLaunchKernelGGL(recip_kernel<true>, dim3(n_items), dim3(kBlock), lds, e->stream, e->tp, e->bx, e->d_pos,
-                           e->d_nmol, e->d_res_q, e->d_kpack, e->d_kw, A_base, d_items, (const double *)e->d_sites.p,
+        hipLaunchKernelGGL(recip_kernel<true>, dim3(n_items), dim3(kBlock), lds, ln.stream, e->tp, e->bx, e->d_pos,
+                           e->d_nmol, e->d_res_q, e->d_kpack, e->d_kw, A_base, d_items, (const double *)ln.d_sites.p,
                            site_stride, d_u);
     else
-        hipLaunchKernelGGL(recip_kernel<false>, dim3(n_items), dim3(kBlock), lds, e->stream, e->tp, e->bx, e->d_pos,
-                           e->d_nmol, e->d_res_q, e->d_kpack, e->d_kw, A_base, d_items, (const double *)e->d_sites.p,
+        hipLaunchKernelGGL(recip_kernel<false>, dim3(n_items), dim3(kBlock), lds, ln.stream, e->tp, e->bx, e->d_pos,
+                           e->d_nmol, e->d_res_q, e->d_kpack, e->d_kw, A_base, d_items, (const double *)ln.d_sites.p,
                            site_stride, d_u);
-    rc = prof_end(e, slot, a, b);
+    rc = prof_end(e, ln, slot, a, b);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return MGPU_OK;
@@ -284,13 +305,13 @@ int launch_recip(mgpu_engine *e, const RecipItem *d_items, int n_items, int n1_m
 int launch_sfactor(mgpu_engine *e, int replica, double2 *dst) {
     const int ncap = e->tp.n_cap_atoms;
     hipEvent_t a = nullptr, b = nullptr;
-    int rc = prof_begin(e, MGPU_KERNEL_SFACTOR, &a, &b);
+    int rc = prof_begin(e, e->lanes[0], MGPU_KERNEL_SFACTOR, &a, &b);
     if (rc) return rc;
     hipLaunchKernelGGL(phase_table_kernel, dim3((ncap + 255) / 256), dim3(256), 0, e->stream, e->tp, e->bx, e->d_pos,
                        e->d_nmol, e->d_atom_res, e->d_atom_mol, replica, e->d_phase_tab);
     hipLaunchKernelGGL(sfactor_kernel, dim3(e->nk), dim3(kBlock), 0, e->stream, e->tp, e->bx, e->d_nmol, e->d_atom_res,
                        e->d_atom_mol, e->d_atom_q, e->d_kpack, replica, e->d_phase_tab, dst);
-    rc = prof_end(e, MGPU_KERNEL_SFACTOR, a, b);
+    rc = prof_end(e, e->lanes[0], MGPU_KERNEL_SFACTOR, a, b);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return MGPU_OK;
@@ -441,7 +462,7 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
             return fail(set_error(MGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(err__)));          \
     } while (0)
     HIP_TRY_E(hipSetDevice(device));
-    HIP_TRY_E(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (auto &ln : e->lanes) HIP_TRY_E(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
     const size_t ncap = tp.n_cap_atoms, R = n_replicas;
     const int ktot = e->kmax[0] + e->kmax[1] + e->kmax[2] + 3;
     HIP_TRY_E(hipMalloc(&e->d_pos, R * 3 * ncap * sizeof(double)));
@@ -483,16 +504,18 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
 int mgpu_engine_destroy(mgpu_engine *e) {
     if (!e) return MGPU_OK;
     (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto &ln : e->lanes) if (ln.stream) (void)hipStreamSynchronize(ln.stream);
     for (void *p : {(void *)e->d_pos, (void *)e->d_nmol, (void *)e->d_A, (void *)e->d_kpack, (void *)e->d_kw,
                     (void *)e->d_pair_tab, (void *)e->d_erfc_tab, (void *)e->d_res_q, (void *)e->d_res_atype, (void *)e->d_atom_res,
                     (void *)e->d_atom_mol, (void *)e->d_atom_q, (void *)e->d_phase_tab, (void *)e->d_S})
         if (p) (void)hipFree(p);
-    e->d_items.release(); e->d_items2.release(); e->d_sites.release(); e->d_partials.release(); e->d_out.release();
-    e->h_stage.release(); e->h_out.release();
-    for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    e->h_stage.release();
+    for (auto &ln : e->lanes) {
+        ln.release();
+        for (auto &p : ln.pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        if (ln.stream) (void)hipStreamDestroy(ln.stream);
+    }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return MGPU_OK;
 }
@@ -703,7 +726,7 @@ int mgpu_pair_energy_candidates(mgpu_engine *e, int n, const int *replica, const
     if (any_sites && (rc = upload_sites(e, sites, n, site_stride))) return rc;
     double *d_lj = (double *)e->d_out.p, *d_c = d_lj + n;
     const int nsplit = choose_nsplit(e, n, replica[0]);
-    if ((rc = launch_pair(e, (const PairItem *)e->d_items.p, n, common_site_count(e, items), site_stride, nsplit, d_lj, d_c))) return rc;
+    if ((rc = launch_pair(e, e->lanes[0], (const PairItem *)e->d_items.p, n, common_site_count(e, items), site_stride, nsplit, d_lj, d_c))) return rc;
     HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_out.p, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     if ((rc = sync_stream(e))) return rc;
     std::memcpy(e_nc, e->h_out.p, n * sizeof(double));
@@ -739,7 +762,7 @@ int mgpu_recip_energy_candidates(mgpu_engine *e, int n, const int *replica, cons
     if ((rc = e->h_out.reserve((size_t)n * sizeof(double)))) return rc;
     HIP_TRY(hipMemcpyAsync(e->d_items2.p, items.data(), n * sizeof(RecipItem), hipMemcpyHostToDevice, e->stream));
     if (any_sites && (rc = upload_sites(e, sites, n, site_stride))) return rc;
-    if ((rc = launch_recip(e, (const RecipItem *)e->d_items2.p, n, n1_max, site_stride, false, e->d_A, (double *)e->d_out.p)))
+    if ((rc = launch_recip(e, e->lanes[0], (const RecipItem *)e->d_items2.p, n, n1_max, site_stride, false, e->d_A, (double *)e->d_out.p)))
         return rc;
     HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     if ((rc = sync_stream(e))) return rc;
@@ -787,42 +810,60 @@ int mgpu_intra_energy_candidates(mgpu_engine *e, int n, const int *replica, cons
     return MGPU_OK;
 }
 
-int mgpu_trial_energy_candidates(mgpu_engine *e, int n, const int *replica, const int *t, const int *m,
-                                 const double *sites, int site_stride, double *old_energy, double *new_energy) {
-    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
-    if (n == 0) return MGPU_OK;
-    if (n < 0 || !replica || !t || !m || !sites || !old_energy || !new_energy)
-        return set_error(MGPU_ERR_INVALID_ARG, "trial_energy_candidates: bad argument");
-    int rc = use_device(e);
-    if (rc) return rc;
+// Queue one translation / rotation trial per candidate on a lane: inputs are staged through pinned
+// host memory, so the call returns as soon as the copies and the four kernels are enqueued.
+static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica, const int *t, const int *m,
+                             const double *sites, int site_stride) {
+    if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "trial_submit: the lane still holds an un-waited trial");
+    int rc;
+    const size_t n2 = 2 * (size_t)n;
+    const size_t site_bytes = (size_t)n * site_stride * 3 * sizeof(double);
+    const size_t pit_bytes = n2 * sizeof(PairItem), rit_bytes = n2 * sizeof(RecipItem);
+    if ((rc = ln.h_in.reserve(site_bytes + pit_bytes + rit_bytes))) return rc;
+    double *h_sites = (double *)ln.h_in.p;
+    PairItem *pit = (PairItem *)((char *)ln.h_in.p + site_bytes);
+    RecipItem *rit = (RecipItem *)((char *)ln.h_in.p + site_bytes + pit_bytes);
     // items [0, n): old state (resident sites, A unchanged); items [n, 2n): new state
-    std::vector<PairItem> pit(2 * (size_t)n);
-    std::vector<RecipItem> rit(2 * (size_t)n);
-    int n1_max = 1;
+    int n1_max = 1, common = -1;
     for (int c = 0; c < n; ++c) {
         if ((rc = check_candidate(e, c, replica[c], t[c], m[c], true))) return rc;
-        if (e->tp.n1[t[c]] > site_stride) return set_error(MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res");
-        n1_max = std::max(n1_max, e->tp.n1[t[c]]);
+        const int n1 = e->tp.n1[t[c]];
+        if (n1 > site_stride) return set_error(MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res");
+        n1_max = std::max(n1_max, n1);
+        common = (common == -1 || common == n1) ? n1 : 0;
         pit[c] = PairItem{replica[c], t[c], m[c], -1, 0};
         pit[n + c] = PairItem{replica[c], t[c], m[c], c, 0};
         rit[c] = RecipItem{replica[c], t[c], m[c], MGPU_NONE, -1, 0};
         rit[n + c] = RecipItem{replica[c], t[c], m[c], MGPU_MOVE, c, 0};
     }
-    const size_t n2 = 2 * (size_t)n;
-    if ((rc = e->d_items.reserve(n2 * sizeof(PairItem)))) return rc;
-    if ((rc = e->d_items2.reserve(n2 * sizeof(RecipItem)))) return rc;
-    if ((rc = e->d_out.reserve(3 * n2 * sizeof(double)))) return rc;
-    if ((rc = e->h_out.reserve(3 * n2 * sizeof(double)))) return rc;
-    HIP_TRY(hipMemcpyAsync(e->d_items.p, pit.data(), n2 * sizeof(PairItem), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->d_items2.p, rit.data(), n2 * sizeof(RecipItem), hipMemcpyHostToDevice, e->stream));
-    if ((rc = upload_sites(e, sites, n, site_stride))) return rc;
-    double *d_lj = (double *)e->d_out.p, *d_c = d_lj + n2, *d_u = d_c + n2;
+    std::memcpy(h_sites, sites, site_bytes);
+    if ((rc = ln.d_items.reserve(pit_bytes))) return rc;
+    if ((rc = ln.d_items2.reserve(rit_bytes))) return rc;
+    if ((rc = ln.d_sites.reserve(site_bytes))) return rc;
+    if ((rc = ln.d_out.reserve(3 * n2 * sizeof(double)))) return rc;
+    if ((rc = ln.h_out.reserve(3 * n2 * sizeof(double)))) return rc;
+    HIP_TRY(hipMemcpyAsync(ln.d_sites.p, h_sites, site_bytes, hipMemcpyHostToDevice, ln.stream));
+    HIP_TRY(hipMemcpyAsync(ln.d_items.p, pit, pit_bytes, hipMemcpyHostToDevice, ln.stream));
+    HIP_TRY(hipMemcpyAsync(ln.d_items2.p, rit, rit_bytes, hipMemcpyHostToDevice, ln.stream));
+    double *d_lj = (double *)ln.d_out.p, *d_c = d_lj + n2, *d_u = d_c + n2;
     const int nsplit = choose_nsplit(e, (int)n2, replica[0]);
-    if ((rc = launch_pair(e, (const PairItem *)e->d_items.p, (int)n2, common_site_count(e, pit), site_stride, nsplit, d_lj, d_c))) return rc;
-    if ((rc = launch_recip(e, (const RecipItem *)e->d_items2.p, (int)n2, n1_max, site_stride, false, e->d_A, d_u))) return rc;
-    HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_out.p, 3 * n2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    if ((rc = sync_stream(e))) return rc;
-    const double *h = (const double *)e->h_out.p;
+    if ((rc = launch_pair(e, ln, (const PairItem *)ln.d_items.p, (int)n2, std::max(common, 0), site_stride, nsplit, d_lj, d_c)))
+        return rc;
+    if ((rc = launch_recip(e, ln, (const RecipItem *)ln.d_items2.p, (int)n2, n1_max, site_stride, false, e->d_A, d_u)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(ln.h_out.p, ln.d_out.p, 3 * n2 * sizeof(double), hipMemcpyDeviceToHost, ln.stream));
+    ln.n_submitted = n;
+    return MGPU_OK;
+}
+
+static int trial_wait_impl(mgpu_engine *e, Lane &ln, double *old_energy, double *new_energy) {
+    const int n = ln.n_submitted;
+    if (n == 0) return set_error(MGPU_ERR_STATE, "trial_wait: nothing was submitted on this lane");
+    ln.n_submitted = 0;
+    int rc = sync_lane(e, ln);
+    if (rc) return rc;
+    const size_t n2 = 2 * (size_t)n;
+    const double *h = (const double *)ln.h_out.p;
     for (int c = 0; c < n; ++c) {
         old_energy[3 * c + 0] = h[c];          old_energy[3 * c + 1] = h[n2 + c];     old_energy[3 * c + 2] = h[2 * n2 + c];
         new_energy[3 * c + 0] = h[n + c];      new_energy[3 * c + 1] = h[n2 + n + c]; new_energy[3 * c + 2] = h[2 * n2 + n + c];
@@ -830,14 +871,16 @@ int mgpu_trial_energy_candidates(mgpu_engine *e, int n, const int *replica, cons
     return MGPU_OK;
 }
 
-int mgpu_commit_candidates(mgpu_engine *e, int n, const int *replica, const int *t, const int *m, const int *kind,
-                           const double *sites, int site_stride, const int *accept) {
-    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
-    if (n == 0) return MGPU_OK;
-    if (n < 0 || !replica || !t || !m || !kind || !accept) return set_error(MGPU_ERR_INVALID_ARG, "commit_candidates: bad argument");
-    int rc = use_device(e);
-    if (rc) return rc;
-    std::vector<RecipItem> items;
+// Queue the commit of the accepted candidates on a lane (no synchronisation).  The host-side
+// molecule counts are updated immediately; the device applies them in stream order.
+static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica, const int *t, const int *m,
+                              const int *kind, const double *sites, int site_stride, const int *accept) {
+    int rc;
+    const size_t site_bytes = sites ? (size_t)n * site_stride * 3 * sizeof(double) : 0;
+    if ((rc = ln.h_commit.reserve(site_bytes + (size_t)n * sizeof(RecipItem)))) return rc;
+    if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "commit_submit: wait for the lane's trial first");
+    RecipItem *items = (RecipItem *)((char *)ln.h_commit.p + site_bytes);
+    int n_items = 0;
     std::vector<char> seen(e->n_replicas, 0);
     std::vector<int> new_counts;  // (index into h_nmol, value) pairs applied after validation
     bool any_sites = false;
@@ -853,7 +896,7 @@ int mgpu_commit_candidates(mgpu_engine *e, int n, const int *replica, const int 
         RecipItem it{replica[c], t[c], m[c], kind[c], -1, nm};
         if (kind[c] == MGPU_CREATION) {
             if (nm >= e->tp.cap[t[c]]) return set_error(MGPU_ERR_CAPACITY, "commit: residue type is at mol_capacity");
-            it.m = nm;  // appended at the first free slot, create_molecule.f90:64 / monte_carlo.f90 (num_residues + 1)
+            it.m = nm;  // appended at the first free slot: num_residues + 1 (monte_carlo.f90:63, create_molecule.f90:64)
             it.aux = nm + 1;
         } else {
             if ((rc = check_candidate(e, c, replica[c], t[c], m[c], true))) return rc;
@@ -866,18 +909,77 @@ int mgpu_commit_candidates(mgpu_engine *e, int n, const int *replica, const int 
         }
         n1_max = std::max(n1_max, e->tp.n1[t[c]]);
         if (kind[c] != MGPU_MOVE) { new_counts.push_back(idx); new_counts.push_back(it.aux); }
-        items.push_back(it);
+        items[n_items++] = it;
     }
-    if (items.empty()) return MGPU_OK;
+    if (n_items == 0) return MGPU_OK;
     if (any_sites && !sites) return set_error(MGPU_ERR_INVALID_ARG, "commit_candidates: sites is null");
-    if ((rc = e->d_items2.reserve(items.size() * sizeof(RecipItem)))) return rc;
-    HIP_TRY(hipMemcpyAsync(e->d_items2.p, items.data(), items.size() * sizeof(RecipItem), hipMemcpyHostToDevice, e->stream));
-    if (any_sites && (rc = upload_sites(e, sites, n, site_stride))) return rc;
-    if ((rc = launch_recip(e, (const RecipItem *)e->d_items2.p, (int)items.size(), n1_max, site_stride, true, e->d_A, nullptr)))
+    if ((rc = ln.d_items2.reserve((size_t)n_items * sizeof(RecipItem)))) return rc;
+    HIP_TRY(hipMemcpyAsync(ln.d_items2.p, items, (size_t)n_items * sizeof(RecipItem), hipMemcpyHostToDevice, ln.stream));
+    if (any_sites) {
+        std::memcpy(ln.h_commit.p, sites, site_bytes);
+        if ((rc = ln.d_sites.reserve(site_bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(ln.d_sites.p, ln.h_commit.p, site_bytes, hipMemcpyHostToDevice, ln.stream));
+    }
+    if ((rc = launch_recip(e, ln, (const RecipItem *)ln.d_items2.p, n_items, n1_max, site_stride, true, e->d_A, nullptr)))
         return rc;
-    if ((rc = sync_stream(e))) return rc;
     for (size_t i = 0; i < new_counts.size(); i += 2) e->h_nmol[new_counts[i]] = new_counts[i + 1];
     return MGPU_OK;
+}
+
+static int check_lane(const mgpu_engine *e, int lane) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    if (lane < 0 || lane >= kLanes) return set_error(MGPU_ERR_INVALID_ARG, "lane out of range");
+    return MGPU_OK;
+}
+
+int mgpu_trial_submit(mgpu_engine *e, int lane, int n, const int *replica, const int *t, const int *m,
+                      const double *sites, int site_stride) {
+    int rc = check_lane(e, lane);
+    if (rc) return rc;
+    if (n <= 0 || !replica || !t || !m || !sites) return set_error(MGPU_ERR_INVALID_ARG, "trial_submit: bad argument");
+    if ((rc = use_device(e))) return rc;
+    return trial_submit_impl(e, e->lanes[lane], n, replica, t, m, sites, site_stride);
+}
+
+int mgpu_trial_wait(mgpu_engine *e, int lane, double *old_energy, double *new_energy) {
+    int rc = check_lane(e, lane);
+    if (rc) return rc;
+    if (!old_energy || !new_energy) return set_error(MGPU_ERR_INVALID_ARG, "trial_wait: null output");
+    if ((rc = use_device(e))) return rc;
+    return trial_wait_impl(e, e->lanes[lane], old_energy, new_energy);
+}
+
+int mgpu_commit_submit(mgpu_engine *e, int lane, int n, const int *replica, const int *t, const int *m, const int *kind,
+                       const double *sites, int site_stride, const int *accept) {
+    int rc = check_lane(e, lane);
+    if (rc) return rc;
+    if (n == 0) return MGPU_OK;
+    if (n < 0 || !replica || !t || !m || !kind || !accept) return set_error(MGPU_ERR_INVALID_ARG, "commit_submit: bad argument");
+    if ((rc = use_device(e))) return rc;
+    return commit_submit_impl(e, e->lanes[lane], n, replica, t, m, kind, sites, site_stride, accept);
+}
+
+int mgpu_trial_energy_candidates(mgpu_engine *e, int n, const int *replica, const int *t, const int *m,
+                                 const double *sites, int site_stride, double *old_energy, double *new_energy) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    if (n == 0) return MGPU_OK;
+    if (n < 0 || !replica || !t || !m || !sites || !old_energy || !new_energy)
+        return set_error(MGPU_ERR_INVALID_ARG, "trial_energy_candidates: bad argument");
+    int rc = use_device(e);
+    if (rc) return rc;
+    if ((rc = trial_submit_impl(e, e->lanes[0], n, replica, t, m, sites, site_stride))) return rc;
+    return trial_wait_impl(e, e->lanes[0], old_energy, new_energy);
+}
+
+int mgpu_commit_candidates(mgpu_engine *e, int n, const int *replica, const int *t, const int *m, const int *kind,
+                           const double *sites, int site_stride, const int *accept) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    if (n == 0) return MGPU_OK;
+    if (n < 0 || !replica || !t || !m || !kind || !accept) return set_error(MGPU_ERR_INVALID_ARG, "commit_candidates: bad argument");
+    int rc = use_device(e);
+    if (rc) return rc;
+    if ((rc = commit_submit_impl(e, e->lanes[0], n, replica, t, m, kind, sites, site_stride, accept))) return rc;
+    return sync_stream(e);
 }
 
 // ---- static energy ---------------------------------------------------------------------------
@@ -902,7 +1004,7 @@ int mgpu_system_energy(mgpu_engine *e, int replica, double out[6]) {
         HIP_TRY(hipMemcpyAsync(e->d_items.p, items.data(), n * sizeof(PairItem), hipMemcpyHostToDevice, e->stream));
         double *d_lj = (double *)e->d_out.p, *d_c = d_lj + n, *d_in = d_c + n;
         const int nsplit = choose_nsplit(e, n, replica);
-        if ((rc = launch_pair(e, (const PairItem *)e->d_items.p, n, 0, 1, nsplit, d_lj, d_c, true))) return rc;
+        if ((rc = launch_pair(e, e->lanes[0], (const PairItem *)e->d_items.p, n, 0, 1, nsplit, d_lj, d_c, true))) return rc;
         hipLaunchKernelGGL(intra_kernel, dim3((n + 63) / 64), dim3(64), 0, e->stream, e->tp, e->bx, e->d_pos, e->d_res_q,
                            (const PairItem *)e->d_items.p, n, (const double *)nullptr, 1, d_in);
         HIP_TRY(hipGetLastError());
@@ -916,7 +1018,7 @@ int mgpu_system_energy(mgpu_engine *e, int replica, double out[6]) {
     if ((rc = e->d_items2.reserve(sizeof(RecipItem)))) return rc;
     HIP_TRY(hipMemcpyAsync(e->d_items2.p, &rit, sizeof(RecipItem), hipMemcpyHostToDevice, e->stream));
     double *d_u = (double *)e->d_out.p + (size_t)3 * n;
-    if ((rc = launch_recip(e, (const RecipItem *)e->d_items2.p, 1, 1, 1, false, e->d_S, d_u))) return rc;
+    if ((rc = launch_recip(e, e->lanes[0], (const RecipItem *)e->d_items2.p, 1, 1, 1, false, e->d_S, d_u))) return rc;
     HIP_TRY(hipMemcpyAsync(&e_recip, d_u, sizeof(double), hipMemcpyDeviceToHost, e->stream));
     if ((rc = sync_stream(e))) return rc;
     int i = 0;
@@ -945,7 +1047,9 @@ int mgpu_synchronize(mgpu_engine *e) {
     if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
     int rc = use_device(e);
     if (rc) return rc;
-    return sync_stream(e);
+    for (auto &ln : e->lanes)
+        if ((rc = sync_lane(e, ln))) return rc;
+    return MGPU_OK;
 }
 
 int mgpu_profile_enable(mgpu_engine *e, int on) {
