@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--replicas", type=int, default=1024, help="independent chains per GPU")
     ap.add_argument("--n-side", type=int, default=15, help="SPC/E lattice side (15 -> 10 125 atoms)")
+    ap.add_argument("--host", choices=["fortran", "python"], default="fortran",
+                    help="Metropolis driver: the Fortran farm (mc_farm.f90, two overlapped lanes) or the numpy one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -92,17 +94,18 @@ def main():
         torch.cuda.set_device(local_rank)
 
     from maniac_mc_amd import _lib, synth
-    from maniac_mc_amd.farm import ReplicaFarm
-
     system = synth.spce_box(args.n_side)
     t_step, r_step = 0.3, 0.3
-    farm = ReplicaFarm(system, args.replicas, device=local_rank, seed=1000 + rank,
-                       translation_step=t_step, rotation_step=r_step, p_translation=0.5)
+    if args.host == "fortran":
+        from maniac_mc_amd.fortran_host import FortranFarm as Farm
+    else:
+        from maniac_mc_amd.farm import ReplicaFarm as Farm
+    farm = Farm(system, args.replicas, device=local_rank, seed=1000 + rank,
+                translation_step=t_step, rotation_step=r_step, p_translation=0.5)
     eng = farm.eng
     N, Nk, R = system.n_atoms, eng.nk, args.replicas
 
-    for _ in range(args.warmup):
-        farm.step()
+    farm.run(args.warmup)
     eng.profile_enable(True)
     eng.profile_reset()
 
@@ -138,7 +141,8 @@ def main():
         # the 36 N part (x, y, z, q fp64 + int32 type per atom), the k sweep the 52 Nk part.
         bytes_pair_eval = 36.0 * N
         bytes_eval = 36.0 * N + 52.0 * Nk
-        evals_per_launch = 2 * R
+        # the Fortran driver splits the replicas over two lanes: each launch carries half of them
+        evals_per_launch = (2 * R) / (2 if args.host == "fortran" and R > 1 else 1)
         avg_pair_s = ms_pair / max(1, n_pair) * 1e-3
         achieved = bytes_pair_eval * evals_per_launch / avg_pair_s / 1e9 if n_pair else 0.0
         evals_total = 2.0 * tot_trials
@@ -148,7 +152,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"spce_{system.n_mol[0]}mol_{N}atoms_lj_cut_coul_long_ewald_Nk{Nk}",
-                       "replicas_per_gpu": R, "moves": "50% translation / 50% rotation, 0.3 A / 0.3 rad, 300 K",
+                       "replicas_per_gpu": R, "host_driver": args.host, "moves": "50% translation / 50% rotation, 0.3 A / 0.3 rad, 300 K",
                        "trials_per_step": R * world, "dE_evals_per_step": 2 * R * world, "parallelism": f"replicas x{world}"},
             "trial_moves_per_s": tot_trials / elapsed,
             "acceptance": tot_acc / max(1.0, tot_trials),

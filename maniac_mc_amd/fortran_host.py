@@ -1,0 +1,135 @@
+"""Build / load the Fortran host side (maniac_mc_amd/fortran/*.f90 -> libmaniac_host.so) and drive it.
+
+The Metropolis loop of the replica farm is Fortran (mc_farm.f90), as the north star asks: it calls
+the HIP engine through the ISO_C_BINDING module maniac_gpu.f90 -> include/maniac_gpu.h.  Python only
+creates the engine, hands over the initial configuration and asks for n steps.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _lib
+from .engine import Engine
+from .system import System
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmaniac_host.so")
+FSRC = [os.path.join(_HERE, "fortran", f) for f in ("maniac_gpu.f90", "mc_farm.f90")]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    _lib.build()
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(f) for f in FSRC + [_lib.LIB_PATH]):
+            return LIB_PATH
+    moddir = os.path.join(_HERE, "..", "build", "fmod")
+    os.makedirs(moddir, exist_ok=True)
+    cmd = ["amdflang", "-O2", "-fPIC", "-shared", "-module-dir", moddir, "-o", LIB_PATH] + FSRC + \
+          ["-L" + _HERE, "-lmaniac_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_host = None
+
+
+def lib():
+    global _host
+    if _host is None:
+        _lib.lib()       # libmaniac_hip.so first, so the dependency resolves in-tree
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (needs amdflang)")
+        L = C.CDLL(LIB_PATH)
+        L.mfarm_create.restype = C.c_int
+        L.mfarm_run.restype = C.c_int
+        _host = L
+    return _host
+
+
+class FortranFarm:
+    """R chains of `system` on one GPU, advanced by the Fortran driver (mc_farm.f90)."""
+
+    def __init__(self, system: System, n_replicas: int, device: int = 0, seed: int = 1,
+                 translation_step: float = 0.3, rotation_step: float = 0.3, p_translation: float = 0.5):
+        self.H = lib()
+        self.sys = system
+        self.R = int(n_replicas)
+        self.eng = Engine(system.topo, system.box_matrix, system.bounds_lo, system.real_space_cutoff,
+                          system.ewald_tolerance, self.R, device,
+                          [max(1, int(n)) for n in system.n_mol])
+        self.eng.load_system(system, 0)
+        self.eng.init_structure_factor(0, True)
+        for r in range(1, self.R):
+            self.eng.replica_copy(r, 0)
+        e0 = self.eng.system_energy(0)
+        topo = system.topo
+        active = [t for t in range(topo.n_res) if topo.is_active[t] and system.n_mol[t] > 0]
+        self.active = np.array(active, dtype=np.int32)
+        n1 = np.array([topo.atoms_in_res[t] for t in active], dtype=np.int32)
+        nmol = np.array([system.n_mol[t] for t in active], dtype=np.int32)
+        max_n1 = int(n1.max())
+        cap = int(nmol.sum())
+        com = np.zeros((cap, 3))
+        off = np.zeros((cap, max_n1, 3))
+        pos = 0
+        for k, t in enumerate(active):
+            com[pos:pos + nmol[k]] = system.com[t]
+            off[pos:pos + nmol[k], :n1[k]] = system.offsets[t]
+            pos += nmol[k]
+        energy0 = np.array([e0["non_coulomb"], e0["coulomb"], e0["recip_coulomb"]])
+        lo = np.ascontiguousarray(system.bounds_lo)
+        length = np.ascontiguousarray(np.diag(system.box_matrix))
+        rc = self.H.mfarm_create(self.eng.h, C.c_int(self.R), C.c_int(len(active)), self.active.ctypes.data_as(_ip),
+                                 n1.ctypes.data_as(_ip), nmol.ctypes.data_as(_ip), C.c_int(max_n1),
+                                 com.ctypes.data_as(_dp), off.ctypes.data_as(_dp), energy0.ctypes.data_as(_dp),
+                                 lo.ctypes.data_as(_dp), length.ctypes.data_as(_dp), C.c_double(system.temperature),
+                                 C.c_double(translation_step), C.c_double(rotation_step), C.c_double(p_translation),
+                                 C.c_int(seed))
+        _lib.check(rc)
+        self.max_n1 = max_n1
+        self.stats = np.zeros(6)
+
+    def run(self, n_steps: int) -> int:
+        """Advance every chain by n_steps trials; returns the moves accepted during this call."""
+        before = self.stats[1]
+        rc = self.H.mfarm_run(C.c_int(n_steps), self.stats.ctypes.data_as(_dp))
+        _lib.check(rc)
+        return int(self.stats[1] - before)
+
+    def recalibrate(self):
+        s = np.zeros(2)
+        self.H.mfarm_recalibrate(s.ctypes.data_as(_dp))
+        return s
+
+    def energy(self, replica: int):
+        e = np.zeros(3)
+        self.H.mfarm_get_energy(C.c_int(replica), e.ctypes.data_as(_dp))
+        return e
+
+    def molecule(self, replica: int, ia: int, slot: int):
+        com = np.zeros(3)
+        off = np.zeros((self.max_n1, 3))
+        self.H.mfarm_get_molecule(C.c_int(replica), C.c_int(ia), C.c_int(slot), com.ctypes.data_as(_dp),
+                                  off.ctypes.data_as(_dp))
+        return com, off
+
+    @property
+    def trials(self):
+        return int(self.stats[0])
+
+    @property
+    def accepted(self):
+        return int(self.stats[1])
+
+    def close(self):
+        self.H.mfarm_destroy()
+        self.eng.close()
