@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--n-side", type=int, default=15, help="SPC/E lattice side (15 -> 10 125 atoms)")
     ap.add_argument("--host", choices=["fortran", "python"], default="fortran",
                     help="Metropolis driver: the Fortran farm (mc_farm.f90, two overlapped lanes) or the numpy one")
+    ap.add_argument("--host-threads", type=int, default=8, help="OpenMP threads of the Fortran driver (per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -100,8 +101,9 @@ def main():
         from maniac_mc_amd.fortran_host import FortranFarm as Farm
     else:
         from maniac_mc_amd.farm import ReplicaFarm as Farm
+    kw = dict(n_threads=args.host_threads) if args.host == "fortran" else {}
     farm = Farm(system, args.replicas, device=local_rank, seed=1000 + rank,
-                translation_step=t_step, rotation_step=r_step, p_translation=0.5)
+                translation_step=t_step, rotation_step=r_step, p_translation=0.5, **kw)
     eng = farm.eng
     N, Nk, R = system.n_atoms, eng.nk, args.replicas
 
@@ -152,7 +154,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"spce_{system.n_mol[0]}mol_{N}atoms_lj_cut_coul_long_ewald_Nk{Nk}",
-                       "replicas_per_gpu": R, "host_driver": args.host, "moves": "50% translation / 50% rotation, 0.3 A / 0.3 rad, 300 K",
+                       "replicas_per_gpu": R, "host_driver": args.host, "host_threads": args.host_threads if args.host == "fortran" else 1, "moves": "50% translation / 50% rotation, 0.3 A / 0.3 rad, 300 K",
                        "trials_per_step": R * world, "dE_evals_per_step": 2 * R * world, "parallelism": f"replicas x{world}"},
             "trial_moves_per_s": tot_trials / elapsed,
             "acceptance": tot_acc / max(1.0, tot_trials),
@@ -165,6 +167,8 @@ def main():
                          "job_frac": (evals_total / world / elapsed) * bytes_eval / 1e9 / HBM_PEAK_GBS,
                          "recip_avg_launch_us": ms_rec / max(1, n_rec) * 1e3, "commit_avg_launch_us": ms_com / max(1, n_com) * 1e3},
         }
+        if hasattr(farm, "timers"):
+            out["host_seconds"] = farm.timers()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(system, t_step, r_step, budget_s=args.cpu_budget)
         print(json.dumps(out))

@@ -208,7 +208,9 @@ int mgpu_commit_candidates(mgpu_engine *e, int n_candidates, const int *replica,
  * replicas overlaps the GPU's evaluation of another.  The engine has MGPU_LANES submission lanes,
  * each a HIP stream with private scratch; work on different lanes may run concurrently and must
  * touch disjoint replicas.  submit returns once copies and kernels are queued; wait blocks for the
- * lane and returns the energies; a commit is ordered before any later submit on the same lane. */
+ * lane and returns the energies; a commit is ordered before any later submit on the same lane.
+ * mgpu_commit_submit accepts sites = NULL when it commits the candidates of the lane's last
+ * mgpu_trial_submit (same n_candidates, order and site_stride): their rows are still on the device. */
 #define MGPU_LANES 2
 int mgpu_trial_submit(mgpu_engine *e, int lane, int n_candidates, const int *replica, const int *t,
                       const int *m, const double *sites, int site_stride);

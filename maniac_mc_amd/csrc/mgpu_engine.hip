@@ -76,6 +76,7 @@ struct Lane {
     struct Pending { int kernel; hipEvent_t a, b; };
     std::vector<Pending> pending;
     int n_submitted = 0;          // candidates of the trial in flight (0 = none)
+    int last_trial_n = 0, last_trial_stride = 0;   // shape of the site rows still resident in d_sites
     void release() {
         d_items.release(); d_items2.release(); d_sites.release(); d_partials.release(); d_out.release();
         h_in.release(); h_commit.release(); h_out.release();
@@ -211,6 +212,7 @@ int choose_nsplit(const mgpu_engine *e, int n_items, int replica_hint) {
 
 int upload_sites(Lane &ln, const double *sites, int n_rows, int site_stride) {
     if (!sites || n_rows == 0) return MGPU_OK;
+    ln.last_trial_n = 0;
     const size_t bytes = (size_t)n_rows * site_stride * 3 * sizeof(double);
     int rc = ln.d_sites.reserve(bytes);
     if (rc) return rc;
@@ -853,6 +855,8 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
         return rc;
     HIP_TRY(hipMemcpyAsync(ln.h_out.p, ln.d_out.p, 3 * n2 * sizeof(double), hipMemcpyDeviceToHost, ln.stream));
     ln.n_submitted = n;
+    ln.last_trial_n = n;
+    ln.last_trial_stride = site_stride;
     return MGPU_OK;
 }
 
@@ -873,8 +877,11 @@ static int trial_wait_impl(mgpu_engine *e, Lane &ln, double *old_energy, double 
 
 // Queue the commit of the accepted candidates on a lane (no synchronisation).  The host-side
 // molecule counts are updated immediately; the device applies them in stream order.
+// reuse_sites: `sites` may be NULL, meaning "the rows the lane's last trial_submit uploaded" (same
+// candidates, same order), which are still resident in the lane's device scratch.
 static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica, const int *t, const int *m,
-                              const int *kind, const double *sites, int site_stride, const int *accept) {
+                              const int *kind, const double *sites, int site_stride, const int *accept,
+                              bool reuse_sites = false) {
     int rc;
     const size_t site_bytes = sites ? (size_t)n * site_stride * 3 * sizeof(double) : 0;
     if ((rc = ln.h_commit.reserve(site_bytes + (size_t)n * sizeof(RecipItem)))) return rc;
@@ -912,10 +919,11 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
         items[n_items++] = it;
     }
     if (n_items == 0) return MGPU_OK;
-    if (any_sites && !sites) return set_error(MGPU_ERR_INVALID_ARG, "commit_candidates: sites is null");
+    if (any_sites && !sites && !reuse_sites) return set_error(MGPU_ERR_INVALID_ARG, "commit_candidates: sites is null");
     if ((rc = ln.d_items2.reserve((size_t)n_items * sizeof(RecipItem)))) return rc;
     HIP_TRY(hipMemcpyAsync(ln.d_items2.p, items, (size_t)n_items * sizeof(RecipItem), hipMemcpyHostToDevice, ln.stream));
-    if (any_sites) {
+    if (any_sites && sites) {
+        ln.last_trial_n = 0;
         std::memcpy(ln.h_commit.p, sites, site_bytes);
         if ((rc = ln.d_sites.reserve(site_bytes))) return rc;
         HIP_TRY(hipMemcpyAsync(ln.d_sites.p, ln.h_commit.p, site_bytes, hipMemcpyHostToDevice, ln.stream));
@@ -956,7 +964,9 @@ int mgpu_commit_submit(mgpu_engine *e, int lane, int n, const int *replica, cons
     if (n == 0) return MGPU_OK;
     if (n < 0 || !replica || !t || !m || !kind || !accept) return set_error(MGPU_ERR_INVALID_ARG, "commit_submit: bad argument");
     if ((rc = use_device(e))) return rc;
-    return commit_submit_impl(e, e->lanes[lane], n, replica, t, m, kind, sites, site_stride, accept);
+    Lane &ln = e->lanes[lane];
+    const bool reuse = (sites == nullptr) && ln.last_trial_n == n && ln.last_trial_stride == site_stride;
+    return commit_submit_impl(e, ln, n, replica, t, m, kind, sites, site_stride, accept, reuse);
 }
 
 int mgpu_trial_energy_candidates(mgpu_engine *e, int n, const int *replica, const int *t, const int *m,

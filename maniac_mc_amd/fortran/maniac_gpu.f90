@@ -165,13 +165,14 @@ module maniac_gpu
             real(c_double), intent(out) :: old_energy(*), new_energy(*)
             integer(c_int) :: rc
         end function
+        ! sites: c_loc of a (3, site_stride, n) array, or c_null_ptr to commit the candidates of the
+        ! lane's last mgpu_trial_submit, whose rows are still resident on the device
         function mgpu_commit_submit(e, lane, n, replica, t, m, kind, sites, site_stride, accept) &
                 bind(C, name="mgpu_commit_submit") result(rc)
-            import :: c_ptr, c_int, c_double
-            type(c_ptr), value :: e
+            import :: c_ptr, c_int
+            type(c_ptr), value :: e, sites
             integer(c_int), value :: lane, n, site_stride
             integer(c_int), intent(in) :: replica(*), t(*), m(*), kind(*), accept(*)
-            real(c_double), intent(in) :: sites(*)
             integer(c_int) :: rc
         end function
         function mgpu_synchronize(e) bind(C, name="mgpu_synchronize") result(rc)

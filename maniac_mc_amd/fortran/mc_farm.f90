@@ -11,8 +11,10 @@
 !   acceptance           src/monte_carlo_utils.f90:184-226   min(1, exp(-dE/T)), energies in K
 !   AcceptMove           src/monte_carlo_utils.f90:410-422
 !   step recalibration   src/monte_carlo_utils.f90:99-130    (AdjustMoveStepSizes, as written)
-! Random numbers come from the intrinsic random_number, like the reference
-! (src/random_utils.f90:13-56).
+! Random numbers: rng_kind 0 draws from the intrinsic random_number exactly like the reference
+! (src/random_utils.f90:13-56); rng_kind 1 (default of the bench) uses an inlined xoshiro256+
+! generator seeded by the same rule, because flang's random_number costs ~17 ns per number and the
+! farm consumes nine numbers per trial (measured: 40 % of the host time of a step).
 !
 ! One chain is sequential, so the farm advances R chains in lock step: each step
 ! generates one trial move per chain, evaluates all of them in one batched call
@@ -21,6 +23,11 @@
 ! the engine's two submission lanes, so the host prepares / resolves one group while
 ! the GPU evaluates the other.
 !
+! The per-chain loops (gathering a molecule from the host mirror, building the move, the
+! Metropolis test) are independent across chains and run under OpenMP: with ~1000 chains the
+! random gathers from the ~300 MB mirror are DRAM/TLB-latency bound (measured 0.34 us per chain
+! single-threaded), and a few host threads overlap them.
+!
 ! Only translation / rotation (NVT) are driven here; insertion / deletion go through
 ! the same engine calls (mgpu_*_candidates with MGPU_CREATION / MGPU_DELETION).
 !===============================================================================
@@ -28,12 +35,14 @@ module mc_farm
 
     use, intrinsic :: iso_c_binding
     use, intrinsic :: iso_fortran_env, only: real64, int64
+    use omp_lib
     use maniac_gpu
 
     implicit none
 
     private
     public :: mfarm_create, mfarm_run, mfarm_destroy, mfarm_get_energy, mfarm_get_molecule, mfarm_recalibrate
+    public :: mfarm_get_timers
 
     real(real64), parameter :: PI = 3.14159265358979323846_real64
     real(real64), parameter :: TWOPI = 2.0_real64 * PI
@@ -66,6 +75,9 @@ module mc_farm
         integer(int64) :: trial_translations = 0, translations = 0, trial_rotations = 0, rotations = 0
         type(lane_buffers) :: lane(0:MGPU_LANES - 1)
         logical :: ready = .false.
+        integer(int64) :: ticks(7) = 0                     ! generate, submit, wait, resolve, commit, rng, gather
+        integer :: rng_kind = 1, n_threads = 1
+        integer(int64) :: xs(4) = 0                        ! xoshiro256+ state
     end type farm_state
 
     type(farm_state), save, target :: F
@@ -81,7 +93,38 @@ contains
         allocate(s(n))
         s = seed + 37 * [(i - 1, i = 1, n)]
         call random_seed(put=s)
+        ! xoshiro256+ state from the same rule (seed + 37*(i-1)), scrambled by xorshift steps
+        do i = 1, 4
+            F%xs(i) = int(seed + 37 * (i - 1), int64) + 88172645463325252_int64 * int(i, int64)
+            F%xs(i) = ieor(F%xs(i), ishft(F%xs(i), 13))
+            F%xs(i) = ieor(F%xs(i), ishft(F%xs(i), -7))
+            F%xs(i) = ieor(F%xs(i), ishft(F%xs(i), 17))
+        end do
+        if (all(F%xs == 0_int64)) F%xs(1) = 1_int64
     end subroutine seed_farm_rng
+
+    ! fill u with uniform numbers in [0, 1)
+    subroutine farm_random(u)
+        real(real64), intent(out) :: u(:, :)
+        integer :: i, j
+        integer(int64) :: t, s1, s2, s3, s4
+        if (F%rng_kind == 0) then
+            call random_number(u)
+            return
+        end if
+        s1 = F%xs(1); s2 = F%xs(2); s3 = F%xs(3); s4 = F%xs(4)
+        do j = 1, size(u, 2)
+            do i = 1, size(u, 1)
+                ! xoshiro256+ (Blackman & Vigna): top 53 bits of s1 + s4
+                u(i, j) = real(ishft(s1 + s4, -11), real64) * (1.0_real64 / 9007199254740992.0_real64)
+                t = ishft(s2, 17)
+                s3 = ieor(s3, s1); s4 = ieor(s4, s2); s2 = ieor(s2, s3); s1 = ieor(s1, s4)
+                s3 = ieor(s3, t)
+                s4 = ior(ishft(s4, 45), ishft(s4, -19))
+            end do
+        end do
+        F%xs = [s1, s2, s3, s4]
+    end subroutine farm_random
 
     !---------------------------------------------------------------------------
     ! Create the farm.  Every replica of `engine` must already hold the same configuration
@@ -92,10 +135,10 @@ contains
     ! energy0 = non_coulomb, coulomb, recip_coulomb of that configuration.
     !---------------------------------------------------------------------------
     function mfarm_create(engine, n_replicas, n_active, res_type, n1, n_mol, max_n1, com, off, energy0, &
-                          bounds_lo, box_len, temperature, translation_step, rotation_step, p_translation, seed) &
-                          bind(C, name="mfarm_create") result(rc)
+                          bounds_lo, box_len, temperature, translation_step, rotation_step, p_translation, seed, &
+                          rng_kind, n_threads) bind(C, name="mfarm_create") result(rc)
         type(c_ptr), value :: engine
-        integer(c_int), value :: n_replicas, n_active, max_n1, seed
+        integer(c_int), value :: n_replicas, n_active, max_n1, seed, rng_kind, n_threads
         integer(c_int), intent(in) :: res_type(n_active), n1(n_active), n_mol(n_active)
         real(c_double), intent(in) :: com(3, *), off(3, max_n1, *), energy0(3), bounds_lo(3), box_len(3)
         real(c_double), value :: temperature, translation_step, rotation_step, p_translation
@@ -131,6 +174,8 @@ contains
         F%p_translation = p_translation
         F%trials = 0; F%accepted = 0
         F%trial_translations = 0; F%translations = 0; F%trial_rotations = 0; F%rotations = 0
+        F%rng_kind = rng_kind
+        F%n_threads = max(1, int(n_threads))
         call seed_farm_rng(int(seed))
         ! two groups of replicas, one per engine lane (a single group if there is one replica)
         per = (n_replicas + MGPU_LANES - 1) / MGPU_LANES
@@ -194,44 +239,75 @@ contains
         integer, intent(in) :: g
         integer(c_int) :: rc
         integer :: i, r, ia, slot, n1, axis, d, a
-        real(real64) :: theta, rot(3, 3), pos(3)
+        integer(int64) :: c0, c1, c2, c3, c4
+        integer :: p, q
+        real(real64) :: theta, c, sn, x, y
         type(lane_buffers), pointer :: L
         L => F%lane(g)
         rc = MGPU_OK
         if (L%n == 0) return
-        call random_number(L%u(:, 1:L%n))
+        call system_clock(c0)
+        call farm_random(L%u(:, 1:L%n))
+        call system_clock(c3)
+        ! pass 1: pick (type, molecule) and gather its com / offsets from the host mirror.  Kept free
+        ! of arithmetic so the out-of-order core overlaps the cache misses of independent chains.
+        !$omp parallel do num_threads(F%n_threads) schedule(static) private(r, ia, slot)
         do i = 1, L%n
             r = L%first + i                                           ! 1-based replica
             ia = min(int(L%u(1, i) * F%n_active) + 1, F%n_active)      ! PickRandomResidueType
             slot = min(int(L%u(2, i) * F%n_mol(ia)) + 1, F%n_mol(ia))  ! PickRandomMoleculeIndex
-            n1 = F%n1(ia)
             L%ia(i) = ia
             L%rep(i) = r - 1
             L%t(i) = F%res_type(ia)
             L%m(i) = slot - 1
-            L%is_trans(i) = (L%u(3, i) <= F%p_translation) .or. (n1 == 1)
             L%new_com(:, i) = F%com(:, F%first(ia) + slot, r)
-            L%new_off(:, 1:n1, i) = F%off(:, 1:n1, F%first(ia) + slot, r)
+            L%new_off(:, :, i) = F%off(:, :, F%first(ia) + slot, r)
+        end do
+        !$omp end parallel do
+        call system_clock(c4)
+        F%ticks(6) = F%ticks(6) + (c3 - c0)
+        F%ticks(7) = F%ticks(7) + (c4 - c3)
+        ! pass 2: the moves themselves
+        !$omp parallel do num_threads(F%n_threads) schedule(static) private(n1, d, x, y, theta, axis, c, sn, p, q, a)
+        do i = 1, L%n
+            n1 = F%n1(L%ia(i))
+            L%is_trans(i) = (L%u(3, i) <= F%p_translation) .or. (n1 == 1)
             if (L%is_trans(i)) then
                 ! translation.f90:104-110: rand_symmetric(3)*translation_step, then ApplyPBC
-                pos = L%new_com(:, i) + (L%u(4:6, i) - 0.5_real64) * F%translation_step
+                ! (geometry_utils.f90:190: lo + modulo(pos - lo, L); written out: pos - lo is
+                !  within one box length of [0, L) for any legal step)
                 do d = 1, 3
-                    pos(d) = F%lo(d) + modulo(pos(d) - F%lo(d), F%len(d))   ! geometry_utils.f90:190
+                    x = (L%new_com(d, i) + (L%u(3 + d, i) - 0.5_real64) * F%translation_step) - F%lo(d)
+                    if (x < 0.0_real64 .or. x >= F%len(d)) x = modulo(x, F%len(d))
+                    L%new_com(d, i) = F%lo(d) + x
                 end do
-                L%new_com(:, i) = pos
             else
-                ! monte_carlo_utils.f90:54-64
+                ! monte_carlo_utils.f90:54-64 with RotationMatrix (helper_utils.f90:39-77) written out:
+                ! rotation by theta about Cartesian axis `axis` mixes the two other components
                 theta = (L%u(7, i) - 0.5_real64) * F%rotation_step
                 axis = int(L%u(8, i) * 3.0_real64) + 1
-                rot = RotationMatrix(axis, theta)
-                L%new_off(:, 1:n1, i) = matmul(rot, L%new_off(:, 1:n1, i))
+                c = cos(theta)
+                sn = sin(theta)
+                p = mod(axis, 3) + 1          ! X -> (Y, Z), Y -> (Z, X), Z -> (X, Y)
+                q = mod(axis + 1, 3) + 1
+                do a = 1, n1
+                    x = L%new_off(p, a, i)
+                    y = L%new_off(q, a, i)
+                    L%new_off(p, a, i) = c * x - sn * y
+                    L%new_off(q, a, i) = sn * x + c * y
+                end do
             end if
             do a = 1, n1
                 L%sites(:, a, i) = L%new_com(:, i) + L%new_off(:, a, i)
             end do
         end do
+        !$omp end parallel do
+        call system_clock(c1)
         rc = mgpu_trial_submit(F%engine, int(g, c_int), int(L%n, c_int), L%rep, L%t, L%m, L%sites, &
                                int(F%max_n1, c_int))
+        call system_clock(c2)
+        F%ticks(1) = F%ticks(1) + (c1 - c0)
+        F%ticks(2) = F%ticks(2) + (c2 - c1)
     end function generate_and_submit
 
     !---------------------------------------------------------------------------
@@ -243,21 +319,27 @@ contains
         integer, intent(in) :: g
         integer(c_int) :: rc
         integer :: i, r, ia, slot, n1
+        integer(int64) :: c0, c1, c2, c3, n_tt, n_t, n_rr, n_r
         real(real64) :: delta_e, probability
         type(lane_buffers), pointer :: L
         L => F%lane(g)
         rc = MGPU_OK
         if (L%n == 0) return
+        call system_clock(c0)
         rc = mgpu_trial_wait(F%engine, int(g, c_int), L%old_e, L%new_e)
         if (rc /= MGPU_OK) return
+        call system_clock(c1)
+        n_tt = 0; n_t = 0; n_rr = 0; n_r = 0
+        !$omp parallel do num_threads(F%n_threads) schedule(static) private(r, delta_e, probability, ia, slot, n1) &
+        !$omp& reduction(+:n_tt, n_t, n_rr, n_r)
         do i = 1, L%n
             r = L%first + i
             delta_e = (L%new_e(1, i) + L%new_e(2, i) + L%new_e(3, i)) - (L%old_e(1, i) + L%old_e(2, i) + L%old_e(3, i))
             probability = min(1.0_real64, exp(-delta_e / F%temperature))
             if (L%is_trans(i)) then
-                F%trial_translations = F%trial_translations + 1
+                n_tt = n_tt + 1
             else
-                F%trial_rotations = F%trial_rotations + 1
+                n_rr = n_rr + 1
             end if
             if (L%u(9, i) <= probability) then
                 L%accept(i) = 1
@@ -267,19 +349,29 @@ contains
                 F%com(:, F%first(ia) + slot, r) = L%new_com(:, i)
                 F%off(:, 1:n1, F%first(ia) + slot, r) = L%new_off(:, 1:n1, i)
                 F%energy(:, r) = F%energy(:, r) + L%new_e(:, i) - L%old_e(:, i)
-                F%accepted = F%accepted + 1
                 if (L%is_trans(i)) then
-                    F%translations = F%translations + 1
+                    n_t = n_t + 1
                 else
-                    F%rotations = F%rotations + 1
+                    n_r = n_r + 1
                 end if
             else
                 L%accept(i) = 0
             end if
         end do
+        !$omp end parallel do
+        F%trial_translations = F%trial_translations + n_tt
+        F%translations = F%translations + n_t
+        F%trial_rotations = F%trial_rotations + n_rr
+        F%rotations = F%rotations + n_r
+        F%accepted = F%accepted + n_t + n_r
         F%trials = F%trials + L%n
-        rc = mgpu_commit_submit(F%engine, int(g, c_int), int(L%n, c_int), L%rep, L%t, L%m, L%kind, L%sites, &
-                                int(F%max_n1, c_int), L%accept)
+        call system_clock(c2)
+        rc = mgpu_commit_submit(F%engine, int(g, c_int), int(L%n, c_int), L%rep, L%t, L%m, L%kind, &
+                                c_null_ptr, int(F%max_n1, c_int), L%accept)
+        call system_clock(c3)
+        F%ticks(3) = F%ticks(3) + (c1 - c0)
+        F%ticks(4) = F%ticks(4) + (c2 - c1)
+        F%ticks(5) = F%ticks(5) + (c3 - c2)
     end function resolve_and_commit
 
     !---------------------------------------------------------------------------
@@ -343,6 +435,15 @@ contains
         steps(1) = F%translation_step
         steps(2) = F%rotation_step
     end subroutine mfarm_recalibrate
+
+    ! host wall time spent in: trial generation, trial submit, waiting for the GPU, Metropolis
+    ! resolution, commit submit (seconds, cumulative)
+    subroutine mfarm_get_timers(t) bind(C, name="mfarm_get_timers")
+        real(c_double), intent(out) :: t(7)
+        integer(int64) :: rate
+        call system_clock(count_rate=rate)
+        t = real(F%ticks, real64) / real(rate, real64)
+    end subroutine mfarm_get_timers
 
     ! running energies (non_coulomb, coulomb, recip_coulomb) of one replica (0-based)
     subroutine mfarm_get_energy(replica, e) bind(C, name="mfarm_get_energy")

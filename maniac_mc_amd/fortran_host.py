@@ -31,8 +31,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             return LIB_PATH
     moddir = os.path.join(_HERE, "..", "build", "fmod")
     os.makedirs(moddir, exist_ok=True)
-    cmd = ["amdflang", "-O2", "-fPIC", "-shared", "-module-dir", moddir, "-o", LIB_PATH] + FSRC + \
-          ["-L" + _HERE, "-lmaniac_hip", "-Wl,-rpath,$ORIGIN"]
+    cmd = ["amdflang", "-O2", "-fopenmp", "-fPIC", "-shared", "-module-dir", moddir, "-o", LIB_PATH] + FSRC + \
+          ["-L" + _HERE, "-lmaniac_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib/llvm/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -59,7 +59,8 @@ class FortranFarm:
     """R chains of `system` on one GPU, advanced by the Fortran driver (mc_farm.f90)."""
 
     def __init__(self, system: System, n_replicas: int, device: int = 0, seed: int = 1,
-                 translation_step: float = 0.3, rotation_step: float = 0.3, p_translation: float = 0.5):
+                 translation_step: float = 0.3, rotation_step: float = 0.3, p_translation: float = 0.5,
+                 rng_kind: int = 1, n_threads: int = 8):
         self.H = lib()
         self.sys = system
         self.R = int(n_replicas)
@@ -93,7 +94,7 @@ class FortranFarm:
                                  com.ctypes.data_as(_dp), off.ctypes.data_as(_dp), energy0.ctypes.data_as(_dp),
                                  lo.ctypes.data_as(_dp), length.ctypes.data_as(_dp), C.c_double(system.temperature),
                                  C.c_double(translation_step), C.c_double(rotation_step), C.c_double(p_translation),
-                                 C.c_int(seed))
+                                 C.c_int(seed), C.c_int(rng_kind), C.c_int(n_threads))
         _lib.check(rc)
         self.max_n1 = max_n1
         self.stats = np.zeros(6)
@@ -109,6 +110,12 @@ class FortranFarm:
         s = np.zeros(2)
         self.H.mfarm_recalibrate(s.ctypes.data_as(_dp))
         return s
+
+    def timers(self):
+        """Host seconds in: generate, submit, wait-for-GPU, resolve, commit-submit."""
+        t = np.zeros(7)
+        self.H.mfarm_get_timers(t.ctypes.data_as(_dp))
+        return dict(zip(("generate", "submit", "wait", "resolve", "commit", "gen_rng", "gen_gather"), t.tolist()))
 
     def energy(self, replica: int):
         e = np.zeros(3)
