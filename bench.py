@@ -7,9 +7,10 @@ ewald_tolerance 1e-5 -> alpha = 0.2346, kmax = 10, Nk = 2242 -- 50 % translation
 steps 0.3 A / 0.3 rad, T = 300 K.  Synthetic coordinates (seeded lattice + jitter), no files read.
 
 A "step" = one Metropolis trial in each of the R replicas a GPU holds: R candidates x (old + new)
-= 2R Delta-E evaluations (pair sweep + k sweep each) in one batched launch, the acceptance test on
-the host, and one commit launch for the accepted candidates.  Nothing is cached or skipped: both
-halves of ComputeOldEnergy / ComputeNewEnergy are computed for every trial.
+= 2R Delta-E evaluations in batched launches (two pair sweeps per candidate; one pass over k that
+yields both reciprocal energies, sum ff W |A|^2 and sum ff W |A + delta|^2), the acceptance test on
+the host (Fortran, mc_farm.f90), and one commit launch for the accepted candidates.  Nothing is
+cached or skipped: both halves of ComputeOldEnergy / ComputeNewEnergy are computed for every trial.
 value = accepted MC moves per second over all GPUs (replicas are independent chains; weak scaling).
 """
 import argparse
@@ -25,6 +26,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def pmc_traffic_per_evaluation():
+    """HBM bytes per Delta-E evaluation of the pair sweep from the committed rocprofv3 PMC passes
+    (FETCH_SIZE doubled per the gfx950 calibration, + WRITE_SIZE); None if the summary is absent.
+    PMC cannot be collected from inside this process, so the figure comes from profiles/."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["pair_sweep_kernel"]["hbm_bytes_per_evaluation"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(system, translation_step, rotation_step, budget_s=15.0, seed=3):
@@ -71,9 +84,9 @@ def cpu_baseline(system, translation_step, rotation_step, budget_s=15.0, seed=3)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--replicas", type=int, default=1024, help="independent chains per GPU")
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--replicas", type=int, default=2048, help="independent chains per GPU")
     ap.add_argument("--n-side", type=int, default=15, help="SPC/E lattice side (15 -> 10 125 atoms)")
     ap.add_argument("--host", choices=["fortran", "python"], default="fortran",
                     help="Metropolis driver: the Fortran farm (mc_farm.f90, two overlapped lanes) or the numpy one")
@@ -148,6 +161,7 @@ def main():
         avg_pair_s = ms_pair / max(1, n_pair) * 1e-3
         achieved = bytes_pair_eval * evals_per_launch / avg_pair_s / 1e9 if n_pair else 0.0
         evals_total = 2.0 * tot_trials
+        traffic_eval = pmc_traffic_per_evaluation()
         out = {
             "metric": "MC moves/sec", "value": tot_acc / elapsed, "unit": "accepted MC moves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -161,7 +175,9 @@ def main():
             "ns_per_dE_eval": elapsed / evals_total * 1e9 * world,
             "ns_per_dE_eval_note": "wall time per Delta-E evaluation per GPU (pair sweep + k sweep), host loop included",
             "roofline": {"bound": "hbm", "kernel": "pair_sweep_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (traffic_eval * evals_per_launch) if traffic_eval else None,
+                         "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
                          "algorithmic_bytes_per_launch": bytes_pair_eval * evals_per_launch,
                          "avg_launch_us": avg_pair_s * 1e6, "launches": n_pair,
                          "job_frac": (evals_total / world / elapsed) * bytes_eval / 1e9 / HBM_PEAK_GBS,

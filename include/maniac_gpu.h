@@ -186,7 +186,8 @@ int mgpu_intra_energy_candidates(mgpu_engine *e, int n_candidates, const int *re
 /* One translation / rotation trial per candidate, both halves in one call: what
  * ComputeOldEnergy + ComputeNewEnergy compute for the default branch
  * (monte_carlo_utils.f90:384-393, :310-318).  old_/new_ arrays are [n_candidates][3] =
- * non_coulomb, coulomb, recip_coulomb.  Every candidate costs two pair sweeps and two k sweeps. */
+ * non_coulomb, coulomb, recip_coulomb.  Every candidate costs two pair sweeps and one pass over k
+ * that yields both reciprocal energies (sum ff W |A|^2 and sum ff W |A + delta|^2). */
 int mgpu_trial_energy_candidates(mgpu_engine *e, int n_candidates, const int *replica, const int *t,
                                  const int *m, const double *sites, int site_stride,
                                  double *old_energy, double *new_energy);

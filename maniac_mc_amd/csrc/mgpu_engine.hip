@@ -276,11 +276,12 @@ int common_site_count(const mgpu_engine *e, const std::vector<Item> &items) {
 
 size_t recip_lds_bytes(const mgpu_engine *e, int n1_max) {
     const int ktot = e->kmax[0] + e->kmax[1] + e->kmax[2] + 3;
-    return (size_t)2 * n1_max * ktot * sizeof(double2);
+    return (size_t)2 * n1_max * ktot * sizeof(double2) + (size_t)n1_max * sizeof(double);
 }
 
+// d_u_old != nullptr: also return the energy of the unchanged A(k) from the same pass (trial moves)
 int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items, int n1_max, int site_stride,
-                 bool commit, double2 *A_base, double *d_u) {
+                 bool commit, double2 *A_base, double *d_u, double *d_u_old = nullptr) {
     const size_t lds = recip_lds_bytes(e, n1_max);
     if (lds > 64 * 1024)
         return set_error(MGPU_ERR_CAPACITY, "reciprocal update: molecule too large for the LDS phase tables (" +
@@ -289,14 +290,14 @@ int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items
     const int slot = commit ? MGPU_KERNEL_COMMIT : MGPU_KERNEL_RECIP;
     int rc = prof_begin(e, ln, slot, &a, &b);
     if (rc) return rc;
-    if (commit)
-        hipLaunchKernelGGL(recip_kernel<true>, dim3(n_items), dim3(kBlock), lds, ln.stream, e->tp, e->bx, e->d_pos,
-                           e->d_nmol, e->d_res_q, e->d_kpack, e->d_kw, A_base, d_items, (const double *)ln.d_sites.p,
-                           site_stride, d_u);
-    else
-        hipLaunchKernelGGL(recip_kernel<false>, dim3(n_items), dim3(kBlock), lds, ln.stream, e->tp, e->bx, e->d_pos,
-                           e->d_nmol, e->d_res_q, e->d_kpack, e->d_kw, A_base, d_items, (const double *)ln.d_sites.p,
-                           site_stride, d_u);
+#define MGPU_LAUNCH_RECIP(COMMIT, BOTH)                                                                              \
+    hipLaunchKernelGGL((recip_kernel<COMMIT, BOTH>), dim3(n_items), dim3(kBlock), lds, ln.stream, e->tp, e->bx,          \
+                       e->d_pos, e->d_nmol, e->d_res_q, e->d_kpack, e->d_kw, A_base, d_items,                            \
+                       (const double *)ln.d_sites.p, site_stride, d_u, d_u_old)
+    if (commit) MGPU_LAUNCH_RECIP(true, false);
+    else if (d_u_old) MGPU_LAUNCH_RECIP(false, true);
+    else MGPU_LAUNCH_RECIP(false, false);
+#undef MGPU_LAUNCH_RECIP
     rc = prof_end(e, ln, slot, a, b);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
@@ -820,7 +821,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     int rc;
     const size_t n2 = 2 * (size_t)n;
     const size_t site_bytes = (size_t)n * site_stride * 3 * sizeof(double);
-    const size_t pit_bytes = n2 * sizeof(PairItem), rit_bytes = n2 * sizeof(RecipItem);
+    const size_t pit_bytes = n2 * sizeof(PairItem), rit_bytes = (size_t)n * sizeof(RecipItem);
     if ((rc = ln.h_in.reserve(site_bytes + pit_bytes + rit_bytes))) return rc;
     double *h_sites = (double *)ln.h_in.p;
     PairItem *pit = (PairItem *)((char *)ln.h_in.p + site_bytes);
@@ -835,8 +836,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
         common = (common == -1 || common == n1) ? n1 : 0;
         pit[c] = PairItem{replica[c], t[c], m[c], -1, 0};
         pit[n + c] = PairItem{replica[c], t[c], m[c], c, 0};
-        rit[c] = RecipItem{replica[c], t[c], m[c], MGPU_NONE, -1, 0};
-        rit[n + c] = RecipItem{replica[c], t[c], m[c], MGPU_MOVE, c, 0};
+        rit[c] = RecipItem{replica[c], t[c], m[c], MGPU_MOVE, c, 0};   // one k sweep yields old and new
     }
     std::memcpy(h_sites, sites, site_bytes);
     if ((rc = ln.d_items.reserve(pit_bytes))) return rc;
@@ -851,7 +851,8 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     const int nsplit = choose_nsplit(e, (int)n2, replica[0]);
     if ((rc = launch_pair(e, ln, (const PairItem *)ln.d_items.p, (int)n2, std::max(common, 0), site_stride, nsplit, d_lj, d_c)))
         return rc;
-    if ((rc = launch_recip(e, ln, (const RecipItem *)ln.d_items2.p, (int)n2, n1_max, site_stride, false, e->d_A, d_u)))
+    // d_u layout matches the pair outputs: [0, n) old state, [n, 2n) new state
+    if ((rc = launch_recip(e, ln, (const RecipItem *)ln.d_items2.p, n, n1_max, site_stride, false, e->d_A, d_u + n, d_u)))
         return rc;
     HIP_TRY(hipMemcpyAsync(ln.h_out.p, ln.d_out.p, 3 * n2 * sizeof(double), hipMemcpyDeviceToHost, ln.stream));
     ln.n_submitted = n;

@@ -430,24 +430,30 @@ __device__ __forceinline__ double2 phase_entry(double theta, int k) {
 
 // SingleMolFourierTerms + ComputeRecipEnergySingleMol (ewald_phase.f90:383-420,
 // ewald_energy.f90:191-274) for one item per workgroup.
-// COMMIT = false: u[item] = prefactor * sum_k ff W |A + delta|^2, A untouched.
+// COMMIT = false: u_new[item] = prefactor * sum_k ff W |A + delta|^2, A untouched; with BOTH also
+//                 u_old[item] = prefactor * sum_k ff W |A|^2 from the same pass over k (the reference's
+//                 ComputeOldEnergy call, where delta = 0, monte_carlo_utils.f90:388).
 // COMMIT = true : A <- A + delta, then the replica's coordinates / molecule count are updated.
 // Dynamic LDS: two table sets (new, old) of n1 * ktot complex entries,
-// ktot = (kmax_x + 1) + (kmax_y + 1) + (kmax_z + 1); entry (a, axis, k >= 0).
-template <bool COMMIT>
+// ktot = (kmax_x + 1) + (kmax_y + 1) + (kmax_z + 1); entry (a, axis, k >= 0), then n1 charges.
+// Each thread owns k = tid + 256 j; A, ff*W and the packed indices of kRecipChunk of them are
+// loaded up front so that the L2 latencies overlap instead of serialising per k.
+constexpr int kRecipChunk = 5;
+template <bool COMMIT, bool BOTH>
 __global__ __launch_bounds__(kBlock) void recip_kernel(
     Topo tp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
     const int *__restrict__ kpack, const double *__restrict__ kw, double2 *__restrict__ A_base,
     const RecipItem *__restrict__ items, const double *__restrict__ cand_sites, int site_stride,
-    double *__restrict__ u_out) {
+    double *__restrict__ u_new, double *__restrict__ u_old) {
     extern __shared__ double2 s_tab[];
-    __shared__ double s_red[kWavesPerBlock];
+    __shared__ double s_red[2 * kWavesPerBlock];
 
     const RecipItem it = items[blockIdx.x];
     const int n1 = tp.n1[it.t];
     const int kofs[3] = {0, bx.kmax[0] + 1, bx.kmax[0] + bx.kmax[1] + 2};
     const int ktot = bx.kmax[0] + bx.kmax[1] + bx.kmax[2] + 3;
     double2 *tab_new = s_tab, *tab_old = s_tab + n1 * ktot;
+    double *s_q = reinterpret_cast<double *>(s_tab + 2 * n1 * ktot);
     double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
     double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
     const bool use_new = (it.kind == 0 /*MOVE*/ || it.kind == 1 /*CREATION*/);
@@ -469,51 +475,69 @@ __global__ __launch_bounds__(kBlock) void recip_kernel(
         }
         s_tab[e] = phase_entry(atom_phase(bx, axis, x, y, z), k);
     }
+    for (int a = threadIdx.x; a < n1; a += kBlock) s_q[a] = res_q[it.t * tp.max_atom + a];
     __syncthreads();
 
     double2 *A = A_base + (size_t)it.replica * bx.nk;
-    double acc = 0.0;
-    for (int k = threadIdx.x; k < bx.nk; k += kBlock) {
-        const int kp = kpack[k];
-        const int kx = kp & 0xff, ky = ((kp >> 8) & 0xff) - 128, kz = ((kp >> 16) & 0xff) - 128;
-        const int aky = ky < 0 ? -ky : ky, akz = kz < 0 ? -kz : kz;
-        double dre = 0.0, dim = 0.0;
-        for (int a = 0; a < n1; ++a) {
-            const double q = res_q[it.t * tp.max_atom + a];
-            double2 pn = make_double2(0.0, 0.0), po = make_double2(0.0, 0.0);
-            if (use_new) {
-                const double2 *t = tab_new + a * ktot;
-                double2 Y = t[kofs[1] + aky], Z = t[kofs[2] + akz];
-                if (ky < 0) Y.y = -Y.y;
-                if (kz < 0) Z.y = -Z.y;
-                pn = cmul(cmul(t[kx], Y), Z);
-            }
-            if (use_old) {
-                const double2 *t = tab_old + a * ktot;
-                double2 Y = t[kofs[1] + aky], Z = t[kofs[2] + akz];
-                if (ky < 0) Y.y = -Y.y;
-                if (kz < 0) Z.y = -Z.y;
-                po = cmul(cmul(t[kx], Y), Z);
-            }
-            // ewald_energy.f90:241-256
-            dre += q * (pn.x - po.x);
-            dim += q * (pn.y - po.y);
+    double acc = 0.0, acc0 = 0.0;
+    for (int k0 = threadIdx.x; k0 < bx.nk; k0 += kBlock * kRecipChunk) {
+        double2 Ak[kRecipChunk];
+        double w[kRecipChunk];
+        int kp[kRecipChunk];
+#pragma unroll
+        for (int j = 0; j < kRecipChunk; ++j) {
+            const int k = k0 + j * kBlock;
+            const bool in = k < bx.nk;
+            Ak[j] = in ? A[k] : make_double2(0.0, 0.0);
+            w[j] = (in && !COMMIT) ? kw[k] : 0.0;
+            kp[j] = in ? kpack[k] : ((128 << 8) | (128 << 16));   // (0, 0, 0): harmless filler
         }
-        double2 Ak = A[k];
-        Ak.x += dre;
-        Ak.y += dim;
-        if (COMMIT) A[k] = Ak;
-        else acc += kw[k] * fma(Ak.x, Ak.x, Ak.y * Ak.y);   // ewald_energy.f90:259-266
+#pragma unroll
+        for (int j = 0; j < kRecipChunk; ++j) {
+            const int kx = kp[j] & 0xff, ky = ((kp[j] >> 8) & 0xff) - 128, kz = ((kp[j] >> 16) & 0xff) - 128;
+            const int aky = ky < 0 ? -ky : ky, akz = kz < 0 ? -kz : kz;
+            double dre = 0.0, dim = 0.0;
+            for (int a = 0; a < n1; ++a) {
+                const double q = s_q[a];
+                double2 pn = make_double2(0.0, 0.0), po = make_double2(0.0, 0.0);
+                if (use_new) {
+                    const double2 *t = tab_new + a * ktot;
+                    double2 Y = t[kofs[1] + aky], Z = t[kofs[2] + akz];
+                    if (ky < 0) Y.y = -Y.y;
+                    if (kz < 0) Z.y = -Z.y;
+                    pn = cmul(cmul(t[kx], Y), Z);
+                }
+                if (use_old) {
+                    const double2 *t = tab_old + a * ktot;
+                    double2 Y = t[kofs[1] + aky], Z = t[kofs[2] + akz];
+                    if (ky < 0) Y.y = -Y.y;
+                    if (kz < 0) Z.y = -Z.y;
+                    po = cmul(cmul(t[kx], Y), Z);
+                }
+                // ewald_energy.f90:241-256
+                dre += q * (pn.x - po.x);
+                dim += q * (pn.y - po.y);
+            }
+            if (BOTH) acc0 += w[j] * fma(Ak[j].x, Ak[j].x, Ak[j].y * Ak[j].y);
+            const double nx = Ak[j].x + dre, ny = Ak[j].y + dim;
+            if (COMMIT) {
+                if (k0 + j * kBlock < bx.nk) A[k0 + j * kBlock] = make_double2(nx, ny);
+            } else {
+                acc += w[j] * fma(nx, nx, ny * ny);                 // ewald_energy.f90:259-266
+            }
+        }
     }
 
     if (!COMMIT) {
         acc = wave_sum(acc);
-        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+        if (BOTH) acc0 = wave_sum(acc0);
+        if ((threadIdx.x & 63) == 0) { s_red[2 * (threadIdx.x >> 6)] = acc; s_red[2 * (threadIdx.x >> 6) + 1] = acc0; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            double u = 0.0;
-            for (int w = 0; w < kWavesPerBlock; ++w) u += s_red[w];
-            u_out[blockIdx.x] = u * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;   // ewald_energy.f90:272
+            double u = 0.0, u0 = 0.0;
+            for (int wv = 0; wv < kWavesPerBlock; ++wv) { u += s_red[2 * wv]; u0 += s_red[2 * wv + 1]; }
+            u_new[blockIdx.x] = u * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;   // ewald_energy.f90:272
+            if (BOTH) u_old[blockIdx.x] = u0 * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;
         }
     } else {
         // every read of the old coordinates happened before the barrier above
