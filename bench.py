@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--host", choices=["fortran", "python"], default="fortran",
                     help="Metropolis driver: the Fortran farm (mc_farm.f90, two overlapped lanes) or the numpy one")
     ap.add_argument("--host-threads", type=int, default=8, help="OpenMP threads of the Fortran driver (per GPU)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
+    ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -99,13 +101,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
+    device = local_rank if args.device is None else args.device
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from maniac_mc_amd import _lib, synth
     system = synth.spce_box(args.n_side)
@@ -115,7 +119,7 @@ def main():
     else:
         from maniac_mc_amd.farm import ReplicaFarm as Farm
     kw = dict(n_threads=args.host_threads) if args.host == "fortran" else {}
-    farm = Farm(system, args.replicas, device=local_rank, seed=1000 + rank,
+    farm = Farm(system, args.replicas, device=device, seed=1000 + rank,
                 translation_step=t_step, rotation_step=r_step, p_translation=0.5, **kw)
     eng = farm.eng
     N, Nk, R = system.n_atoms, eng.nk, args.replicas
@@ -124,27 +128,24 @@ def main():
     eng.profile_enable(True)
     eng.profile_reset()
 
+    from maniac_mc_amd import exchange
+
     def fence():
-        if dist is not None:
-            dist.barrier()
+        exchange.barrier()
         torch.cuda.synchronize()
 
     fence()
     t0 = time.perf_counter()
     accepted = farm.run(args.steps)
-    # the path's one real exchange step: per-block gather of each rank's counters
-    stats = torch.tensor([float(accepted), float(args.steps * R)], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        gathered = [torch.zeros_like(stats) for _ in range(world)]
-        dist.all_gather(gathered, stats)
-        stats = torch.stack(gathered).sum(0)
+    # the path's one real exchange step: per-block all-gather of every rank's counters and
+    # molecule-count histogram (NVT here, so the histogram is a single bin; the message size is the same)
+    n_now = [int(system.n_mol[0])] * R
+    sums_by_rank, hist_by_rank = exchange.gather_block_stats(
+        [float(accepted), float(args.steps * R)], exchange.molecule_count_histogram(n_now, 5001))
     fence()
-    elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-    tot_acc, tot_trials = float(stats[0].item()), float(stats[1].item())
+    elapsed = exchange.max_over_ranks(time.perf_counter() - t0)
+    tot_acc, tot_trials = float(sums_by_rank[:, 0].sum()), float(sums_by_rank[:, 1].sum())
+    assert int(hist_by_rank.sum()) == R * world
 
     n_pair, ms_pair = eng.profile_get(_lib.KERNEL_PAIR)
     n_rec, ms_rec = eng.profile_get(_lib.KERNEL_RECIP)
