@@ -88,10 +88,12 @@ int mgpu_ewald_kvectors(const double reciprocal[9], double alpha, const int kmax
                         int *kx, int *ky, int *kz, double *k2mag, double *form_factor,
                         double *weights);
 
-/* The pair sweep reads erfc from an LDS-resident table of piecewise degree-7 polynomials
- * (maniac_mc_amd/csrc/mgpu_erfc_table.h) instead of calling libm's erfc (energy_utils.f90:432).
- * This evaluates the same table with the same arithmetic on the host, for accuracy checks. */
-int mgpu_erfc_table_eval(int n, const double *x, double *out);
+/* The pair sweep does not call libm's erfc (energy_utils.f90:432): it reads G(r^2) =
+ * erfc(alpha r)/r from an LDS-resident table of degree-6 polynomials indexed by the binary exponent
+ * and top 6 mantissa bits of r^2 (built in long double at engine creation for the engine's alpha and
+ * box).  This evaluates the same table with the same arithmetic on the host, for accuracy checks:
+ * out[i] = erfc(alpha sqrt(r2[i])) / sqrt(r2[i]) for r2[i] > 0; r2_max bounds the table range. */
+int mgpu_coulomb_table_eval(double alpha, double r2_max, int n, const double *r2, double *out);
 
 /* ------------------------------------------------------------------------------------------
  * Engine life cycle

@@ -110,7 +110,8 @@ struct mgpu_engine {
     int *d_kpack = nullptr;
     double *d_kw = nullptr;
     double2 *d_pair_tab = nullptr;
-    double *d_erfc_tab = nullptr;    // piecewise-polynomial erfc table (mgpu_erfc_table.h)
+    char *d_coul_tab = nullptr;      // Coulomb table rows (build_coulomb_table), staged into LDS by the pair sweep
+    size_t coul_bytes = 0;
     int n_cu = 256;                  // compute units of the device
     int pair_blocks_per_cu = 2;      // resident pair-sweep workgroups per CU (VGPR / LDS bound)
     double *d_res_q = nullptr;
@@ -239,8 +240,8 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
     rc = prof_begin(e, ln, MGPU_KERNEL_PAIR, &a, &b);
     if (rc) return rc;
 #define MGPU_LAUNCH_PAIR(NS, ORD)                                                                                       \
-    hipLaunchKernelGGL((pair_sweep_kernel<NS, ORD>), dim3(grid), dim3(kPairBlock), 0, ln.stream, e->tp, e->bx,          \
-                       e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_erfc_tab, d_items,          \
+    hipLaunchKernelGGL((pair_sweep_kernel<NS, ORD>), dim3(grid), dim3(kPairBlock), e->coul_bytes, ln.stream, e->tp,   \
+                       e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab, d_items,   \
                        (const double *)ln.d_sites.p, site_stride, nsplit, n_work, (double2 *)ln.d_partials.p)
     if (ordered) {
         MGPU_LAUNCH_PAIR(0, true);
@@ -432,7 +433,6 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     std::memcpy(bx.rcp, e->reciprocal, sizeof(double) * 9);
     bx.rc2 = e->rc * e->rc;
     bx.alpha = e->alpha;
-    bx.alpha32 = e->alpha * (double)kErfcInvH;
     bx.volume = e->volume;
     bx.nk = e->nk;
 
@@ -477,8 +477,19 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     HIP_TRY_E(hipMalloc(&e->d_kpack, e->nk * sizeof(int)));
     HIP_TRY_E(hipMalloc(&e->d_kw, e->nk * sizeof(double)));
     HIP_TRY_E(hipMalloc(&e->d_pair_tab, ptab.size() * sizeof(double2)));
-    HIP_TRY_E(hipMalloc(&e->d_erfc_tab, sizeof(kErfcTable)));
-    HIP_TRY_E(hipMemcpy(e->d_erfc_tab, kErfcTable, sizeof(kErfcTable), hipMemcpyHostToDevice));
+    {
+        // Coulomb table for this alpha, covering every minimum-image distance of this box
+        std::vector<CoulRow> rows;
+        const double s_max = 0.25 * (bx.L[0] * bx.L[0] + bx.L[1] * bx.L[1] + bx.L[2] * bx.L[2]) * 1.0001;
+        int idx_base = 0;
+        if (int rc2 = build_coulomb_table(e->alpha, std::max(s_max, 1.0), rows, &idx_base)) return fail(rc2);
+        e->bx.coul_idx_base = idx_base;
+        e->bx.coul_last_row = (int)rows.size() - 1;
+        e->coul_bytes = rows.size() * sizeof(CoulRow);
+        if (e->coul_bytes + 16 * 1024 > 150 * 1024) return fail(set_error(MGPU_ERR_CAPACITY, "Coulomb table does not fit LDS"));
+        HIP_TRY_E(hipMalloc(&e->d_coul_tab, e->coul_bytes));
+        HIP_TRY_E(hipMemcpy(e->d_coul_tab, rows.data(), e->coul_bytes, hipMemcpyHostToDevice));
+    }
     {
         hipDeviceProp_t prop;
         HIP_TRY_E(hipGetDeviceProperties(&prop, device));
@@ -509,7 +520,7 @@ int mgpu_engine_destroy(mgpu_engine *e) {
     (void)hipSetDevice(e->device);
     for (auto &ln : e->lanes) if (ln.stream) (void)hipStreamSynchronize(ln.stream);
     for (void *p : {(void *)e->d_pos, (void *)e->d_nmol, (void *)e->d_A, (void *)e->d_kpack, (void *)e->d_kw,
-                    (void *)e->d_pair_tab, (void *)e->d_erfc_tab, (void *)e->d_res_q, (void *)e->d_res_atype, (void *)e->d_atom_res,
+                    (void *)e->d_pair_tab, (void *)e->d_coul_tab, (void *)e->d_res_q, (void *)e->d_res_atype, (void *)e->d_atom_res,
                     (void *)e->d_atom_mol, (void *)e->d_atom_q, (void *)e->d_phase_tab, (void *)e->d_S})
         if (p) (void)hipFree(p);
     e->h_stage.release();

@@ -10,9 +10,9 @@
 // W(k) come out identical to the Fortran on the same inputs (checked in tests/).
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "../../include/maniac_gpu.h"
-#include "mgpu_erfc_table.h"
 #include "mgpu_internal.h"
 
 namespace mgpu {
@@ -124,6 +124,96 @@ int ewald_kvectors(const double rcp[9], double alpha, const int kmax[3], int nk,
     return MGPU_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Coulomb table: G(s) = erfc(alpha sqrt(s)) / sqrt(s) against s = r^2, one row per
+// (binary exponent, top kCoulM mantissa bits) of s, i.e. intervals of relative width 2^-6.  Each row
+// is a degree-6 polynomial in t = (s - s_lo) / (s_hi - s_lo) in [0, 1): five fp64 coefficients and
+// two fp32 ones (c5, c6 are < 1e-9 of c0, so 24 bits suffice) = 48 bytes = three ds_read_b128.
+// Coefficients: Chebyshev interpolation at 7 nodes in long double (64-bit mantissa, erfcl),
+// re-expanded in t, rounded once.  Indexing by the bits of s removes sqrt / rsqrt / erfc / exp and
+// every division from the per-pair arithmetic of energy_utils.f90:432.
+// ------------------------------------------------------------------------------------------
+int build_coulomb_table(double alpha, double s_max, std::vector<CoulRow> &rows, int *idx_base) {
+    if (!(alpha > 0.0) || !(s_max > 0.0) || !std::isfinite(s_max))
+        return set_error(MGPU_ERR_INVALID_ARG, "build_coulomb_table: bad alpha / range");
+    int emax = kCoulEmin;
+    while (std::ldexp(1.0, emax + 1) <= s_max) ++emax;          // 2^(emax+1) > s_max
+    if (emax - kCoulEmin + 1 > 40) return set_error(MGPU_ERR_CAPACITY, "build_coulomb_table: range too large");
+    const int per_oct = 1 << kCoulM, n_oct = emax - kCoulEmin + 1;
+    rows.assign((size_t)n_oct * per_oct + 1, CoulRow{});          // last row stays all zero (clamp target)
+    *idx_base = (1023 + kCoulEmin) * per_oct;
+    constexpr int N = 7;
+    const long double pi = 3.14159265358979323846264338327950288L;
+    long double node[N], cosjk[N][N];
+    for (int k = 0; k < N; ++k) {
+        node[k] = cosl(pi * (2 * k + 1) / (2.0L * N));
+        for (int j = 0; j < N; ++j) cosjk[j][k] = cosl(pi * j * (2 * k + 1) / (2.0L * N));
+    }
+    // Chebyshev T_j as monomials in u
+    long double T[N][N] = {};
+    T[0][0] = 1.0L;
+    T[1][1] = 1.0L;
+    for (int j = 2; j < N; ++j)
+        for (int i = 0; i < N; ++i) T[j][i] = (i > 0 ? 2.0L * T[j - 1][i - 1] : 0.0L) - T[j - 2][i];
+    // binomials for u = 2t - 1
+    long double binom[N][N] = {};
+    for (int j = 0; j < N; ++j) {
+        binom[j][0] = 1.0L;
+        for (int i = 1; i <= j; ++i) binom[j][i] = binom[j - 1][i - 1] + (i <= j - 1 ? binom[j - 1][i] : 0.0L);
+    }
+    const long double al = alpha;
+    for (int o = 0; o < n_oct; ++o)
+        for (int q = 0; q < per_oct; ++q) {
+            const long double base = ldexpl(1.0L, kCoulEmin + o);
+            const long double a = base * (1.0L + (long double)q / per_oct), b = base * (1.0L + (long double)(q + 1) / per_oct);
+            long double f[N], c[N], mono[N] = {}, tc[N] = {};
+            for (int k = 0; k < N; ++k) {
+                const long double sv = 0.5L * (a + b) + 0.5L * (b - a) * node[k], r = sqrtl(sv);
+                f[k] = erfcl(al * r) / r;
+            }
+            for (int j = 0; j < N; ++j) {
+                long double acc = 0.0L;
+                for (int k = 0; k < N; ++k) acc += f[k] * cosjk[j][k];
+                c[j] = acc * 2.0L / N;
+            }
+            c[0] *= 0.5L;
+            for (int j = 0; j < N; ++j)
+                for (int i = 0; i <= j; ++i) mono[i] += c[j] * T[j][i];
+            for (int j = 0; j < N; ++j)
+                for (int i = 0; i <= j; ++i) {
+                    const long double sign = ((j - i) & 1) ? -1.0L : 1.0L;
+                    tc[i] += mono[j] * binom[j][i] * ldexpl(1.0L, i) * sign;
+                }
+            CoulRow &row = rows[(size_t)o * per_oct + q];
+            for (int i = 0; i < 5; ++i) row.c[i] = (double)tc[i];
+            row.c5 = (float)tc[5];
+            row.c6 = (float)tc[6];
+        }
+    return MGPU_OK;
+}
+
+double coulomb_table_eval_host(const std::vector<CoulRow> &rows, int idx_base, double alpha, double s) {
+    unsigned long long bits;
+    std::memcpy(&bits, &s, 8);
+    const int hi = (int)(bits >> 32);
+    int row = (hi >> (20 - kCoulM)) - idx_base;
+    if (row < 0) {                                     // below the table (r < 0.5 A): direct evaluation
+        const double r = std::sqrt(s);
+        return std::erfc(alpha * r) / r;
+    }
+    const int last = (int)rows.size() - 1;
+    if (row > last) row = last;
+    const unsigned long long mb = (bits & ((1ull << (52 - kCoulM)) - 1)) | (0x3ffull << 52);
+    double m;
+    std::memcpy(&m, &mb, 8);
+    const double t = std::fma(m, (double)(1 << kCoulM), -(double)(1 << kCoulM));
+    const CoulRow &r = rows[row];
+    double p = (double)r.c6;
+    p = std::fma(p, t, (double)r.c5);
+    for (int i = 4; i >= 0; --i) p = std::fma(p, t, r.c[i]);
+    return p;
+}
+
 }  // namespace mgpu
 
 extern "C" {
@@ -137,20 +227,16 @@ int mgpu_ewald_setup(const double metrics[9], double *rc, double *tol, double *a
     return mgpu::ewald_setup(metrics, rc, tol, alpha, screening_factor, fourier_precision, kmax, n_kvectors);
 }
 
-// Host evaluation of the erfc table the pair sweep reads from LDS (same rows, same Horner/FMA order
-// as erfc_lds() in mgpu_kernels.h), so its accuracy can be checked without a GPU.
-int mgpu_erfc_table_eval(int n, const double *x, double *out) {
-    if (n < 0 || (n > 0 && (!x || !out))) return mgpu::set_error(MGPU_ERR_INVALID_ARG, "mgpu_erfc_table_eval: bad argument");
-    for (int k = 0; k < n; ++k) {
-        if (!(x[k] >= 0.0)) return mgpu::set_error(MGPU_ERR_INVALID_ARG, "mgpu_erfc_table_eval: x must be >= 0");
-        const double x32 = x[k] * (double)mgpu::kErfcInvH;
-        const int i = x32 >= (double)(mgpu::kErfcRows - 1) ? mgpu::kErfcRows - 1 : (int)x32;
-        const double t = x32 - (double)i;
-        const double *c = mgpu::kErfcTable + (size_t)i * mgpu::kErfcStride;
-        double p = c[7];
-        for (int j = 6; j >= 0; --j) p = std::fma(p, t, c[j]);
-        out[k] = p;
-    }
+// Host evaluation of the Coulomb table the pair sweep reads from LDS (same rows and the same
+// index / Horner / FMA arithmetic as coul_lds() in mgpu_kernels.h), so its accuracy can be checked
+// without a GPU.  out[i] = erfc(alpha sqrt(r2[i])) / sqrt(r2[i]).
+int mgpu_coulomb_table_eval(double alpha, double r2_max, int n, const double *r2, double *out) {
+    if (n < 0 || (n > 0 && (!r2 || !out))) return mgpu::set_error(MGPU_ERR_INVALID_ARG, "mgpu_coulomb_table_eval: bad argument");
+    std::vector<mgpu::CoulRow> rows;
+    int idx_base = 0;
+    int rc = mgpu::build_coulomb_table(alpha, r2_max, rows, &idx_base);
+    if (rc) return rc;
+    for (int k = 0; k < n; ++k) out[k] = mgpu::coulomb_table_eval_host(rows, idx_base, alpha, r2[k]);
     return MGPU_OK;
 }
 

@@ -3,6 +3,7 @@
 #define MGPU_INTERNAL_H
 
 #include <string>
+#include <vector>
 
 namespace mgpu {
 
@@ -21,6 +22,17 @@ int ewald_setup(const double metrics[9], double *rc, double *tol, double *alpha,
                 double *fourier_precision, int kmax[3], int *nk);
 int ewald_kvectors(const double rcp[9], double alpha, const int kmax[3], int nk, int *kx, int *ky, int *kz,
                    double *k2mag, double *ff, double *w);
+
+// Coulomb table rows (see build_coulomb_table in mgpu_host_setup.cpp)
+constexpr int kCoulM = 6;        // top mantissa bits used for the row index: 64 rows per octave of r^2
+constexpr int kCoulEmin = -2;    // table starts at r^2 = 2^-2 (r = 0.5 A); below it the slow path runs
+struct CoulRow {
+    double c[5];
+    float c5, c6;
+};
+static_assert(sizeof(CoulRow) == 48, "CoulRow must be three 16-byte LDS reads");
+int build_coulomb_table(double alpha, double s_max, std::vector<CoulRow> &rows, int *idx_base);
+double coulomb_table_eval_host(const std::vector<CoulRow> &rows, int idx_base, double alpha, double s);
 
 }  // namespace mgpu
 

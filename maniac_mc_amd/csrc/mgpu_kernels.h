@@ -24,7 +24,6 @@
 
 #include <type_traits>
 
-#include "mgpu_erfc_table.h"
 #include "mgpu_internal.h"
 
 namespace mgpu {
@@ -59,7 +58,8 @@ struct BoxDev {
     double rcp[9];                // box%reciprocal, row-major
     double rc2;                   // real_space_cutoff^2
     double alpha;
-    double alpha32;               // alpha * 32: distance -> erfc table coordinate
+    int coul_idx_base;            // Coulomb table: row = (hi32(r^2) >> 14) - coul_idx_base
+    int coul_last_row;            // index of the all-zero clamp row (= number of real rows)
     double volume;
     int kmax[3];
     int nk;
@@ -102,19 +102,33 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return fma(y * e, fma(0.375, e, 0.5), y);
 }
 
-// erfc(x) from the LDS-resident table of degree-7 polynomials on intervals of width 1/32
-// (mgpu_erfc_table.h, generated in 60-digit arithmetic).  x32 = 32 x >= 0.  Each lane gathers its
-// own row with four ds_read_b128 (80-byte row stride spreads rows over all bank groups); no exp,
-// no division, no lane-divergent branch.
-__device__ __forceinline__ double erfc_lds(double x32, const double *__restrict__ tab) {
-    const int i = min((int)x32, kErfcRows - 1);        // row 384 is all zeros: erfc(x >= 12) -> 0
-    const double t = x32 - (double)i;                  // exact: local coordinate in [0, 1)
-    const double2 *row = reinterpret_cast<const double2 *>(tab + __umul24(i, kErfcStride));
-    const double2 c01 = row[0], c23 = row[1], c45 = row[2], c67 = row[3];
-    double p = c67.y;
-    p = fma(p, t, c67.x);
-    p = fma(p, t, c45.y);
-    p = fma(p, t, c45.x);
+// 1/x: v_rcp_f64 + one Newton step with its second-order term (used only for LJ pairs)
+__device__ __forceinline__ double fast_rcp(double x) {
+    const double y = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, y, 1.0);
+    return fma(y, fma(e, e, e), y);
+}
+
+// G(s) = erfc(alpha sqrt(s)) / sqrt(s), s = r^2, from the LDS-resident Coulomb table
+// (build_coulomb_table, mgpu_host_setup.cpp): the row is selected by the binary exponent and the top
+// 6 mantissa bits of s, the local coordinate t in [0, 1) is the remaining mantissa, the value a
+// degree-6 polynomial (5 fp64 + 2 fp32 coefficients = 48 bytes = three ds_read_b128).  No sqrt, rsqrt,
+// erfc, exp or division.  `below` is set for s < 2^-2 (r < 0.5 A), where the caller takes the slow path.
+__device__ __forceinline__ double coul_lds(double s, const char *__restrict__ tab, int idx_base, int last_row,
+                                           bool &below) {
+    const int hi = __double2hiint(s);
+    int row = (hi >> (20 - kCoulM)) - idx_base;
+    below = row < 0;
+    row = min(max(row, 0), last_row);
+    const int hi_m = (hi & ((1 << (20 - kCoulM)) - 1)) | 0x3ff00000;
+    const double m = __hiloint2double(hi_m, __double2loint(s));          // in [1, 1 + 2^-6)
+    const double t = fma(m, (double)(1 << kCoulM), -(double)(1 << kCoulM));
+    const double2 *r = reinterpret_cast<const double2 *>(tab + __umul24(row, 48));
+    const double2 c01 = r[0], c23 = r[1], c4f = r[2];
+    const double c5 = (double)__int_as_float(__double2loint(c4f.y));
+    const double c6 = (double)__int_as_float(__double2hiint(c4f.y));
+    double p = fma(c6, t, c5);
+    p = fma(p, t, c4f.x);
     p = fma(p, t, c23.y);
     p = fma(p, t, c23.x);
     p = fma(p, t, c01.y);
@@ -122,29 +136,36 @@ __device__ __forceinline__ double erfc_lds(double x32, const double *__restrict_
     return p;
 }
 
+// r < 0.5 A (never reached by a physical configuration): direct evaluation.  GUARD: CoulombEnergy's
+// r < 1e-10 -> 0 (energy_utils.f90:244), which only the ordered static sweep applies.
+__device__ __attribute__((noinline)) double coul_slow(double s, double alpha, bool guard) {
+    const double r = sqrt(s);
+    if (guard && r < kErrorTol) return 0.0;
+    return erfc(alpha * r) / r;
+}
+
 // One site-atom pair: Lennard-Jones inside the cutoff (energy_utils.f90:417-424) and
-// erfc(alpha r)/r for every distance (energy_utils.f90:427-432).  do_lj / do_c are wave-uniform
-// in the plane-major sweep (scalar branches), per-lane in the site-major sweep.
+// erfc(alpha r)/r for every distance (energy_utils.f90:427-432).  Generic (per-lane flags) form used
+// by the site-major and NS = 0 sweeps; the register-site hot path inlines the same arithmetic.
 template <bool GUARD_R0>
 __device__ __forceinline__ void pair_term(double dx, double dy, double dz, const BoxDev &bx, double qq,
                                           double eps4, double sig2, bool do_lj, bool do_c,
-                                          const double *__restrict__ erfc_tab, double &elj, double &ec) {
+                                          const char *__restrict__ coul_tab, double &elj, double &ec) {
     dx = min_image(dx, bx.L[0], bx.invL[0]);
     dy = min_image(dy, bx.L[1], bx.invL[1]);
     dz = min_image(dz, bx.L[2], bx.invL[2]);
     const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
-    const double rinv = fast_rsqrt(r2);
     if (do_lj) {
-        const double s2 = sig2 * (rinv * rinv);
+        const double s2 = sig2 * fast_rcp(r2);
         const double s6 = s2 * s2 * s2;
         const double e = eps4 * fma(s6, s6, -s6);
         elj += (r2 < bx.rc2) ? e : 0.0;
     }
     if (do_c) {
-        const double r = r2 * rinv;
-        double term = qq * (erfc_lds(r * bx.alpha32, erfc_tab) * rinv);
-        if (GUARD_R0) term = (r < kErrorTol) ? 0.0 : term;  // CoulombEnergy, energy_utils.f90:244
-        ec += term;
+        bool below;
+        double g = coul_lds(r2, coul_tab, bx.coul_idx_base, bx.coul_last_row, below);
+        if (below) g = coul_slow(r2, bx.alpha, GUARD_R0);
+        ec += qq * g;
     }
 }
 
@@ -164,17 +185,17 @@ template <int NS, bool ORDERED>
 __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_kernel(
     Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
-    const double *__restrict__ erfc_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
+    const char *__restrict__ coul_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
     int site_stride, int nsplit, int n_work, double2 *__restrict__ partials) {
     constexpr int NREG = NS > 0 ? NS : 1;                 // register-resident sites
     constexpr int NSLAB = NS > 0 ? 1 : kPairWaves * kSiteChunk;
-    __shared__ __attribute__((aligned(16))) double s_erfc[kErfcRows * kErfcStride];
+    extern __shared__ __attribute__((aligned(16))) char s_coul[];     // (coul_last_row + 1) x 48 B
     __shared__ double2 s_pair[kMaxTypes * kMaxTypes];
     __shared__ double s_site[NSLAB * 4];
     __shared__ int s_sty[NSLAB];
 
-    for (int i = threadIdx.x; i < kErfcRows * kErfcStride / 2; i += kPairBlock)
-        reinterpret_cast<double2 *>(s_erfc)[i] = reinterpret_cast<const double2 *>(erfc_tab_g)[i];
+    for (int i = threadIdx.x; i < (bx.coul_last_row + 1) * 3; i += kPairBlock)
+        reinterpret_cast<double2 *>(s_coul)[i] = reinterpret_cast<const double2 *>(coul_tab_g)[i];
     const int nt = tp.n_types;
     for (int i = threadIdx.x; i < nt * nt; i += kPairBlock) s_pair[i] = pair_tab[i];
     __syncthreads();
@@ -290,28 +311,34 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                                     if (c + nsplit < cpp) fetch(c + nsplit, xn, yn, zn, vn);
                                     const double wgt = valid ? 1.0 : 0.0;
                                     const double rc2l = valid ? bx.rc2 : -1.0;
-                                    double r2[NREG], rinv[NREG];
+                                    double r2[NREG], g[NREG];
+                                    bool any_below = false;
 #pragma unroll
                                     for (int s = 0; s < NREG; ++s) {
                                         const double dx = min_image(xj - rx[s], bx.L[0], bx.invL[0]);
                                         const double dy = min_image(yj - ry[s], bx.L[1], bx.invL[1]);
                                         const double dz = min_image(zj - rz[s], bx.L[2], bx.invL[2]);
                                         r2[s] = fma(dz, dz, fma(dy, dy, dx * dx));
-                                        rinv[s] = fast_rsqrt(r2[s]);
                                     }
 #pragma unroll
                                     for (int s = 0; s < NREG; ++s) {
-                                        if (!ALL_C && !c_on[s]) continue;
-                                        const double r = r2[s] * rinv[s];
-                                        double e = erfc_lds(r * bx.alpha32, s_erfc) * rinv[s];
-                                        if (ORDERED) e = (r < kErrorTol) ? 0.0 : e;   // energy_utils.f90:244
-                                        acc[s] = fma(wgt, e, acc[s]);
+                                        if (!ALL_C && !c_on[s]) { g[s] = 0.0; continue; }
+                                        bool below;
+                                        g[s] = coul_lds(r2[s], s_coul, bx.coul_idx_base, bx.coul_last_row, below);
+                                        any_below = any_below || below;
                                     }
+                                    if (any_below) {   // r < 0.5 A somewhere in the wave: rare slow path
+#pragma unroll
+                                        for (int s = 0; s < NREG; ++s)
+                                            if ((ALL_C || c_on[s]) && r2[s] < 0.25) g[s] = coul_slow(r2[s], bx.alpha, ORDERED);
+                                    }
+#pragma unroll
+                                    for (int s = 0; s < NREG; ++s) acc[s] = fma(wgt, g[s], acc[s]);
                                     if (any_lj) {
 #pragma unroll
                                         for (int s = 0; s < NREG; ++s) {
                                             if (!lj[s]) continue;
-                                            const double s2 = sg2[s] * (rinv[s] * rinv[s]);
+                                            const double s2 = sg2[s] * fast_rcp(r2[s]);
                                             const double s6 = s2 * s2 * s2;
                                             const double e = e4[s] * fma(s6, s6, -s6);  // energy_utils.f90:421-423
                                             elj += (r2[s] < rc2l) ? e : 0.0;            // energy_utils.f90:417
@@ -346,7 +373,7 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                                 const bool do_lj = pt.x != 0.0;                        // epsilon = 0 contributes 0
                                 if ((do_c || do_lj) && valid)
                                     pair_term<ORDERED>(xj - w_site[s * 4 + 0], yj - w_site[s * 4 + 1], zj - w_site[s * 4 + 2],
-                                                       bx, qs * qj, pt.x, pt.y, do_lj, do_c, s_erfc, elj, ec);
+                                                       bx, qs * qj, pt.x, pt.y, do_lj, do_c, s_coul, elj, ec);
                             }
                         }
                     }
@@ -371,7 +398,7 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                             const bool do_c = qj_on && (fabs(qs) >= kErrorTol);
                             if (valid) {
                                 double e1 = 0.0, e2 = 0.0;
-                                pair_term<ORDERED>(xj - sx, yj - sy, zj - sz, bx, qs * qj, pt.x, pt.y, true, true, s_erfc, e1, e2);
+                                pair_term<ORDERED>(xj - sx, yj - sy, zj - sz, bx, qs * qj, pt.x, pt.y, true, true, s_coul, e1, e2);
                                 elj += (pt.x != 0.0) ? e1 : 0.0;
                                 ec += do_c ? e2 : 0.0;
                             }
