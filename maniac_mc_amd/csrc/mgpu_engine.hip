@@ -201,12 +201,12 @@ int replica_units(const mgpu_engine *e, int replica) {
 }
 
 int choose_nsplit(const mgpu_engine *e, int n_items, int replica_hint) {
-    // one wave per (item, split).  Aim at ~2 work units per resident wave (n_cu x 16): fewer, longer
-    // sweeps amortise the per-plane setup (measured: nsplit 2-4 beats 8-32 at 2048 items), but never
-    // give a wave fewer than ~8 sweep units of 64 atoms.
+    // one wave per (item, split).  Aim at one work unit per resident wave (n_cu x 16): fewer, longer
+    // sweeps amortise the per-plane setup (measured at 2048 items: nsplit 2 beats 1 and 4-32), but
+    // never give a wave fewer than ~8 sweep units of 64 atoms.
     const int units = std::max(1, replica_units(e, replica_hint));
     const int max_split = std::max(1, units / 8);
-    const int want = (2 * e->n_cu * 16 + n_items - 1) / std::max(1, n_items);
+    const int want = (e->n_cu * 16 + n_items - 1) / std::max(1, n_items);
     if (const char *ov = std::getenv("MGPU_PAIR_NSPLIT")) return std::max(1, std::min(std::atoi(ov), std::max(1, units)));
     return std::max(1, std::min(want, max_split));
 }

@@ -127,7 +127,7 @@ int ewald_kvectors(const double rcp[9], double alpha, const int kmax[3], int nk,
 // ------------------------------------------------------------------------------------------
 // Coulomb table: G(s) = erfc(alpha sqrt(s)) / sqrt(s) against s = r^2, one row per
 // (binary exponent, top kCoulM mantissa bits) of s, i.e. intervals of relative width 2^-6.  Each row
-// is a degree-6 polynomial in t = (s - s_lo) / (s_hi - s_lo) in [0, 1): five fp64 coefficients and
+// is a degree-6 polynomial in the mantissa remainder t' = (s - s_lo) / 2^e in [0, 2^-6): five fp64 coefficients and
 // two fp32 ones (c5, c6 are < 1e-9 of c0, so 24 bits suffice) = 48 bytes = three ds_read_b128.
 // Coefficients: Chebyshev interpolation at 7 nodes in long double (64-bit mantissa, erfcl),
 // re-expanded in t, rounded once.  Indexing by the bits of s removes sqrt / rsqrt / erfc / exp and
@@ -184,10 +184,11 @@ int build_coulomb_table(double alpha, double s_max, std::vector<CoulRow> &rows, 
                     const long double sign = ((j - i) & 1) ? -1.0L : 1.0L;
                     tc[i] += mono[j] * binom[j][i] * ldexpl(1.0L, i) * sign;
                 }
+            // the device evaluates in t' = t / 64 = mantissa remainder (m - 1): scale c_i by 64^i
             CoulRow &row = rows[(size_t)o * per_oct + q];
-            for (int i = 0; i < 5; ++i) row.c[i] = (double)tc[i];
-            row.c5 = (float)tc[5];
-            row.c6 = (float)tc[6];
+            for (int i = 0; i < 5; ++i) row.c[i] = (double)ldexpl(tc[i], kCoulM * i);
+            row.c5 = (float)ldexpl(tc[5], kCoulM * 5);
+            row.c6 = (float)ldexpl(tc[6], kCoulM * 6);
         }
     return MGPU_OK;
 }
@@ -206,7 +207,7 @@ double coulomb_table_eval_host(const std::vector<CoulRow> &rows, int idx_base, d
     const unsigned long long mb = (bits & ((1ull << (52 - kCoulM)) - 1)) | (0x3ffull << 52);
     double m;
     std::memcpy(&m, &mb, 8);
-    const double t = std::fma(m, (double)(1 << kCoulM), -(double)(1 << kCoulM));
+    const double t = m - 1.0;
     const CoulRow &r = rows[row];
     double p = (double)r.c6;
     p = std::fma(p, t, (double)r.c5);

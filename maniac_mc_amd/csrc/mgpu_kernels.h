@@ -111,18 +111,21 @@ __device__ __forceinline__ double fast_rcp(double x) {
 
 // G(s) = erfc(alpha sqrt(s)) / sqrt(s), s = r^2, from the LDS-resident Coulomb table
 // (build_coulomb_table, mgpu_host_setup.cpp): the row is selected by the binary exponent and the top
-// 6 mantissa bits of s, the local coordinate t in [0, 1) is the remaining mantissa, the value a
+// 6 mantissa bits of s, the local coordinate t in [0, 2^-6) is the remaining mantissa, the value a
 // degree-6 polynomial (5 fp64 + 2 fp32 coefficients = 48 bytes = three ds_read_b128).  No sqrt, rsqrt,
 // erfc, exp or division.  `below` is set for s < 2^-2 (r < 0.5 A), where the caller takes the slow path.
 __device__ __forceinline__ double coul_lds(double s, const char *__restrict__ tab, int idx_base, int last_row,
                                            bool &below) {
     const int hi = __double2hiint(s);
-    int row = (hi >> (20 - kCoulM)) - idx_base;
-    below = row < 0;
-    row = min(max(row, 0), last_row);
-    const int hi_m = (hi & ((1 << (20 - kCoulM)) - 1)) | 0x3ff00000;
+    const int srow = (hi >> (20 - kCoulM)) - idx_base;
+    below = srow < 0;
+    // one unsigned min clamps both ends: rows below the table wrap to huge values and land, like rows
+    // above it, on the all-zero last row (the caller replaces `below` lanes by the slow path)
+    const unsigned row = min((unsigned)srow, (unsigned)last_row);
+    constexpr int kMant = (1 << (20 - kCoulM)) - 1;
+    const int hi_m = (kMant & hi) | (~kMant & 0x3ff00000);                 // v_bfi_b32
     const double m = __hiloint2double(hi_m, __double2loint(s));          // in [1, 1 + 2^-6)
-    const double t = fma(m, (double)(1 << kCoulM), -(double)(1 << kCoulM));
+    const double t = m - 1.0;                                            // exact; rows are expanded in it
     const double2 *r = reinterpret_cast<const double2 *>(tab + __umul24(row, 48));
     const double2 c01 = r[0], c23 = r[1], c4f = r[2];
     const double c5 = (double)__int_as_float(__double2loint(c4f.y));
@@ -232,6 +235,9 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                 load_site(a, rx[a], ry[a], rz[a]);
                 rq[a] = res_q[it.t * tp.max_atom + a];
                 rty[a] = res_atype[it.t * tp.max_atom + a];
+                // wave-uniform values, but parked in VGPRs: the sweep already needs ~100 SGPRs for box,
+                // pointers and per-plane parameters, and spilled SGPRs cost v_readlane in the hot loop
+                asm volatile("" : "+v"(rx[a]), "+v"(ry[a]), "+v"(rz[a]));
             }
         }
 
@@ -289,12 +295,22 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                             int c = split - ((plane_base + a2) * cpp) % nsplit;    // units are dealt round-robin
                             if (c < 0) c += nsplit;
                             if (c >= cpp) continue;
-                            auto fetch = [&](int cc, double &x, double &y, double &z, bool &ok) {
-                                const int m2 = cc * 64 + lane;
-                                ok = m2 < nm;
-                                if (same_t) ok = ok && (ORDERED ? (m2 > it.m) : (m2 != it.m));
-                                const int j = seg2 + a2 * cap2 + (ok ? m2 : dummy_m);
-                                x = px[j]; y = py[j]; z = pz[j];
+                            // A unit is "special" when some lane must be masked off: the tail chunk of the
+                            // plane, the chunk holding the excluded molecule, or any chunk of an ordered sweep.
+                            // Ordinary units skip the masks entirely.
+                            const double *pxp = px + seg2 + a2 * cap2, *pyp = py + seg2 + a2 * cap2, *pzp = pz + seg2 + a2 * cap2;
+                            auto is_special = [&](int cc) {
+                                return ORDERED || (cc == cpp - 1 && (nm & 63) != 0) || (same_t && cc == (it.m >> 6));
+                            };
+                            auto fetch = [&](int cc, bool special, double &x, double &y, double &z, bool &ok) {
+                                int m2 = cc * 64 + lane;
+                                ok = true;
+                                if (special) {
+                                    ok = m2 < nm;
+                                    if (same_t) ok = ok && (ORDERED ? (m2 > it.m) : (m2 != it.m));
+                                    m2 = ok ? m2 : dummy_m;
+                                }
+                                x = pxp[m2]; y = pyp[m2]; z = pzp[m2];
                             };
                             double acc[NREG];
 #pragma unroll
@@ -302,15 +318,10 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                             // ALL_C: every site is charged -> the NS Coulomb chains form one basic block
                             auto sweep_plane = [&](auto all_tag) {
                                 constexpr bool ALL_C = decltype(all_tag)::value;
-                                double xj, yj, zj;
-                                bool valid;
-                                fetch(c, xj, yj, zj, valid);
-                                for (; c < cpp; c += nsplit) {
-                                    double xn = xj, yn = yj, zn = zj;
-                                    bool vn = false;
-                                    if (c + nsplit < cpp) fetch(c + nsplit, xn, yn, zn, vn);
-                                    const double wgt = valid ? 1.0 : 0.0;
-                                    const double rc2l = valid ? bx.rc2 : -1.0;
+                                auto unit = [&](auto masked_tag, double xj, double yj, double zj, bool valid) {
+                                    constexpr bool MASKED = decltype(masked_tag)::value;
+                                    const double wgt = (MASKED && !valid) ? 0.0 : 1.0;
+                                    const double rc2l = (MASKED && !valid) ? -1.0 : bx.rc2;
                                     double r2[NREG], g[NREG];
                                     bool any_below = false;
 #pragma unroll
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                                             if ((ALL_C || c_on[s]) && r2[s] < 0.25) g[s] = coul_slow(r2[s], bx.alpha, ORDERED);
                                     }
 #pragma unroll
-                                    for (int s = 0; s < NREG; ++s) acc[s] = fma(wgt, g[s], acc[s]);
+                                    for (int s = 0; s < NREG; ++s) acc[s] = MASKED ? fma(wgt, g[s], acc[s]) : acc[s] + g[s];
                                     if (any_lj) {
 #pragma unroll
                                         for (int s = 0; s < NREG; ++s) {
@@ -344,7 +355,19 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                                             elj += (r2[s] < rc2l) ? e : 0.0;            // energy_utils.f90:417
                                         }
                                     }
-                                    xj = xn; yj = yn; zj = zn; valid = vn;
+                                };
+                                double xj, yj, zj;
+                                bool valid, special = is_special(c);
+                                fetch(c, special, xj, yj, zj, valid);
+                                for (; c < cpp; c += nsplit) {
+                                    double xn = xj, yn = yj, zn = zj;
+                                    bool vn = true;
+                                    const bool special_n = is_special(c + nsplit);
+                                    if (c + nsplit < cpp) fetch(c + nsplit, special_n, xn, yn, zn, vn);
+                                    // (a mask-free copy of the unit for ordinary chunks was measured slower:
+                                    //  the duplicated body costs more registers than the masks cost cycles)
+                                    unit(std::true_type{}, xj, yj, zj, valid);
+                                    xj = xn; yj = yn; zj = zn; valid = vn; special = special_n;
                                 }
                             };
                             if (all_c) sweep_plane(std::true_type{});
