@@ -222,6 +222,16 @@ int mgpu_commit_submit(mgpu_engine *e, int lane, int n_candidates, const int *re
                        const int *m, const int *kind, const double *sites, int site_stride,
                        const int *accept);
 
+/* Mixed batches for grand-canonical chains: kind[c] in {MGPU_MOVE, MGPU_CREATION, MGPU_DELETION}.
+ * old_/new_ arrays are [n_candidates][5] = non_coulomb, coulomb, recip_coulomb, ewald_self,
+ * intra_coulomb, filled exactly as ComputeOldEnergy / ComputeNewEnergy fill their energy_state
+ * (monte_carlo_utils.f90:292-318, :364-393), except that a deletion's new recip_coulomb is the
+ * intended sum ff W |A - S_mol|^2.  m[c] is ignored for creations (the new molecule is
+ * appended by the commit).  Commit with mgpu_commit_submit (sites = NULL reuses the rows). */
+int mgpu_gcmc_trial_submit(mgpu_engine *e, int lane, int n_candidates, const int *replica, const int *t,
+                           const int *m, const int *kind, const double *sites, int site_stride);
+int mgpu_gcmc_trial_wait(mgpu_engine *e, int lane, double *old_energy, double *new_energy);
+
 /* ReplaceFourierTermsSingleMol + the coordinate copy of RemoveMolecule (ewald_phase.f90:276-322,
  * delete_molecule.f90:99-116): slot m_dst <- slot m_src. */
 int mgpu_replica_replace_molecule(mgpu_engine *e, int replica, int t, int m_dst, int m_src);

@@ -77,6 +77,9 @@ struct Lane {
     std::vector<Pending> pending;
     int n_submitted = 0;          // candidates of the trial in flight (0 = none)
     int last_trial_n = 0, last_trial_stride = 0;   // shape of the site rows still resident in d_sites
+    int n_pair_items = 0;
+    std::vector<int> pair_old, pair_new, intra_idx, kinds;   // per-candidate rows of the trial in flight
+    std::vector<double> self_of;                              // per-candidate Ewald self term (host constant)
     void release() {
         d_items.release(); d_items2.release(); d_sites.release(); d_partials.release(); d_out.release();
         h_in.release(); h_commit.release(); h_out.release();
@@ -824,65 +827,107 @@ int mgpu_intra_energy_candidates(mgpu_engine *e, int n, const int *replica, cons
     return MGPU_OK;
 }
 
-// Queue one translation / rotation trial per candidate on a lane: inputs are staged through pinned
-// host memory, so the call returns as soon as the copies and the four kernels are enqueued.
+// Queue one trial per candidate on a lane: inputs are staged through pinned host memory, so the call
+// returns as soon as the copies and the kernels are enqueued.  kind == nullptr: all MGPU_MOVE.
+// Per candidate (ComputeOldEnergy / ComputeNewEnergy, monte_carlo_utils.f90:275-395):
+//   MOVE      pair(resident) | pair(sites)          recip(A) | recip(A + new - old)
+//   CREATION  --             | pair(sites), intra   recip(A) | recip(A + new)         (m ignored)
+//   DELETION  pair(resident), intra | --            recip(A) | recip(A - old)
+// One pass over k per candidate yields both reciprocal energies.  Device output rows (doubles):
+//   lj[n_pair] c[n_pair] u_old[n] u_new[n] intra[n]; the lane remembers where each candidate's
+//   pair items are.
 static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica, const int *t, const int *m,
-                             const double *sites, int site_stride) {
+                             const int *kind, const double *sites, int site_stride) {
     if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "trial_submit: the lane still holds an un-waited trial");
     int rc;
-    const size_t n2 = 2 * (size_t)n;
     const size_t site_bytes = (size_t)n * site_stride * 3 * sizeof(double);
-    const size_t pit_bytes = n2 * sizeof(PairItem), rit_bytes = (size_t)n * sizeof(RecipItem);
-    if ((rc = ln.h_in.reserve(site_bytes + pit_bytes + rit_bytes))) return rc;
+    const size_t pit_cap = 2 * (size_t)n * sizeof(PairItem), rit_bytes = (size_t)n * sizeof(RecipItem);
+    const size_t iit_cap = (size_t)n * sizeof(PairItem);
+    if ((rc = ln.h_in.reserve(site_bytes + pit_cap + rit_bytes + iit_cap))) return rc;
     double *h_sites = (double *)ln.h_in.p;
     PairItem *pit = (PairItem *)((char *)ln.h_in.p + site_bytes);
-    RecipItem *rit = (RecipItem *)((char *)ln.h_in.p + site_bytes + pit_bytes);
-    // items [0, n): old state (resident sites, A unchanged); items [n, 2n): new state
-    int n1_max = 1, common = -1;
+    RecipItem *rit = (RecipItem *)((char *)ln.h_in.p + site_bytes + pit_cap);
+    PairItem *iit = (PairItem *)((char *)ln.h_in.p + site_bytes + pit_cap + rit_bytes);
+    ln.pair_old.assign(n, -1);
+    ln.pair_new.assign(n, -1);
+    ln.intra_idx.assign(n, -1);
+    ln.kinds.assign(n, MGPU_MOVE);
+    ln.self_of.assign(n, 0.0);
+    int n1_max = 1, common = -1, n_pair = 0, n_intra = 0;
     for (int c = 0; c < n; ++c) {
-        if ((rc = check_candidate(e, c, replica[c], t[c], m[c], true))) return rc;
+        const int k = kind ? kind[c] : MGPU_MOVE;
+        if (k < MGPU_MOVE || k > MGPU_DELETION) return set_error(MGPU_ERR_INVALID_ARG, "trial_submit: unknown candidate kind");
+        const int mc = (k == MGPU_CREATION) ? -1 : m[c];
+        if ((rc = check_candidate(e, c, replica[c], t[c], mc, k != MGPU_CREATION))) return rc;
         const int n1 = e->tp.n1[t[c]];
         if (n1 > site_stride) return set_error(MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res");
         n1_max = std::max(n1_max, n1);
         common = (common == -1 || common == n1) ? n1 : 0;
-        pit[c] = PairItem{replica[c], t[c], m[c], -1, 0};
-        pit[n + c] = PairItem{replica[c], t[c], m[c], c, 0};
-        rit[c] = RecipItem{replica[c], t[c], m[c], MGPU_MOVE, c, 0};   // one k sweep yields old and new
+        ln.kinds[c] = k;
+        if (k != MGPU_MOVE) ln.self_of[c] = self_energy_host(e, t[c]);
+        if (k != MGPU_CREATION) { ln.pair_old[c] = n_pair; pit[n_pair++] = PairItem{replica[c], t[c], mc, -1, 0}; }
+        if (k != MGPU_DELETION) { ln.pair_new[c] = n_pair; pit[n_pair++] = PairItem{replica[c], t[c], mc, c, 0}; }
+        rit[c] = RecipItem{replica[c], t[c], mc, k, k == MGPU_DELETION ? -1 : c, 0};   // one k sweep: old and new
+        if (k == MGPU_CREATION) { ln.intra_idx[c] = n_intra; iit[n_intra++] = PairItem{replica[c], t[c], -1, c, 0}; }
+        if (k == MGPU_DELETION) { ln.intra_idx[c] = n_intra; iit[n_intra++] = PairItem{replica[c], t[c], mc, -1, 0}; }
     }
     std::memcpy(h_sites, sites, site_bytes);
-    if ((rc = ln.d_items.reserve(pit_bytes))) return rc;
+    const size_t pit_bytes = (size_t)n_pair * sizeof(PairItem), iit_bytes = (size_t)n_intra * sizeof(PairItem);
+    const size_t out_doubles = 2 * (size_t)n_pair + 3 * (size_t)n;
+    if ((rc = ln.d_items.reserve(pit_bytes + iit_bytes + 16))) return rc;
     if ((rc = ln.d_items2.reserve(rit_bytes))) return rc;
     if ((rc = ln.d_sites.reserve(site_bytes))) return rc;
-    if ((rc = ln.d_out.reserve(3 * n2 * sizeof(double)))) return rc;
-    if ((rc = ln.h_out.reserve(3 * n2 * sizeof(double)))) return rc;
+    if ((rc = ln.d_out.reserve(out_doubles * sizeof(double)))) return rc;
+    if ((rc = ln.h_out.reserve(out_doubles * sizeof(double)))) return rc;
     HIP_TRY(hipMemcpyAsync(ln.d_sites.p, h_sites, site_bytes, hipMemcpyHostToDevice, ln.stream));
     HIP_TRY(hipMemcpyAsync(ln.d_items.p, pit, pit_bytes, hipMemcpyHostToDevice, ln.stream));
     HIP_TRY(hipMemcpyAsync(ln.d_items2.p, rit, rit_bytes, hipMemcpyHostToDevice, ln.stream));
-    double *d_lj = (double *)ln.d_out.p, *d_c = d_lj + n2, *d_u = d_c + n2;
-    const int nsplit = choose_nsplit(e, (int)n2, replica[0]);
-    if ((rc = launch_pair(e, ln, (const PairItem *)ln.d_items.p, (int)n2, std::max(common, 0), site_stride, nsplit, d_lj, d_c)))
+    PairItem *d_iit = (PairItem *)((char *)ln.d_items.p + pit_bytes);
+    if (n_intra) HIP_TRY(hipMemcpyAsync(d_iit, iit, iit_bytes, hipMemcpyHostToDevice, ln.stream));
+    double *d_lj = (double *)ln.d_out.p, *d_c = d_lj + n_pair, *d_uo = d_c + n_pair, *d_un = d_uo + n, *d_in = d_un + n;
+    if (n_pair) {
+        const int nsplit = choose_nsplit(e, n_pair, replica[0]);
+        if ((rc = launch_pair(e, ln, (const PairItem *)ln.d_items.p, n_pair, std::max(common, 0), site_stride, nsplit, d_lj, d_c)))
+            return rc;
+    }
+    if ((rc = launch_recip(e, ln, (const RecipItem *)ln.d_items2.p, n, n1_max, site_stride, false, e->d_A, d_un, d_uo)))
         return rc;
-    // d_u layout matches the pair outputs: [0, n) old state, [n, 2n) new state
-    if ((rc = launch_recip(e, ln, (const RecipItem *)ln.d_items2.p, n, n1_max, site_stride, false, e->d_A, d_u + n, d_u)))
-        return rc;
-    HIP_TRY(hipMemcpyAsync(ln.h_out.p, ln.d_out.p, 3 * n2 * sizeof(double), hipMemcpyDeviceToHost, ln.stream));
+    if (n_intra) {
+        hipLaunchKernelGGL(intra_kernel, dim3((n_intra + 63) / 64), dim3(64), 0, ln.stream, e->tp, e->bx, e->d_pos, e->d_res_q,
+                           (const PairItem *)d_iit, n_intra, (const double *)ln.d_sites.p, site_stride, d_in);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(ln.h_out.p, ln.d_out.p, out_doubles * sizeof(double), hipMemcpyDeviceToHost, ln.stream));
     ln.n_submitted = n;
+    ln.n_pair_items = n_pair;
     ln.last_trial_n = n;
     ln.last_trial_stride = site_stride;
     return MGPU_OK;
 }
 
-static int trial_wait_impl(mgpu_engine *e, Lane &ln, double *old_energy, double *new_energy) {
+// ncomp = 3: non_coulomb, coulomb, recip_coulomb; ncomp = 5: + ewald_self, intra_coulomb
+static int trial_wait_impl(mgpu_engine *e, Lane &ln, double *old_energy, double *new_energy, int ncomp) {
     const int n = ln.n_submitted;
     if (n == 0) return set_error(MGPU_ERR_STATE, "trial_wait: nothing was submitted on this lane");
     ln.n_submitted = 0;
     int rc = sync_lane(e, ln);
     if (rc) return rc;
-    const size_t n2 = 2 * (size_t)n;
+    const int np = ln.n_pair_items;
     const double *h = (const double *)ln.h_out.p;
+    const double *lj = h, *cc = h + np, *uo = cc + np, *un = uo + n, *in = un + n;
     for (int c = 0; c < n; ++c) {
-        old_energy[3 * c + 0] = h[c];          old_energy[3 * c + 1] = h[n2 + c];     old_energy[3 * c + 2] = h[2 * n2 + c];
-        new_energy[3 * c + 0] = h[n + c];      new_energy[3 * c + 1] = h[n2 + n + c]; new_energy[3 * c + 2] = h[2 * n2 + n + c];
+        double *o = old_energy + (size_t)ncomp * c, *w = new_energy + (size_t)ncomp * c;
+        for (int k = 0; k < ncomp; ++k) { o[k] = 0.0; w[k] = 0.0; }
+        if (ln.pair_old[c] >= 0) { o[0] = lj[ln.pair_old[c]]; o[1] = cc[ln.pair_old[c]]; }
+        if (ln.pair_new[c] >= 0) { w[0] = lj[ln.pair_new[c]]; w[1] = cc[ln.pair_new[c]]; }
+        o[2] = uo[c];
+        w[2] = un[c];
+        if (ncomp == 5) {
+            // ewald_self / intra_coulomb enter on the side where the molecule exists
+            // (monte_carlo_utils.f90:298-299 creation new, :378-379 deletion old)
+            if (ln.kinds[c] == MGPU_CREATION) { w[3] = ln.self_of[c]; w[4] = in[ln.intra_idx[c]]; }
+            if (ln.kinds[c] == MGPU_DELETION) { o[3] = ln.self_of[c]; o[4] = in[ln.intra_idx[c]]; }
+        }
     }
     return MGPU_OK;
 }
@@ -958,7 +1003,24 @@ int mgpu_trial_submit(mgpu_engine *e, int lane, int n, const int *replica, const
     if (rc) return rc;
     if (n <= 0 || !replica || !t || !m || !sites) return set_error(MGPU_ERR_INVALID_ARG, "trial_submit: bad argument");
     if ((rc = use_device(e))) return rc;
-    return trial_submit_impl(e, e->lanes[lane], n, replica, t, m, sites, site_stride);
+    return trial_submit_impl(e, e->lanes[lane], n, replica, t, m, nullptr, sites, site_stride);
+}
+
+int mgpu_gcmc_trial_submit(mgpu_engine *e, int lane, int n, const int *replica, const int *t, const int *m,
+                           const int *kind, const double *sites, int site_stride) {
+    int rc = check_lane(e, lane);
+    if (rc) return rc;
+    if (n <= 0 || !replica || !t || !m || !kind || !sites) return set_error(MGPU_ERR_INVALID_ARG, "gcmc_trial_submit: bad argument");
+    if ((rc = use_device(e))) return rc;
+    return trial_submit_impl(e, e->lanes[lane], n, replica, t, m, kind, sites, site_stride);
+}
+
+int mgpu_gcmc_trial_wait(mgpu_engine *e, int lane, double *old_energy, double *new_energy) {
+    int rc = check_lane(e, lane);
+    if (rc) return rc;
+    if (!old_energy || !new_energy) return set_error(MGPU_ERR_INVALID_ARG, "gcmc_trial_wait: null output");
+    if ((rc = use_device(e))) return rc;
+    return trial_wait_impl(e, e->lanes[lane], old_energy, new_energy, 5);
 }
 
 int mgpu_trial_wait(mgpu_engine *e, int lane, double *old_energy, double *new_energy) {
@@ -966,7 +1028,7 @@ int mgpu_trial_wait(mgpu_engine *e, int lane, double *old_energy, double *new_en
     if (rc) return rc;
     if (!old_energy || !new_energy) return set_error(MGPU_ERR_INVALID_ARG, "trial_wait: null output");
     if ((rc = use_device(e))) return rc;
-    return trial_wait_impl(e, e->lanes[lane], old_energy, new_energy);
+    return trial_wait_impl(e, e->lanes[lane], old_energy, new_energy, 3);
 }
 
 int mgpu_commit_submit(mgpu_engine *e, int lane, int n, const int *replica, const int *t, const int *m, const int *kind,
@@ -989,8 +1051,8 @@ int mgpu_trial_energy_candidates(mgpu_engine *e, int n, const int *replica, cons
         return set_error(MGPU_ERR_INVALID_ARG, "trial_energy_candidates: bad argument");
     int rc = use_device(e);
     if (rc) return rc;
-    if ((rc = trial_submit_impl(e, e->lanes[0], n, replica, t, m, sites, site_stride))) return rc;
-    return trial_wait_impl(e, e->lanes[0], old_energy, new_energy);
+    if ((rc = trial_submit_impl(e, e->lanes[0], n, replica, t, m, nullptr, sites, site_stride))) return rc;
+    return trial_wait_impl(e, e->lanes[0], old_energy, new_energy, 3);
 }
 
 int mgpu_commit_candidates(mgpu_engine *e, int n, const int *replica, const int *t, const int *m, const int *kind,

@@ -239,6 +239,27 @@ class Engine:
                                                   C.c_int(sites.shape[1]), _d(old), _d(new)))
         return old, new
 
+    def gcmc_trial(self, replica, t, m, kind, sites, lane=0):
+        """Mixed batch (moves, creations, deletions): (old[n,5], new[n,5]) as ComputeOld/NewEnergy fill them."""
+        n, replica, t, m, sites = self._cand(replica, t, m, sites)
+        kind = _ints(kind, n)
+        old = np.zeros((n, 5)); new = np.zeros((n, 5))
+        self._last_stride = sites.shape[1]
+        check(self.L.mgpu_gcmc_trial_submit(self.h, C.c_int(lane), C.c_int(n), _i(replica), _i(t), _i(m), _i(kind),
+                                            _d(sites), C.c_int(sites.shape[1])))
+        check(self.L.mgpu_gcmc_trial_wait(self.h, C.c_int(lane), _d(old), _d(new)))
+        return old, new
+
+    def commit_lane(self, lane, replica, t, m, kind, accept, sites=None):
+        """mgpu_commit_submit + synchronize; sites=None reuses the rows of the lane's last trial."""
+        n, replica, t, m, sites = self._cand(replica, t, m, sites)
+        kind = _ints(kind, n)
+        accept = _ints(accept, n)
+        stride = self._last_stride if sites is None else sites.shape[1]
+        check(self.L.mgpu_commit_submit(self.h, C.c_int(lane), C.c_int(n), _i(replica), _i(t), _i(m), _i(kind),
+                                        _d(sites), C.c_int(stride), _i(accept)))
+        self.synchronize()
+
     def commit_candidates(self, replica, t, m, kind, sites, accept):
         n, replica, t, m, sites = self._cand(replica, t, m, sites)
         kind = _ints(kind, n)
