@@ -175,6 +175,23 @@ module maniac_gpu
             integer(c_int), intent(in) :: replica(*), t(*), m(*), kind(*), accept(*)
             integer(c_int) :: rc
         end function
+        ! mixed batches (moves, insertions, deletions); energies come back as rows of 5
+        function mgpu_gcmc_trial_submit(e, lane, n, replica, t, m, kind, sites, site_stride) &
+                bind(C, name="mgpu_gcmc_trial_submit") result(rc)
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: e
+            integer(c_int), value :: lane, n, site_stride
+            integer(c_int), intent(in) :: replica(*), t(*), m(*), kind(*)
+            real(c_double), intent(in) :: sites(*)
+            integer(c_int) :: rc
+        end function
+        function mgpu_gcmc_trial_wait(e, lane, old_energy, new_energy) bind(C, name="mgpu_gcmc_trial_wait") result(rc)
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: e
+            integer(c_int), value :: lane
+            real(c_double), intent(out) :: old_energy(*), new_energy(*)
+            integer(c_int) :: rc
+        end function
         function mgpu_synchronize(e) bind(C, name="mgpu_synchronize") result(rc)
             import :: c_ptr, c_int
             type(c_ptr), value :: e

@@ -8,28 +8,31 @@
 !   Translation          src/translation.f90:36-112   (rand_symmetric(3)*step, ApplyPBC)
 !   Rotation             src/rotation.f90:34-75, src/monte_carlo_utils.f90:30-92
 !                        (theta = (u - 1/2)*rotation_step_angle about a random Cartesian axis)
-!   acceptance           src/monte_carlo_utils.f90:184-226   min(1, exp(-dE/T)), energies in K
-!   AcceptMove           src/monte_carlo_utils.f90:410-422
+!   CreateMolecule       src/create_molecule.f90:41-207 (uniform position, geometry of molecule 1,
+!                        full random rotation; slot num_residues + 1)
+!   DeleteMolecule       src/delete_molecule.f90:41-116 (swap-with-last)
+!   acceptance           src/monte_carlo_utils.f90:184-226   energies in K, fugacity in molecules/A^3
+!   AcceptMove & co.     src/monte_carlo_utils.f90:410-422, create_molecule.f90:96-131,
+!                        delete_molecule.f90:126-168
 !   step recalibration   src/monte_carlo_utils.f90:99-130    (AdjustMoveStepSizes, as written)
+! Deliberate differences from the reference (SURVEY F2 / F3): A(k) is initialised to S(k) before
+! the first move, and a deletion's new reciprocal energy is sum ff W |A - S_mol|^2.
+!
 ! Random numbers: rng_kind 0 draws from the intrinsic random_number exactly like the reference
 ! (src/random_utils.f90:13-56); rng_kind 1 (default of the bench) uses an inlined xoshiro256+
 ! generator seeded by the same rule, because flang's random_number costs ~17 ns per number and the
-! farm consumes nine numbers per trial (measured: 40 % of the host time of a step).
+! farm consumes ten numbers per trial (measured: 40 % of the host time of a step).
 !
-! One chain is sequential, so the farm advances R chains in lock step: each step
-! generates one trial move per chain, evaluates all of them in one batched call
-! (old and new state of every candidate), applies the Metropolis test per chain and
-! commits the accepted ones.  The chains are split into two groups that alternate on
-! the engine's two submission lanes, so the host prepares / resolves one group while
-! the GPU evaluates the other.
+! One chain is sequential, so the farm advances R chains in lock step: each step generates one
+! trial move per chain, evaluates all of them in one batched call (old and new state of every
+! candidate), applies the Metropolis test per chain and commits the accepted ones.  The chains are
+! split into two groups that alternate on the engine's two submission lanes, so the host prepares /
+! resolves one group while the GPU evaluates the other.
 !
 ! The per-chain loops (gathering a molecule from the host mirror, building the move, the
 ! Metropolis test) are independent across chains and run under OpenMP: with ~1000 chains the
 ! random gathers from the ~300 MB mirror are DRAM/TLB-latency bound (measured 0.34 us per chain
 ! single-threaded), and a few host threads overlap them.
-!
-! Only translation / rotation (NVT) are driven here; insertion / deletion go through
-! the same engine calls (mgpu_*_candidates with MGPU_CREATION / MGPU_DELETION).
 !===============================================================================
 module mc_farm
 
@@ -42,7 +45,7 @@ module mc_farm
 
     private
     public :: mfarm_create, mfarm_run, mfarm_destroy, mfarm_get_energy, mfarm_get_molecule, mfarm_recalibrate
-    public :: mfarm_get_timers
+    public :: mfarm_get_timers, mfarm_set_gcmc, mfarm_get_counts, mfarm_get_counters
 
     real(real64), parameter :: PI = 3.14159265358979323846_real64
     real(real64), parameter :: TWOPI = 2.0_real64 * PI
@@ -50,29 +53,38 @@ module mc_farm
     real(real64), parameter :: TARGET_ACCEPTANCE = 0.40d0, TOL_ACCEPTANCE = 0.05d0
     real(real64), parameter :: MIN_TRANSLATION_STEP = 1.0d-3, MAX_TRANSLATION_STEP = 3.0d0
     real(real64), parameter :: MIN_ROTATION_ANGLE = 1.0d-3, MAX_ROTATION_ANGLE = 0.78d0
+    real(real64), parameter :: PROB_CREATE_DELETE = 0.5d0
     integer, parameter :: MIN_TRIALS_FOR_RECALIBRATION = 500
-    integer, parameter :: NRAND = 9                       ! uniform numbers consumed per trial
+    integer, parameter :: NRAND = 10                      ! uniform numbers consumed per trial
+    ! internal move codes; engine kinds are MGPU_MOVE / MGPU_CREATION / MGPU_DELETION
+    integer, parameter :: MV_TRANSLATION = 1, MV_ROTATION = 2, MV_CREATION = 3, MV_DELETION = 4
 
     type :: lane_buffers
         integer :: first = 0, n = 0                        ! replicas [first, first + n)
+        integer :: nc = 0                                  ! candidates of the trial in flight (<= n)
         integer(c_int), allocatable :: rep(:), t(:), m(:), kind(:), accept(:)
-        integer, allocatable :: ia(:)                      ! index into the active-type tables
-        logical, allocatable :: is_trans(:)
+        integer, allocatable :: ia(:), move(:), cidx(:)    ! active-type index, move code, chain index
         real(real64), allocatable :: sites(:, :, :)        ! (3, max_n1, n)
         real(real64), allocatable :: new_com(:, :), new_off(:, :, :)
-        real(real64), allocatable :: old_e(:, :), new_e(:, :), u(:, :)
+        real(real64), allocatable :: old_e(:), new_e(:)    ! (ne * nc) rows packed by the engine
+        real(real64), allocatable :: u(:, :)
     end type lane_buffers
 
     type :: farm_state
         type(c_ptr) :: engine = c_null_ptr
         integer :: n_replicas = 0, n_active = 0, max_n1 = 0, cap_total = 0
-        integer, allocatable :: res_type(:), n1(:), n_mol(:), first(:)   ! per active type
+        integer, allocatable :: res_type(:), n1(:), cap(:), first(:)     ! per active type
+        integer, allocatable :: cnt(:, :)                  ! (n_active, R)  primary%num_residues
         real(real64), allocatable :: com(:, :, :)          ! (3, cap_total, R)    primary%mol_com
         real(real64), allocatable :: off(:, :, :, :)       ! (3, max_n1, cap_total, R) primary%site_offset
-        real(real64), allocatable :: energy(:, :)          ! (3, R) non_coulomb, coulomb, recip_coulomb
-        real(real64) :: lo(3), len(3), temperature, translation_step, rotation_step, p_translation
+        real(real64), allocatable :: energy(:, :)          ! (5, R) non_coulomb, coulomb, recip, self, intra
+        real(real64), allocatable :: fugacity(:, :)        ! (n_active, R) molecules per cubic Angstrom
+        real(real64) :: lo(3), len(3), volume, temperature, translation_step, rotation_step
+        real(real64) :: p_translation, p_rotation          ! the rest is insertion / deletion
+        logical :: gcmc = .false.
         integer(int64) :: trials = 0, accepted = 0
-        integer(int64) :: trial_translations = 0, translations = 0, trial_rotations = 0, rotations = 0
+        integer(int64) :: counters(8) = 0   ! trial/accepted: translations, rotations, creations, deletions
+        integer(int64) :: skipped = 0                      ! no-op selections (empty type, full type)
         type(lane_buffers) :: lane(0:MGPU_LANES - 1)
         logical :: ready = .false.
         integer(int64) :: ticks(7) = 0                     ! generate, submit, wait, resolve, commit, rng, gather
@@ -129,51 +141,71 @@ contains
     !---------------------------------------------------------------------------
     ! Create the farm.  Every replica of `engine` must already hold the same configuration
     ! (mgpu_replica_copy) with A(k) initialised.  Active residue types are listed in
-    ! res_type(1:n_active) (0-based engine ids); com / off hold their molecules back to back:
-    !   com(3, cap_total), off(3, max_n1, cap_total), type ia occupying slots
-    !   first(ia)+1 .. first(ia)+n_mol(ia).
-    ! energy0 = non_coulomb, coulomb, recip_coulomb of that configuration.
+    ! res_type(1:n_active) (0-based engine ids) with n_mol molecules each and room for cap (the
+    ! engine's mol_capacity); com / off hold the initial molecules of the types back to back:
+    !   com(3, sum n_mol), off(3, max_n1, sum n_mol).
+    ! energy0 = non_coulomb, coulomb, recip_coulomb, ewald_self, intra_coulomb of that configuration.
     !---------------------------------------------------------------------------
-    function mfarm_create(engine, n_replicas, n_active, res_type, n1, n_mol, max_n1, com, off, energy0, &
+    function mfarm_create(engine, n_replicas, n_active, res_type, n1, n_mol, cap, max_n1, com, off, energy0, &
                           bounds_lo, box_len, temperature, translation_step, rotation_step, p_translation, seed, &
                           rng_kind, n_threads) bind(C, name="mfarm_create") result(rc)
         type(c_ptr), value :: engine
         integer(c_int), value :: n_replicas, n_active, max_n1, seed, rng_kind, n_threads
-        integer(c_int), intent(in) :: res_type(n_active), n1(n_active), n_mol(n_active)
-        real(c_double), intent(in) :: com(3, *), off(3, max_n1, *), energy0(3), bounds_lo(3), box_len(3)
+        integer(c_int), intent(in) :: res_type(n_active), n1(n_active), n_mol(n_active), cap(n_active)
+        real(c_double), intent(in) :: com(3, *), off(3, max_n1, *), energy0(5), bounds_lo(3), box_len(3)
         real(c_double), value :: temperature, translation_step, rotation_step, p_translation
         integer(c_int) :: rc
-        integer :: ia, r, g, per, cap
+        integer :: ia, r, g, per, tot, src
 
         call mfarm_destroy()
+        rc = MGPU_OK
+        do ia = 1, n_active
+            if (n_mol(ia) > cap(ia) .or. cap(ia) < 1) then
+                rc = 3
+                return
+            end if
+        end do
         F%engine = engine
         F%n_replicas = n_replicas
         F%n_active = n_active
         F%max_n1 = max_n1
-        allocate(F%res_type(n_active), F%n1(n_active), F%n_mol(n_active), F%first(n_active))
+        allocate(F%res_type(n_active), F%n1(n_active), F%cap(n_active), F%first(n_active))
+        allocate(F%cnt(n_active, n_replicas), F%fugacity(n_active, n_replicas))
         F%res_type = res_type
         F%n1 = n1
-        F%n_mol = n_mol
-        cap = 0
+        F%cap = cap
+        tot = 0
         do ia = 1, n_active
-            F%first(ia) = cap
-            cap = cap + n_mol(ia)
+            F%first(ia) = tot
+            tot = tot + cap(ia)
         end do
-        F%cap_total = cap
-        allocate(F%com(3, cap, n_replicas), F%off(3, max_n1, cap, n_replicas), F%energy(3, n_replicas))
+        F%cap_total = tot
+        allocate(F%com(3, tot, n_replicas), F%off(3, max_n1, tot, n_replicas), F%energy(5, n_replicas))
+        F%com = 0.0_real64
+        F%off = 0.0_real64
+        src = 0
+        do ia = 1, n_active
+            do r = 1, n_replicas
+                F%com(:, F%first(ia) + 1:F%first(ia) + n_mol(ia), r) = com(:, src + 1:src + n_mol(ia))
+                F%off(:, :, F%first(ia) + 1:F%first(ia) + n_mol(ia), r) = off(:, :, src + 1:src + n_mol(ia))
+                F%cnt(ia, r) = n_mol(ia)
+            end do
+            src = src + n_mol(ia)
+        end do
         do r = 1, n_replicas
-            F%com(:, :, r) = com(:, 1:cap)
-            F%off(:, :, :, r) = off(:, :, 1:cap)
             F%energy(:, r) = energy0
         end do
+        F%fugacity = 0.0_real64
         F%lo = bounds_lo
         F%len = box_len
+        F%volume = box_len(1) * box_len(2) * box_len(3)
         F%temperature = temperature
         F%translation_step = translation_step
         F%rotation_step = rotation_step
         F%p_translation = p_translation
-        F%trials = 0; F%accepted = 0
-        F%trial_translations = 0; F%translations = 0; F%trial_rotations = 0; F%rotations = 0
+        F%p_rotation = 1.0_real64 - p_translation
+        F%gcmc = .false.
+        F%trials = 0; F%accepted = 0; F%counters = 0; F%skipped = 0; F%ticks = 0
         F%rng_kind = rng_kind
         F%n_threads = max(1, int(n_threads))
         call seed_farm_rng(int(seed))
@@ -182,205 +214,335 @@ contains
         do g = 0, MGPU_LANES - 1
             F%lane(g)%first = min(g * per, n_replicas)
             F%lane(g)%n = max(0, min(per, n_replicas - g * per))
+            F%lane(g)%nc = 0
             call alloc_lane(F%lane(g), max(1, F%lane(g)%n), max_n1)
         end do
         F%ready = .true.
-        rc = MGPU_OK
     end function mfarm_create
+
+    !---------------------------------------------------------------------------
+    ! Switch insertion / deletion on: move probabilities as in the .maniac input
+    ! (translation_proba, rotation_proba; the remainder is insertion/deletion, split 50/50,
+    ! monte_carlo.f90:53-75) and one fugacity per (active type, replica), already converted to
+    ! molecules per cubic Angstrom (ConvertFugacity, prepare_utils.f90:48-73).
+    !---------------------------------------------------------------------------
+    function mfarm_set_gcmc(p_translation, p_rotation, fugacity) bind(C, name="mfarm_set_gcmc") result(rc)
+        real(c_double), value :: p_translation, p_rotation
+        real(c_double), intent(in) :: fugacity(F%n_active, F%n_replicas)
+        integer(c_int) :: rc
+        rc = MGPU_OK
+        if (.not. F%ready) then
+            rc = 5
+            return
+        end if
+        if (p_translation < 0.0_real64 .or. p_rotation < 0.0_real64 .or. &
+            p_translation + p_rotation > 1.0_real64 + 1.0d-12 .or. any(fugacity <= 0.0_real64)) then
+            rc = 1
+            return
+        end if
+        F%p_translation = p_translation
+        F%p_rotation = p_rotation
+        F%fugacity = fugacity
+        F%gcmc = .true.
+    end function mfarm_set_gcmc
 
     subroutine alloc_lane(L, n, max_n1)
         type(lane_buffers), intent(inout) :: L
         integer, intent(in) :: n, max_n1
-        allocate(L%rep(n), L%t(n), L%m(n), L%kind(n), L%accept(n), L%ia(n), L%is_trans(n))
+        allocate(L%rep(n), L%t(n), L%m(n), L%kind(n), L%accept(n), L%ia(n), L%move(n), L%cidx(n))
         allocate(L%sites(3, max_n1, n), L%new_com(3, n), L%new_off(3, max_n1, n))
-        allocate(L%old_e(3, n), L%new_e(3, n), L%u(NRAND, n))
+        allocate(L%old_e(5 * n), L%new_e(5 * n), L%u(NRAND, n))
         L%sites = 0.0_real64
         L%kind = MGPU_MOVE
     end subroutine alloc_lane
 
     subroutine mfarm_destroy() bind(C, name="mfarm_destroy")
         integer :: g
-        if (allocated(F%res_type)) deallocate(F%res_type, F%n1, F%n_mol, F%first)
+        if (allocated(F%res_type)) deallocate(F%res_type, F%n1, F%cap, F%first, F%cnt, F%fugacity)
         if (allocated(F%com)) deallocate(F%com, F%off, F%energy)
         do g = 0, MGPU_LANES - 1
             if (allocated(F%lane(g)%rep)) then
                 deallocate(F%lane(g)%rep, F%lane(g)%t, F%lane(g)%m, F%lane(g)%kind, F%lane(g)%accept, &
-                           F%lane(g)%ia, F%lane(g)%is_trans, F%lane(g)%sites, F%lane(g)%new_com, &
+                           F%lane(g)%ia, F%lane(g)%move, F%lane(g)%cidx, F%lane(g)%sites, F%lane(g)%new_com, &
                            F%lane(g)%new_off, F%lane(g)%old_e, F%lane(g)%new_e, F%lane(g)%u)
             end if
         end do
         F%ready = .false.
     end subroutine mfarm_destroy
 
-    ! RotationMatrix (src/helper_utils.f90:39-77)
-    pure function RotationMatrix(axis, theta) result(r)
-        integer, intent(in) :: axis
+    ! rotation by theta about Cartesian axis `axis`: RotationMatrix (src/helper_utils.f90:39-77)
+    ! written out -- it mixes the two other components: X -> (Y, Z), Y -> (Z, X), Z -> (X, Y)
+    pure subroutine rotate_offsets(off, n1, axis, theta)
+        real(real64), intent(inout) :: off(:, :)
+        integer, intent(in) :: n1, axis
         real(real64), intent(in) :: theta
-        real(real64) :: r(3, 3), c, s
+        real(real64) :: c, sn, x, y
+        integer :: p, q, a
         c = cos(theta)
-        s = sin(theta)
-        r = 0.0_real64
-        r(1, 1) = 1.0_real64; r(2, 2) = 1.0_real64; r(3, 3) = 1.0_real64
-        select case (axis)
-        case (1)
-            r(2, 2) = c; r(2, 3) = -s; r(3, 2) = s; r(3, 3) = c
-        case (2)
-            r(1, 1) = c; r(1, 3) = s; r(3, 1) = -s; r(3, 3) = c
-        case (3)
-            r(1, 1) = c; r(1, 2) = -s; r(2, 1) = s; r(2, 2) = c
-        end select
-    end function RotationMatrix
+        sn = sin(theta)
+        p = mod(axis, 3) + 1
+        q = mod(axis + 1, 3) + 1
+        do a = 1, n1
+            x = off(p, a)
+            y = off(q, a)
+            off(p, a) = c * x - sn * y
+            off(q, a) = sn * x + c * y
+        end do
+    end subroutine rotate_offsets
 
     !---------------------------------------------------------------------------
-    ! One trial move per replica of a lane (monte_carlo.f90:50-58 + RandomTranslation /
-    ! ApplyRandomRotation), then queue its evaluation.
+    ! One trial move per replica of a lane, then queue its evaluation.
     !---------------------------------------------------------------------------
     function generate_and_submit(g) result(rc)
         integer, intent(in) :: g
         integer(c_int) :: rc
-        integer :: i, r, ia, slot, n1, axis, d, a
-        integer(int64) :: c0, c1, c2, c3, c4
-        integer :: p, q
-        real(real64) :: theta, c, sn, x, y
+        integer :: i, j, r, ia, slot, n1, axis, d, a, mv, n
+        integer(int64) :: c0, c1, c2, c3, c4, skipped
+        real(real64) :: x, draw
         type(lane_buffers), pointer :: L
         L => F%lane(g)
         rc = MGPU_OK
+        L%nc = 0
         if (L%n == 0) return
         call system_clock(c0)
         call farm_random(L%u(:, 1:L%n))
         call system_clock(c3)
-        ! pass 1: pick (type, molecule) and gather its com / offsets from the host mirror.  Kept free
-        ! of arithmetic so the out-of-order core overlaps the cache misses of independent chains.
-        !$omp parallel do num_threads(F%n_threads) schedule(static) private(r, ia, slot)
+        ! pass 0 (serial, cheap): which move each chain attempts (monte_carlo.f90:50-75); chains whose
+        ! selection is a no-op in the reference (empty type, molecule_index = 0) submit nothing
+        j = 0
+        skipped = 0
         do i = 1, L%n
-            r = L%first + i                                           ! 1-based replica
+            r = L%first + i
             ia = min(int(L%u(1, i) * F%n_active) + 1, F%n_active)      ! PickRandomResidueType
-            slot = min(int(L%u(2, i) * F%n_mol(ia)) + 1, F%n_mol(ia))  ! PickRandomMoleculeIndex
-            L%ia(i) = ia
-            L%rep(i) = r - 1
-            L%t(i) = F%res_type(ia)
-            L%m(i) = slot - 1
-            L%new_com(:, i) = F%com(:, F%first(ia) + slot, r)
-            L%new_off(:, :, i) = F%off(:, :, F%first(ia) + slot, r)
+            n = F%cnt(ia, r)
+            draw = L%u(3, i)
+            if (draw <= F%p_translation) then
+                mv = MV_TRANSLATION
+            else if (draw <= F%p_rotation + F%p_translation) then
+                mv = MV_ROTATION
+            else if (L%u(10, i) <= PROB_CREATE_DELETE) then
+                mv = MV_CREATION
+            else
+                mv = MV_DELETION
+            end if
+            if (.not. F%gcmc .and. mv > MV_ROTATION) mv = MV_ROTATION
+            if (mv == MV_ROTATION .and. F%n1(ia) == 1) then
+                if (F%gcmc) then
+                    skipped = skipped + 1                               ! rotation.f90:45 returns
+                    cycle
+                end if
+                mv = MV_TRANSLATION                                     ! NVT farm of atoms: always translate
+            end if
+            if (mv == MV_CREATION) then
+                if (n >= F%cap(ia)) then
+                    skipped = skipped + 1                               ! reference aborts past NB_MAX_MOLECULE
+                    cycle
+                end if
+                slot = n + 1                                            ! monte_carlo.f90:63
+            else
+                if (n == 0) then
+                    skipped = skipped + 1                               ! molecule_index = 0: the drivers return
+                    cycle
+                end if
+                slot = min(int(L%u(2, i) * n) + 1, n)                   ! PickRandomMoleculeIndex
+            end if
+            j = j + 1
+            L%cidx(j) = i
+            L%ia(j) = ia
+            L%move(j) = mv
+            L%rep(j) = r - 1
+            L%t(j) = F%res_type(ia)
+            L%m(j) = slot - 1
+            select case (mv)
+            case (MV_CREATION)
+                L%kind(j) = MGPU_CREATION
+            case (MV_DELETION)
+                L%kind(j) = MGPU_DELETION
+            case default
+                L%kind(j) = MGPU_MOVE
+            end select
+        end do
+        L%nc = j
+        F%skipped = F%skipped + skipped
+        ! pass 1: gather com / offsets from the host mirror.  Kept free of arithmetic so the
+        ! out-of-order cores overlap the cache misses of independent chains.
+        !$omp parallel do num_threads(F%n_threads) schedule(static) private(r, ia, slot)
+        do j = 1, L%nc
+            r = L%rep(j) + 1
+            ia = L%ia(j)
+            slot = L%m(j) + 1
+            if (L%move(j) == MV_CREATION) slot = 1          ! geometry of molecule 1, create_molecule.f90:197-199
+            L%new_com(:, j) = F%com(:, F%first(ia) + slot, r)
+            L%new_off(:, :, j) = F%off(:, :, F%first(ia) + slot, r)
         end do
         !$omp end parallel do
         call system_clock(c4)
         F%ticks(6) = F%ticks(6) + (c3 - c0)
         F%ticks(7) = F%ticks(7) + (c4 - c3)
         ! pass 2: the moves themselves
-        !$omp parallel do num_threads(F%n_threads) schedule(static) private(n1, d, x, y, theta, axis, c, sn, p, q, a)
-        do i = 1, L%n
-            n1 = F%n1(L%ia(i))
-            L%is_trans(i) = (L%u(3, i) <= F%p_translation) .or. (n1 == 1)
-            if (L%is_trans(i)) then
+        !$omp parallel do num_threads(F%n_threads) schedule(static) private(i, n1, d, x, axis, a)
+        do j = 1, L%nc
+            i = L%cidx(j)
+            n1 = F%n1(L%ia(j))
+            select case (L%move(j))
+            case (MV_TRANSLATION)
                 ! translation.f90:104-110: rand_symmetric(3)*translation_step, then ApplyPBC
-                ! (geometry_utils.f90:190: lo + modulo(pos - lo, L); written out: pos - lo is
-                !  within one box length of [0, L) for any legal step)
+                ! (geometry_utils.f90:190: lo + modulo(pos - lo, L))
                 do d = 1, 3
-                    x = (L%new_com(d, i) + (L%u(3 + d, i) - 0.5_real64) * F%translation_step) - F%lo(d)
+                    x = (L%new_com(d, j) + (L%u(3 + d, i) - 0.5_real64) * F%translation_step) - F%lo(d)
                     if (x < 0.0_real64 .or. x >= F%len(d)) x = modulo(x, F%len(d))
-                    L%new_com(d, i) = F%lo(d) + x
+                    L%new_com(d, j) = F%lo(d) + x
                 end do
-            else
-                ! monte_carlo_utils.f90:54-64 with RotationMatrix (helper_utils.f90:39-77) written out:
-                ! rotation by theta about Cartesian axis `axis` mixes the two other components
-                theta = (L%u(7, i) - 0.5_real64) * F%rotation_step
+            case (MV_ROTATION)
+                ! monte_carlo_utils.f90:54-64: theta = (u - 1/2)*rotation_step_angle, random Cartesian axis
                 axis = int(L%u(8, i) * 3.0_real64) + 1
-                c = cos(theta)
-                sn = sin(theta)
-                p = mod(axis, 3) + 1          ! X -> (Y, Z), Y -> (Z, X), Z -> (X, Y)
-                q = mod(axis + 1, 3) + 1
-                do a = 1, n1
-                    x = L%new_off(p, a, i)
-                    y = L%new_off(q, a, i)
-                    L%new_off(p, a, i) = c * x - sn * y
-                    L%new_off(q, a, i) = sn * x + c * y
+                call rotate_offsets(L%new_off(:, :, j), n1, axis, (L%u(7, i) - 0.5_real64) * F%rotation_step)
+            case (MV_CREATION)
+                ! create_molecule.f90:180-203: uniform position in the (orthorhombic) box, full rotation
+                do d = 1, 3
+                    L%new_com(d, j) = F%lo(d) + F%len(d) * L%u(3 + d, i)
                 end do
-            end if
+                if (n1 > 1) then
+                    axis = int(L%u(8, i) * 3.0_real64) + 1
+                    call rotate_offsets(L%new_off(:, :, j), n1, axis, L%u(7, i) * TWOPI)
+                end if
+            case (MV_DELETION)
+                continue                                     ! the resident molecule is evaluated as it is
+            end select
             do a = 1, n1
-                L%sites(:, a, i) = L%new_com(:, i) + L%new_off(:, a, i)
+                L%sites(:, a, j) = L%new_com(:, j) + L%new_off(:, a, j)
             end do
         end do
         !$omp end parallel do
         call system_clock(c1)
-        rc = mgpu_trial_submit(F%engine, int(g, c_int), int(L%n, c_int), L%rep, L%t, L%m, L%sites, &
-                               int(F%max_n1, c_int))
+        if (L%nc > 0) then
+            if (F%gcmc) then
+                rc = mgpu_gcmc_trial_submit(F%engine, int(g, c_int), int(L%nc, c_int), L%rep, L%t, L%m, L%kind, &
+                                            L%sites, int(F%max_n1, c_int))
+            else
+                rc = mgpu_trial_submit(F%engine, int(g, c_int), int(L%nc, c_int), L%rep, L%t, L%m, L%sites, &
+                                       int(F%max_n1, c_int))
+            end if
+        end if
         call system_clock(c2)
         F%ticks(1) = F%ticks(1) + (c1 - c0)
         F%ticks(2) = F%ticks(2) + (c2 - c1)
     end function generate_and_submit
 
     !---------------------------------------------------------------------------
-    ! Collect a lane's energies, apply the Metropolis test per replica
-    ! (mc_acceptance_probability, monte_carlo_utils.f90:204-218), update the host mirrors
-    ! and running energies (AcceptMove) and queue the commit of the accepted moves.
+    ! Collect a lane's energies, apply the acceptance rule per replica
+    ! (mc_acceptance_probability, monte_carlo_utils.f90:184-226), update the host mirrors and
+    ! running energies (AcceptMove / AcceptCreationMove / AcceptDeletionMove) and queue the commit.
     !---------------------------------------------------------------------------
     function resolve_and_commit(g) result(rc)
         integer, intent(in) :: g
         integer(c_int) :: rc
-        integer :: i, r, ia, slot, n1
-        integer(int64) :: c0, c1, c2, c3, n_tt, n_t, n_rr, n_r
-        real(real64) :: delta_e, probability
+        integer :: i, j, k, r, ia, slot, n1, ne, last, base, o
+        integer(int64) :: c0, c1, c2, c3
+        integer(int64) :: k_tt, k_t, k_rt, k_r, k_ct, k_c, k_dt, k_d
+        real(real64) :: delta_e, probability, nn, phi, e_old, e_new
         type(lane_buffers), pointer :: L
         L => F%lane(g)
         rc = MGPU_OK
-        if (L%n == 0) return
+        if (L%nc == 0) return
         call system_clock(c0)
-        rc = mgpu_trial_wait(F%engine, int(g, c_int), L%old_e, L%new_e)
+        if (F%gcmc) then
+            ne = 5
+            rc = mgpu_gcmc_trial_wait(F%engine, int(g, c_int), L%old_e, L%new_e)   ! rows of 5
+        else
+            ne = 3
+            rc = mgpu_trial_wait(F%engine, int(g, c_int), L%old_e, L%new_e)        ! rows of 3
+        end if
         if (rc /= MGPU_OK) return
         call system_clock(c1)
-        n_tt = 0; n_t = 0; n_rr = 0; n_r = 0
-        !$omp parallel do num_threads(F%n_threads) schedule(static) private(r, delta_e, probability, ia, slot, n1) &
-        !$omp& reduction(+:n_tt, n_t, n_rr, n_r)
-        do i = 1, L%n
-            r = L%first + i
-            delta_e = (L%new_e(1, i) + L%new_e(2, i) + L%new_e(3, i)) - (L%old_e(1, i) + L%old_e(2, i) + L%old_e(3, i))
-            probability = min(1.0_real64, exp(-delta_e / F%temperature))
-            if (L%is_trans(i)) then
-                n_tt = n_tt + 1
-            else
-                n_rr = n_rr + 1
-            end if
+        k_tt = 0; k_t = 0; k_rt = 0; k_r = 0; k_ct = 0; k_c = 0; k_dt = 0; k_d = 0
+        !$omp parallel do num_threads(F%n_threads) schedule(static) &
+        !$omp& private(i, k, r, ia, slot, n1, delta_e, probability, nn, phi, last, base, o, e_old, e_new) &
+        !$omp& reduction(+:k_tt, k_t, k_rt, k_r, k_ct, k_c, k_dt, k_d)
+        do j = 1, L%nc
+            i = L%cidx(j)
+            r = L%rep(j) + 1
+            ia = L%ia(j)
+            n1 = F%n1(ia)
+            base = F%first(ia)
+            o = ne * (j - 1)
+            e_old = 0.0_real64
+            e_new = 0.0_real64
+            do k = 1, ne                                                   ! old%total, new%total
+                e_old = e_old + L%old_e(o + k)
+                e_new = e_new + L%new_e(o + k)
+            end do
+            delta_e = e_new - e_old
+            select case (L%move(j))
+            case (MV_CREATION)
+                nn = real(F%cnt(ia, r) + 1, real64)                        ! N already incremented, create_molecule.f90:64
+                phi = F%fugacity(ia, r)
+                probability = min(1.0_real64, (phi * F%volume / nn) * exp(-delta_e / F%temperature))
+                k_ct = k_ct + 1
+            case (MV_DELETION)
+                nn = real(F%cnt(ia, r) - 1, real64)                        ! N already decremented, delete_molecule.f90:73
+                phi = F%fugacity(ia, r)
+                probability = min(1.0_real64, ((nn + 1.0_real64) / (phi * F%volume)) * exp(-delta_e / F%temperature))
+                k_dt = k_dt + 1
+            case (MV_TRANSLATION)
+                probability = min(1.0_real64, exp(-delta_e / F%temperature))
+                k_tt = k_tt + 1
+            case default
+                probability = min(1.0_real64, exp(-delta_e / F%temperature))
+                k_rt = k_rt + 1
+            end select
             if (L%u(9, i) <= probability) then
-                L%accept(i) = 1
-                ia = L%ia(i)
-                slot = L%m(i) + 1
-                n1 = F%n1(ia)
-                F%com(:, F%first(ia) + slot, r) = L%new_com(:, i)
-                F%off(:, 1:n1, F%first(ia) + slot, r) = L%new_off(:, 1:n1, i)
-                F%energy(:, r) = F%energy(:, r) + L%new_e(:, i) - L%old_e(:, i)
-                if (L%is_trans(i)) then
-                    n_t = n_t + 1
-                else
-                    n_r = n_r + 1
-                end if
+                L%accept(j) = 1
+                slot = L%m(j) + 1
+                select case (L%move(j))
+                case (MV_CREATION)
+                    F%com(:, base + slot, r) = L%new_com(:, j)
+                    F%off(:, 1:n1, base + slot, r) = L%new_off(:, 1:n1, j)
+                    F%cnt(ia, r) = F%cnt(ia, r) + 1
+                    k_c = k_c + 1
+                case (MV_DELETION)
+                    last = F%cnt(ia, r)                                    ! RemoveMolecule, delete_molecule.f90:107-114
+                    F%com(:, base + slot, r) = F%com(:, base + last, r)
+                    F%off(:, :, base + slot, r) = F%off(:, :, base + last, r)
+                    F%cnt(ia, r) = last - 1
+                    k_d = k_d + 1
+                case default
+                    F%com(:, base + slot, r) = L%new_com(:, j)
+                    F%off(:, 1:n1, base + slot, r) = L%new_off(:, 1:n1, j)
+                    if (L%move(j) == MV_TRANSLATION) then
+                        k_t = k_t + 1
+                    else
+                        k_r = k_r + 1
+                    end if
+                end select
+                ! monte_carlo_utils.f90:416-419, create_molecule.f90:107-112, delete_molecule.f90:137-142
+                do k = 1, ne
+                    F%energy(k, r) = F%energy(k, r) + L%new_e(o + k) - L%old_e(o + k)
+                end do
             else
-                L%accept(i) = 0
+                L%accept(j) = 0
             end if
         end do
         !$omp end parallel do
-        F%trial_translations = F%trial_translations + n_tt
-        F%translations = F%translations + n_t
-        F%trial_rotations = F%trial_rotations + n_rr
-        F%rotations = F%rotations + n_r
-        F%accepted = F%accepted + n_t + n_r
-        F%trials = F%trials + L%n
+        F%counters = F%counters + [k_tt, k_t, k_rt, k_r, k_ct, k_c, k_dt, k_d]
+        F%accepted = F%accepted + k_t + k_r + k_c + k_d
+        F%trials = F%trials + L%nc
         call system_clock(c2)
-        rc = mgpu_commit_submit(F%engine, int(g, c_int), int(L%n, c_int), L%rep, L%t, L%m, L%kind, &
+        rc = mgpu_commit_submit(F%engine, int(g, c_int), int(L%nc, c_int), L%rep, L%t, L%m, L%kind, &
                                 c_null_ptr, int(F%max_n1, c_int), L%accept)
         call system_clock(c3)
+        L%nc = 0
         F%ticks(3) = F%ticks(3) + (c1 - c0)
         F%ticks(4) = F%ticks(4) + (c2 - c1)
         F%ticks(5) = F%ticks(5) + (c3 - c2)
     end function resolve_and_commit
 
     !---------------------------------------------------------------------------
-    ! Advance every chain by n_steps trial moves.  out = trials, accepted,
-    ! trial_translations, translations, trial_rotations, rotations (cumulative).
+    ! Advance every chain by n_steps move selections.  out = trials, accepted, skipped selections.
     !---------------------------------------------------------------------------
     function mfarm_run(n_steps, out) bind(C, name="mfarm_run") result(rc)
         integer(c_int), value :: n_steps
-        real(c_double), intent(out) :: out(6)
+        real(c_double), intent(out) :: out(3)
         integer(c_int) :: rc
         integer :: step, g
         rc = MGPU_OK
@@ -406,26 +568,33 @@ contains
             end do
             rc = mgpu_synchronize(F%engine)
         end if
-        out(1) = real(F%trials, real64); out(2) = real(F%accepted, real64)
-        out(3) = real(F%trial_translations, real64); out(4) = real(F%translations, real64)
-        out(5) = real(F%trial_rotations, real64); out(6) = real(F%rotations, real64)
+        out(1) = real(F%trials, real64)
+        out(2) = real(F%accepted, real64)
+        out(3) = real(F%skipped, real64)
     end function mfarm_run
+
+    ! trial / accepted counts: translations, rotations, creations, deletions (counter_type,
+    ! src/simulation_state.f90:19-31)
+    subroutine mfarm_get_counters(c) bind(C, name="mfarm_get_counters")
+        real(c_double), intent(out) :: c(8)
+        c = real(F%counters, real64)
+    end subroutine mfarm_get_counters
 
     ! AdjustMoveStepSizes (src/monte_carlo_utils.f90:99-130), as written in the reference
     ! (including its min(..*1.95, MIN_ROTATION_ANGLE) branch), on the farm-wide counters.
     subroutine mfarm_recalibrate(steps) bind(C, name="mfarm_recalibrate")
         real(c_double), intent(out) :: steps(2)
         real(real64) :: acc
-        if (F%trial_translations > MIN_TRIALS_FOR_RECALIBRATION) then
-            acc = real(F%translations, real64) / real(F%trial_translations, real64)
+        if (F%counters(1) > MIN_TRIALS_FOR_RECALIBRATION) then
+            acc = real(F%counters(2), real64) / real(F%counters(1), real64)
             if (acc - TARGET_ACCEPTANCE > TOL_ACCEPTANCE) then
                 F%translation_step = min(F%translation_step * 1.05d0, MAX_TRANSLATION_STEP)
             else if (acc - TARGET_ACCEPTANCE < TOL_ACCEPTANCE) then
                 F%translation_step = max(F%translation_step * 0.95d0, MIN_TRANSLATION_STEP)
             end if
         end if
-        if (F%trial_rotations > MIN_TRIALS_FOR_RECALIBRATION) then
-            acc = real(F%rotations, real64) / real(F%trial_rotations, real64)
+        if (F%counters(3) > MIN_TRIALS_FOR_RECALIBRATION) then
+            acc = real(F%counters(4), real64) / real(F%counters(3), real64)
             if (acc - TARGET_ACCEPTANCE > TOL_ACCEPTANCE) then
                 F%rotation_step = min(F%rotation_step * 1.05d0, MAX_ROTATION_ANGLE)
             else if (acc - TARGET_ACCEPTANCE < TOL_ACCEPTANCE) then
@@ -437,7 +606,7 @@ contains
     end subroutine mfarm_recalibrate
 
     ! host wall time spent in: trial generation, trial submit, waiting for the GPU, Metropolis
-    ! resolution, commit submit (seconds, cumulative)
+    ! resolution, commit submit, and inside generation: random numbers, mirror gathers (seconds)
     subroutine mfarm_get_timers(t) bind(C, name="mfarm_get_timers")
         real(c_double), intent(out) :: t(7)
         integer(int64) :: rate
@@ -445,12 +614,18 @@ contains
         t = real(F%ticks, real64) / real(rate, real64)
     end subroutine mfarm_get_timers
 
-    ! running energies (non_coulomb, coulomb, recip_coulomb) of one replica (0-based)
+    ! running energies (non_coulomb, coulomb, recip_coulomb, ewald_self, intra_coulomb) of one replica
     subroutine mfarm_get_energy(replica, e) bind(C, name="mfarm_get_energy")
         integer(c_int), value :: replica
-        real(c_double), intent(out) :: e(3)
+        real(c_double), intent(out) :: e(5)
         e = F%energy(:, replica + 1)
     end subroutine mfarm_get_energy
+
+    ! current molecule counts, (n_active, R) column-major
+    subroutine mfarm_get_counts(cnt) bind(C, name="mfarm_get_counts")
+        integer(c_int), intent(out) :: cnt(F%n_active, F%n_replicas)
+        cnt = F%cnt
+    end subroutine mfarm_get_counts
 
     ! host mirror of one molecule: active-type index ia (0-based), slot (0-based), replica (0-based)
     subroutine mfarm_get_molecule(replica, ia, slot, com, off) bind(C, name="mfarm_get_molecule")

@@ -51,56 +51,81 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.mfarm_create.restype = C.c_int
         L.mfarm_run.restype = C.c_int
+        L.mfarm_set_gcmc.restype = C.c_int
         _host = L
     return _host
 
 
 class FortranFarm:
-    """R chains of `system` on one GPU, advanced by the Fortran driver (mc_farm.f90)."""
+    """R chains of `system` on one GPU, advanced by the Fortran driver (mc_farm.f90).
+
+    NVT by default (translation / rotation).  ``gcmc=dict(p_translation=..., p_rotation=..., fugacity=...)``
+    switches insertion / deletion on: ``fugacity`` in molecules per cubic Angstrom, scalar, per active
+    type, or (n_active, R) for an isotherm sweep; ``mol_capacity`` bounds the molecule count per type.
+    """
 
     def __init__(self, system: System, n_replicas: int, device: int = 0, seed: int = 1,
                  translation_step: float = 0.3, rotation_step: float = 0.3, p_translation: float = 0.5,
-                 rng_kind: int = 1, n_threads: int = 8):
+                 rng_kind: int = 1, n_threads: int = 8, mol_capacity=None, gcmc=None):
         self.H = lib()
         self.sys = system
         self.R = int(n_replicas)
-        self.eng = Engine(system.topo, system.box_matrix, system.bounds_lo, system.real_space_cutoff,
-                          system.ewald_tolerance, self.R, device,
-                          [max(1, int(n)) for n in system.n_mol])
+        topo = system.topo
+        if mol_capacity is None:
+            mol_capacity = [max(1, int(n)) for n in system.n_mol]
+        self.mol_capacity = [int(c) for c in mol_capacity]
+        self.eng = Engine(topo, system.box_matrix, system.bounds_lo, system.real_space_cutoff,
+                          system.ewald_tolerance, self.R, device, self.mol_capacity)
         self.eng.load_system(system, 0)
         self.eng.init_structure_factor(0, True)
         for r in range(1, self.R):
             self.eng.replica_copy(r, 0)
         e0 = self.eng.system_energy(0)
-        topo = system.topo
-        active = [t for t in range(topo.n_res) if topo.is_active[t] and system.n_mol[t] > 0]
+        active = [t for t in range(topo.n_res) if topo.is_active[t]]
         self.active = np.array(active, dtype=np.int32)
         n1 = np.array([topo.atoms_in_res[t] for t in active], dtype=np.int32)
         nmol = np.array([system.n_mol[t] for t in active], dtype=np.int32)
+        cap = np.array([self.mol_capacity[t] for t in active], dtype=np.int32)
         max_n1 = int(n1.max())
-        cap = int(nmol.sum())
-        com = np.zeros((cap, 3))
-        off = np.zeros((cap, max_n1, 3))
+        tot = max(1, int(nmol.sum()))
+        com = np.zeros((tot, 3))
+        off = np.zeros((tot, max_n1, 3))
         pos = 0
         for k, t in enumerate(active):
             com[pos:pos + nmol[k]] = system.com[t]
             off[pos:pos + nmol[k], :n1[k]] = system.offsets[t]
             pos += nmol[k]
-        energy0 = np.array([e0["non_coulomb"], e0["coulomb"], e0["recip_coulomb"]])
+        energy0 = np.array([e0["non_coulomb"], e0["coulomb"], e0["recip_coulomb"], e0["ewald_self"],
+                            e0["intra_coulomb"]])
         lo = np.ascontiguousarray(system.bounds_lo)
         length = np.ascontiguousarray(np.diag(system.box_matrix))
         rc = self.H.mfarm_create(self.eng.h, C.c_int(self.R), C.c_int(len(active)), self.active.ctypes.data_as(_ip),
-                                 n1.ctypes.data_as(_ip), nmol.ctypes.data_as(_ip), C.c_int(max_n1),
-                                 com.ctypes.data_as(_dp), off.ctypes.data_as(_dp), energy0.ctypes.data_as(_dp),
-                                 lo.ctypes.data_as(_dp), length.ctypes.data_as(_dp), C.c_double(system.temperature),
-                                 C.c_double(translation_step), C.c_double(rotation_step), C.c_double(p_translation),
-                                 C.c_int(seed), C.c_int(rng_kind), C.c_int(n_threads))
+                                 n1.ctypes.data_as(_ip), nmol.ctypes.data_as(_ip), cap.ctypes.data_as(_ip),
+                                 C.c_int(max_n1), com.ctypes.data_as(_dp), off.ctypes.data_as(_dp),
+                                 energy0.ctypes.data_as(_dp), lo.ctypes.data_as(_dp), length.ctypes.data_as(_dp),
+                                 C.c_double(system.temperature), C.c_double(translation_step),
+                                 C.c_double(rotation_step), C.c_double(p_translation), C.c_int(seed),
+                                 C.c_int(rng_kind), C.c_int(n_threads))
         _lib.check(rc)
         self.max_n1 = max_n1
-        self.stats = np.zeros(6)
+        self.n_active = len(active)
+        self.stats = np.zeros(3)
+        if gcmc is not None:
+            fug = np.asarray(gcmc["fugacity"], dtype=np.float64)
+            if fug.ndim == 0:
+                fug = np.full((self.R, self.n_active), float(fug))
+            elif fug.ndim == 1:
+                fug = np.tile(fug[None, :], (self.R, 1)) if fug.shape[0] == self.n_active and self.n_active > 1 \
+                    else (np.tile(fug[:, None], (1, self.n_active)) if fug.shape[0] == self.R
+                          else np.tile(fug[None, :], (self.R, 1)))
+            fug = np.ascontiguousarray(fug.reshape(self.R, self.n_active))     # == Fortran (n_active, R)
+            rc = self.H.mfarm_set_gcmc(C.c_double(gcmc["p_translation"]), C.c_double(gcmc["p_rotation"]),
+                                       fug.ctypes.data_as(_dp))
+            if rc:
+                raise ValueError(f"mfarm_set_gcmc: bad probabilities / fugacity (code {rc})")
 
     def run(self, n_steps: int) -> int:
-        """Advance every chain by n_steps trials; returns the moves accepted during this call."""
+        """Advance every chain by n_steps move selections; returns the moves accepted during this call."""
         before = self.stats[1]
         rc = self.H.mfarm_run(C.c_int(n_steps), self.stats.ctypes.data_as(_dp))
         _lib.check(rc)
@@ -117,8 +142,21 @@ class FortranFarm:
         self.H.mfarm_get_timers(t.ctypes.data_as(_dp))
         return dict(zip(("generate", "submit", "wait", "resolve", "commit", "gen_rng", "gen_gather"), t.tolist()))
 
+    def counters(self):
+        c = np.zeros(8)
+        self.H.mfarm_get_counters(c.ctypes.data_as(_dp))
+        names = ("trial_translations", "translations", "trial_rotations", "rotations", "trial_creations",
+                 "creations", "trial_deletions", "deletions")
+        return dict(zip(names, c.astype(np.int64).tolist()))
+
+    def counts(self):
+        """Current molecule counts, shape (R, n_active)."""
+        c = np.zeros((self.R, self.n_active), dtype=np.int32)
+        self.H.mfarm_get_counts(c.ctypes.data_as(_ip))
+        return c
+
     def energy(self, replica: int):
-        e = np.zeros(3)
+        e = np.zeros(5)
         self.H.mfarm_get_energy(C.c_int(replica), e.ctypes.data_as(_dp))
         return e
 
@@ -136,6 +174,10 @@ class FortranFarm:
     @property
     def accepted(self):
         return int(self.stats[1])
+
+    @property
+    def skipped(self):
+        return int(self.stats[2])
 
     def close(self):
         self.H.mfarm_destroy()

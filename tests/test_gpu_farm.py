@@ -17,7 +17,7 @@ def test_fortran_farm_consistency(maker, R, steps):
     s = maker()
     farm = FortranFarm(s, R, seed=11, translation_step=0.4, rotation_step=0.4)
     acc = farm.run(steps)
-    assert farm.trials == R * steps and 0 < acc <= farm.trials
+    assert farm.trials + farm.skipped == R * steps and 0 < acc <= farm.trials
     assert acc == farm.accepted
     eng = farm.eng
     for r in range(R):
@@ -26,6 +26,7 @@ def test_fortran_farm_consistency(maker, R, steps):
         # the running sums accumulate `steps` increments of O(1e5) K terms: allow their rounding
         tol = TOL_K + 64 * np.finfo(float).eps * max(abs(e["recip_coulomb"]), abs(e["coulomb"])) * np.sqrt(steps)
         assert abs(run[0] - e["non_coulomb"]) < tol and abs(run[1] - e["coulomb"]) < tol and abs(run[2] - e["recip_coulomb"]) < tol
+        assert run[3] == e["ewald_self"] and abs(run[4] - e["intra_coulomb"]) <= 1e-6      # untouched by NVT moves
         A = eng.structure_factor(r)
         eng.init_structure_factor(r, True)
         assert np.max(np.abs(A - eng.structure_factor(r))) < 1e-10
@@ -39,7 +40,7 @@ def test_fortran_farm_consistency(maker, R, steps):
     # replicas diverged (independent chains) and a second run continues
     assert not np.array_equal(eng.get_molecules(0, int(farm.active[0])), eng.get_molecules(R - 1, int(farm.active[0])))
     acc2 = farm.run(5)
-    assert farm.trials == R * (steps + 5) and farm.accepted == acc + acc2
+    assert farm.trials + farm.skipped == R * (steps + 5) and farm.accepted == acc + acc2
     farm.close()
 
 
@@ -55,3 +56,60 @@ def test_fortran_farm_matches_python_farm_statistically():
     a2 = f2.run(30) / (64 * 30)
     f2.close()
     assert abs(a1 - a2) < 0.06, (a1, a2)
+
+
+def test_fortran_farm_intrinsic_rng_and_single_replica():
+    """rng_kind 0 = the reference's random_number; one replica = one lane idle."""
+    from maniac_mc_amd.fortran_host import FortranFarm
+    s = synth.mixture_box(seed=4)
+    farm = FortranFarm(s, 1, seed=3, rng_kind=0, n_threads=1)
+    farm.run(25)
+    assert farm.trials + farm.skipped == 25
+    e = farm.eng.system_energy(0)
+    run = farm.energy(0)
+    assert abs(run[0] - e["non_coulomb"]) < 1e-6 and abs(run[1] - e["coulomb"]) < 1e-6
+    farm.close()
+
+
+def test_gcmc_farm_consistency_and_ideal_gas_limit():
+    """Grand-canonical chains (BASELINE.json configs[2]/[4] in miniature): insertion / deletion /
+    translation / rotation of rigid CO2 in a 50 A box at several fugacities, one per replica group.
+    (1) bookkeeping: counts, running 5-component energies, A(k) and host mirrors equal a from-scratch
+    evaluation; (2) physics: at this density CO2 is nearly ideal, so <N> ~ fugacity * V."""
+    from maniac_mc_amd.fortran_host import FortranFarm
+    s = synth.co2_box(20, seed=13)
+    R = 24
+    V = 50.0 ** 3
+    targets = np.repeat([10.0, 20.0, 30.0], R // 3)               # phi V per replica
+    farm = FortranFarm(s, R, seed=17, translation_step=1.0, rotation_step=0.6, n_threads=4, mol_capacity=[90],
+                       gcmc=dict(p_translation=0.2, p_rotation=0.2, fugacity=targets / V))
+    farm.run(600)                                                   # equilibrate
+    samples = []
+    for _ in range(40):
+        farm.run(40)
+        samples.append(farm.counts()[:, 0].copy())
+    samples = np.array(samples, dtype=np.float64)                  # (40, R)
+    c = farm.counters()
+    assert c["trial_creations"] > 0 and c["trial_deletions"] > 0 and c["creations"] > 0 and c["deletions"] > 0
+    assert farm.trials == sum(c[k] for k in ("trial_translations", "trial_rotations", "trial_creations", "trial_deletions"))
+    assert farm.trials + farm.skipped == R * (600 + 40 * 40)
+    eng = farm.eng
+    counts = farm.counts()[:, 0]
+    for r in range(R):
+        assert eng.num_molecules(r, 0) == counts[r]
+        e = eng.system_energy(r)
+        run = farm.energy(r)
+        ref = np.array([e[k] for k in ("non_coulomb", "coulomb", "recip_coulomb", "ewald_self", "intra_coulomb")])
+        assert np.max(np.abs(run - ref)) < 2e-5 * max(1.0, np.max(np.abs(ref)) * 1e-6), (r, run - ref)
+        A = eng.structure_factor(r)
+        eng.init_structure_factor(r, True)
+        assert np.max(np.abs(A - eng.structure_factor(r))) < 1e-9
+        dev = eng.get_molecules(r, 0)
+        for slot in range(counts[r]):
+            com, off = farm.molecule(r, 0, slot)
+            assert np.array_equal(dev[slot], com[None, :] + off[:3])
+    # ideal-gas limit: mean N per fugacity group within 12 % of phi V (Poisson noise ~3 % here)
+    for g, target in enumerate([10.0, 20.0, 30.0]):
+        mean_n = samples[:, g * (R // 3):(g + 1) * (R // 3)].mean()
+        assert abs(mean_n - target) < 0.12 * target, (target, mean_n)
+    farm.close()
