@@ -110,7 +110,8 @@ int mgpu_coulomb_table_eval(double alpha, double r2_max, int n, const double *r2
  *                                  (parameters_parser.f90:89-98, :141-176)
  *   box_matrix[9], bounds_lo[3]    box%matrix (row-major image), box%bounds(:,1)
  *   real_space_cutoff, ewald_tolerance  as read from the .maniac file; SetupEwald is applied.
- * Triclinic boxes (box_type 3) are rejected with MGPU_ERR_INVALID_ARG in this version. */
+ * Triclinic boxes (box_type 3) use the reference's 27-image distance search (geometry_utils.f90:397-411)
+ * and take the generic sweep; cubic / orthorhombic boxes take the tuned one. */
 int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
                        const int *atoms_in_res, const int *mol_capacity, int max_atom,
                        const int *atom_types, const double *charges, const int *is_active,

@@ -242,19 +242,22 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
     hipEvent_t a = nullptr, b = nullptr;
     rc = prof_begin(e, ln, MGPU_KERNEL_PAIR, &a, &b);
     if (rc) return rc;
-#define MGPU_LAUNCH_PAIR(NS, ORD)                                                                                       \
-    hipLaunchKernelGGL((pair_sweep_kernel<NS, ORD>), dim3(grid), dim3(kPairBlock), e->coul_bytes, ln.stream, e->tp,   \
-                       e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab, d_items,   \
-                       (const double *)ln.d_sites.p, site_stride, nsplit, n_work, (double2 *)ln.d_partials.p)
-    if (ordered) {
-        MGPU_LAUNCH_PAIR(0, true);
+#define MGPU_LAUNCH_PAIR(NS, ORD, TRI)                                                                                  \
+    hipLaunchKernelGGL((pair_sweep_kernel<NS, ORD, TRI>), dim3(grid), dim3(kPairBlock), e->coul_bytes, ln.stream,       \
+                       e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab,     \
+                       d_items, (const double *)ln.d_sites.p, site_stride, nsplit, n_work, (double2 *)ln.d_partials.p)
+    if (e->bx.triclinic) {
+        if (ordered) MGPU_LAUNCH_PAIR(0, true, true);
+        else MGPU_LAUNCH_PAIR(0, false, true);
+    } else if (ordered) {
+        MGPU_LAUNCH_PAIR(0, true, false);
     } else {
         switch (common_n1) {
-            case 1: MGPU_LAUNCH_PAIR(1, false); break;
-            case 2: MGPU_LAUNCH_PAIR(2, false); break;
-            case 3: MGPU_LAUNCH_PAIR(3, false); break;
-            case 4: MGPU_LAUNCH_PAIR(4, false); break;
-            default: MGPU_LAUNCH_PAIR(0, false); break;
+            case 1: MGPU_LAUNCH_PAIR(1, false, false); break;
+            case 2: MGPU_LAUNCH_PAIR(2, false, false); break;
+            case 3: MGPU_LAUNCH_PAIR(3, false, false); break;
+            case 4: MGPU_LAUNCH_PAIR(4, false, false); break;
+            default: MGPU_LAUNCH_PAIR(0, false, false); break;
         }
     }
 #undef MGPU_LAUNCH_PAIR
@@ -391,10 +394,6 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     std::memcpy(e->bounds_lo, bounds_lo, sizeof(double) * 3);
     rc = box_prepare(box_matrix, &e->box_type, &e->volume, e->reciprocal, e->metrics);
     if (rc) { delete e; return rc; }
-    if (e->box_type == 3) {
-        delete e;
-        return set_error(MGPU_ERR_INVALID_ARG, "mgpu_engine_create: triclinic boxes are not supported by this version");
-    }
     e->rc = real_space_cutoff;
     e->tol = ewald_tolerance;
     double screening, fprec;
@@ -434,6 +433,8 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     BoxDev &bx = e->bx;
     for (int d = 0; d < 3; ++d) { bx.L[d] = box_matrix[d * 3 + d]; bx.invL[d] = 1.0 / bx.L[d]; bx.kmax[d] = e->kmax[d]; }
     std::memcpy(bx.rcp, e->reciprocal, sizeof(double) * 9);
+    std::memcpy(bx.m, box_matrix, sizeof(double) * 9);
+    bx.triclinic = e->box_type == 3 ? 1 : 0;
     bx.rc2 = e->rc * e->rc;
     bx.alpha = e->alpha;
     bx.volume = e->volume;
@@ -483,7 +484,11 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     {
         // Coulomb table for this alpha, covering every minimum-image distance of this box
         std::vector<CoulRow> rows;
-        const double s_max = 0.25 * (bx.L[0] * bx.L[0] + bx.L[1] * bx.L[1] + bx.L[2] * bx.L[2]) * 1.0001;
+        // orthorhombic: (half diagonal)^2; triclinic: the 27-image minimum of sites that may sit up to a
+        // cell away is bounded by (|a| + |b| + |c|)^2
+        const double sum_len = e->metrics[0] + e->metrics[1] + e->metrics[2];
+        const double s_max = bx.triclinic ? sum_len * sum_len
+                                          : 0.25 * (bx.L[0] * bx.L[0] + bx.L[1] * bx.L[1] + bx.L[2] * bx.L[2]) * 1.0001;
         int idx_base = 0;
         if (int rc2 = build_coulomb_table(e->alpha, std::max(s_max, 1.0), rows, &idx_base)) return fail(rc2);
         e->bx.coul_idx_base = idx_base;

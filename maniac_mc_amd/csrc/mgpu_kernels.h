@@ -56,6 +56,8 @@ struct Topo {
 struct BoxDev {
     double L[3], invL[3];         // orthorhombic edge lengths box%matrix(d,d)
     double rcp[9];                // box%reciprocal, row-major
+    double m[9];                  // box%matrix, row-major (cell vectors are its columns)
+    int triclinic;                // box%type == 3: 27-image search instead of the per-axis fold
     double rc2;                   // real_space_cutoff^2
     double alpha;
     int coul_idx_base;            // Coulomb table: row = (hi32(r^2) >> 14) - coul_idx_base
@@ -92,6 +94,31 @@ __device__ __forceinline__ double wave_sum(double v) {
 // image (|d'| <= L/2) and differs only in the last bits of d'.
 __device__ __forceinline__ double min_image(double d, double L, double invL) {
     return fma(-L, rint(d * invL), d);
+}
+
+// Squared minimum-image distance for a raw separation (dx, dy, dz): ComputeDistance
+// (geometry_utils.f90:359-415).  Cubic / orthorhombic: per-axis fold.  Triclinic: the minimum over
+// the 27 neighbouring images delta + sx a + sy b + sz c, exactly the reference's search.
+template <bool TRI>
+__device__ __forceinline__ double image_r2(double dx, double dy, double dz, const BoxDev &bx) {
+    if constexpr (!TRI) {
+        dx = min_image(dx, bx.L[0], bx.invL[0]);
+        dy = min_image(dy, bx.L[1], bx.invL[1]);
+        dz = min_image(dz, bx.L[2], bx.invL[2]);
+        return fma(dz, dz, fma(dy, dy, dx * dx));
+    } else {
+        double best = 1.7976931348623157e308;     // huge(1.0_real64), geometry_utils.f90:399
+        for (int sx = -1; sx <= 1; ++sx)
+            for (int sy = -1; sy <= 1; ++sy)
+                for (int sz = -1; sz <= 1; ++sz) {
+                    const double tx = dx + sx * bx.m[0] + sy * bx.m[1] + sz * bx.m[2];
+                    const double ty = dy + sx * bx.m[3] + sy * bx.m[4] + sz * bx.m[5];
+                    const double tz = dz + sx * bx.m[6] + sy * bx.m[7] + sz * bx.m[8];
+                    const double t2 = fma(tz, tz, fma(ty, ty, tx * tx));
+                    best = t2 < best ? t2 : best;
+                }
+        return best;
+    }
 }
 
 // 1/sqrt(x): v_rsq_f64 (2^-24 relative) + one Newton step with its second-order term; measured
@@ -150,14 +177,11 @@ __device__ __attribute__((noinline)) double coul_slow(double s, double alpha, bo
 // One site-atom pair: Lennard-Jones inside the cutoff (energy_utils.f90:417-424) and
 // erfc(alpha r)/r for every distance (energy_utils.f90:427-432).  Generic (per-lane flags) form used
 // by the site-major and NS = 0 sweeps; the register-site hot path inlines the same arithmetic.
-template <bool GUARD_R0>
+template <bool GUARD_R0, bool TRI>
 __device__ __forceinline__ void pair_term(double dx, double dy, double dz, const BoxDev &bx, double qq,
                                           double eps4, double sig2, bool do_lj, bool do_c,
                                           const char *__restrict__ coul_tab, double &elj, double &ec) {
-    dx = min_image(dx, bx.L[0], bx.invL[0]);
-    dy = min_image(dy, bx.L[1], bx.invL[1]);
-    dz = min_image(dz, bx.L[2], bx.invL[2]);
-    const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
+    const double r2 = image_r2<TRI>(dx, dy, dz, bx);
     if (do_lj) {
         const double s2 = sig2 * fast_rcp(r2);
         const double s6 = s2 * s2 * s2;
@@ -183,8 +207,9 @@ __device__ __forceinline__ void pair_term(double dx, double dy, double dz, const
 // NS > 0: every item has exactly NS sites, held in registers; NS = 0: any count, staged through a
 // per-wave LDS slab in chunks of kSiteChunk.  ORDERED selects SingleMolPairwiseEnergy semantics
 // (only molecules after the item's, plus CoulombEnergy's r < 1e-10 guard) for the static total.
+// TRI selects the triclinic 27-image distance (generic NS = 0 path only).
 // ------------------------------------------------------------------------------------------
-template <int NS, bool ORDERED>
+template <int NS, bool ORDERED, bool TRI>
 __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_kernel(
     Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
@@ -326,10 +351,7 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                                     bool any_below = false;
 #pragma unroll
                                     for (int s = 0; s < NREG; ++s) {
-                                        const double dx = min_image(xj - rx[s], bx.L[0], bx.invL[0]);
-                                        const double dy = min_image(yj - ry[s], bx.L[1], bx.invL[1]);
-                                        const double dz = min_image(zj - rz[s], bx.L[2], bx.invL[2]);
-                                        r2[s] = fma(dz, dz, fma(dy, dy, dx * dx));
+                                        r2[s] = image_r2<TRI>(xj - rx[s], yj - ry[s], zj - rz[s], bx);
                                     }
 #pragma unroll
                                     for (int s = 0; s < NREG; ++s) {
@@ -395,7 +417,7 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                                 const bool do_c = qj_on && (fabs(qs) >= kErrorTol);   // energy_utils.f90:430
                                 const bool do_lj = pt.x != 0.0;                        // epsilon = 0 contributes 0
                                 if ((do_c || do_lj) && valid)
-                                    pair_term<ORDERED>(xj - w_site[s * 4 + 0], yj - w_site[s * 4 + 1], zj - w_site[s * 4 + 2],
+                                    pair_term<ORDERED, TRI>(xj - w_site[s * 4 + 0], yj - w_site[s * 4 + 1], zj - w_site[s * 4 + 2],
                                                        bx, qs * qj, pt.x, pt.y, do_lj, do_c, s_coul, elj, ec);
                             }
                         }
@@ -421,7 +443,7 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                             const bool do_c = qj_on && (fabs(qs) >= kErrorTol);
                             if (valid) {
                                 double e1 = 0.0, e2 = 0.0;
-                                pair_term<ORDERED>(xj - sx, yj - sy, zj - sz, bx, qs * qj, pt.x, pt.y, true, true, s_coul, e1, e2);
+                                pair_term<ORDERED, TRI>(xj - sx, yj - sy, zj - sz, bx, qs * qj, pt.x, pt.y, true, true, s_coul, e1, e2);
                                 elj += (pt.x != 0.0) ? e1 : 0.0;
                                 ec += do_c ? e2 : 0.0;
                             }
@@ -699,10 +721,8 @@ __global__ void intra_kernel(Topo tp, BoxDev bx, const double *__restrict__ pos,
             const double q2 = res_q[it.t * tp.max_atom + a2];
             double x2, y2, z2;
             site(a2, x2, y2, z2);
-            const double dx = min_image(x2 - x1, bx.L[0], bx.invL[0]);
-            const double dy = min_image(y2 - y1, bx.L[1], bx.invL[1]);
-            const double dz = min_image(z2 - z1, bx.L[2], bx.invL[2]);
-            const double r = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
+            const double r = sqrt(bx.triclinic ? image_r2<true>(x2 - x1, y2 - y1, z2 - z1, bx)
+                                               : image_r2<false>(x2 - x1, y2 - y1, z2 - z1, bx));
             if (r > kErrorTol) u = u + q1 * q2 * (erfc(bx.alpha * r) - 1.0) / r;
         }
     }

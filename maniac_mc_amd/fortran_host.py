@@ -68,6 +68,9 @@ class FortranFarm:
                  translation_step: float = 0.3, rotation_step: float = 0.3, p_translation: float = 0.5,
                  rng_kind: int = 1, n_threads: int = 8, mol_capacity=None, gcmc=None):
         self.H = lib()
+        if system.is_triclinic():
+            raise NotImplementedError("the Fortran farm generates moves for cubic / orthorhombic boxes only "
+                                      "(the engine itself evaluates triclinic boxes)")
         self.sys = system
         self.R = int(n_replicas)
         topo = system.topo

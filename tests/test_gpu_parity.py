@@ -109,7 +109,8 @@ def test_engine_vs_golden(name):
 
 @pytest.mark.parametrize("maker,nrep", [(lambda: synth.spce_box(6, seed=21), 4), (lambda: synth.mixture_box(seed=5), 3),
                                         (lambda: synth.co2_box(16, seed=2), 2),
-                                        (lambda: synth.framework_water_box(n_water=10, n_frame=260, L=23.0, seed=9), 2)])
+                                        (lambda: synth.framework_water_box(n_water=10, n_frame=260, L=23.0, seed=9), 2),
+                                        (lambda: synth.mixture_box(seed=6, tilt=(1.5, -0.8, 0.6)), 2)])
 def test_batched_candidates_vs_refcpu(maker, nrep, refcpu_mod):
     """Many candidates per launch, on replicas holding DIFFERENT configurations."""
     rng = np.random.default_rng(7)
@@ -321,6 +322,7 @@ def test_edge_cases_and_errors():
         assert ei.value.code == 1
     with pytest.raises(_lib.MgpuError):     # two accepted candidates for one replica
         eng.commit_candidates([0, 0], [0, 0], [0, 0], [MGPU_MOVE, MGPU_MOVE], np.zeros((2, 3, 3)), [1, 1])
-    with pytest.raises(_lib.MgpuError):     # triclinic box is rejected explicitly
-        Engine.from_system(synth.mixture_box(tilt=(1.0, 0.5, 0.2)))
+    tri = Engine.from_system(synth.mixture_box(tilt=(1.0, 0.5, 0.2)))     # triclinic boxes are accepted (type 3)
+    assert tri.box_type == 3
+    tri.close()
     eng.close()

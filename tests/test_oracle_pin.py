@@ -55,7 +55,8 @@ def test_refcpu_reproduces_golden(name, refcpu_mod):
 
 @pytest.mark.parametrize("maker", [lambda: synth.spce_box(5, seed=2), lambda: synth.mixture_box(seed=8),
                                    lambda: synth.co2_box(12, seed=5), lambda: synth.mixture_box(n_a=7, n_b=5, box=(15, 15, 15), seed=1),
-                                   lambda: synth.framework_water_box(n_water=6, n_frame=200, L=22.0, seed=4)])
+                                   lambda: synth.framework_water_box(n_water=6, n_frame=200, L=22.0, seed=4),
+                                   lambda: synth.mixture_box(seed=6, tilt=(1.5, -0.8, 0.6))])
 def test_refcpu_matches_compiled_reference_bitwise(maker, refcpu_mod, reflib_mod):
     s = maker()
     R = reflib_mod.Reference(s)
