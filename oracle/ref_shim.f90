@@ -35,6 +35,10 @@ module ref_shim
     use energy_utils
     use prepare_utils
     use monte_carlo_utils
+    use initoutput_utils
+    use input_parser
+    use data_parser
+    use parameters_parser
 
     implicit none
 
@@ -521,6 +525,113 @@ contains
         input%is_active = act_save
         input%temp_K = t_save
     end function ref_convert_fugacity
+
+    !---------------------------------------------------------------------------
+    ! File-driven path: run the reference's own front end (main.f90:16-27) on a .maniac input,
+    ! a LAMMPS .data topology and a .inc parameter file, up to and including
+    ! PrepareSimulationParameters.  stage = 1 stops after ReadInput (input-file tests).
+    ! The reference allocates its state once and never frees it, so this may be called ONCE per
+    ! process (tests run it in a subprocess); a fatal input error ends the process with `stop`.
+    !---------------------------------------------------------------------------
+    function ref_load_files(maniac, data, inc, outdir, stage) bind(C, name="ref_load_files") result(rc)
+        character(kind=c_char), intent(in) :: maniac(*), data(*), inc(*), outdir(*)
+        integer(c_int), value :: stage
+        integer(c_int) :: rc
+        rc = 0
+        if (is_setup) then
+            rc = 1
+            return
+        end if
+        maniac_file = cstr(maniac)
+        data_file = cstr(data)
+        inc_file = cstr(inc)
+        output_path = cstr(outdir)
+        res_file = ''
+        call InitOutput()
+        call ReadInput()
+        if (stage > 1) then
+            call ReadSystemData()
+            call ReadParameters()
+            call PrepareSimulationParameters()
+        end if
+        energy%ewald_self = zero
+        is_setup = .true.
+    contains
+        function cstr(c) result(f)
+            character(kind=c_char), intent(in) :: c(*)
+            character(len=200) :: f
+            integer :: i
+            f = ''
+            do i = 1, 200
+                if (c(i) == c_null_char) exit
+                f(i:i) = c(i)
+            end do
+        end function cstr
+    end function ref_load_files
+
+    ! what ReadInput / ReadSystemData produced: sizes, then per-residue tables
+    subroutine ref_get_sizes(n_res, max_atom, n_atom_types) bind(C, name="ref_get_sizes")
+        integer(c_int), intent(out) :: n_res, max_atom, n_atom_types
+        n_res = nb%type_residue
+        max_atom = nb%max_atom_in_residue
+        n_atom_types = primary%num_atomtypes
+    end subroutine ref_get_sizes
+
+    subroutine ref_get_residues(atoms_in_res, types_per_res, is_active, fugacity, n_mol) bind(C, name="ref_get_residues")
+        integer(c_int), intent(out) :: atoms_in_res(nb%type_residue), types_per_res(nb%type_residue)
+        integer(c_int), intent(out) :: is_active(nb%type_residue), n_mol(nb%type_residue)
+        real(c_double), intent(out) :: fugacity(nb%type_residue)
+        atoms_in_res = nb%atom_in_residue
+        types_per_res = nb%types_per_residue
+        is_active = input%is_active
+        fugacity = input%fugacity
+        if (allocated(primary%num_residues)) then
+            n_mol = primary%num_residues
+        else
+            n_mol = 0
+        end if
+    end subroutine ref_get_residues
+
+    ! site template of one residue type (1-based t): atom types and charges per site
+    subroutine ref_get_template(t, atom_types, charges) bind(C, name="ref_get_template")
+        integer(c_int), value :: t
+        integer(c_int), intent(out) :: atom_types(nb%max_atom_in_residue)
+        real(c_double), intent(out) :: charges(nb%max_atom_in_residue)
+        atom_types = primary%atom_types(t, :)
+        charges = primary%atom_charges(t, :)
+    end subroutine ref_get_template
+
+    ! epsilon / sigma of a site pair (1-based), after ReadParameters + ApplyLorentzBerthelot
+    subroutine ref_get_coeff(t1, a1, t2, a2, eps, sig) bind(C, name="ref_get_coeff")
+        integer(c_int), value :: t1, a1, t2, a2
+        real(c_double), intent(out) :: eps, sig
+        eps = coeff%epsilon(t1, t2, a1, a2)
+        sig = coeff%sigma(t1, t2, a1, a2)
+    end subroutine ref_get_coeff
+
+    ! scalars of the .maniac input after parsing and rescaling
+    subroutine ref_get_input(out) bind(C, name="ref_get_input")
+        real(c_double), intent(out) :: out(12)
+        out(1) = real(input%nb_block, real64)
+        out(2) = real(input%nb_step, real64)
+        out(3) = input%temp_K
+        out(4) = input%ewald_tolerance
+        out(5) = input%real_space_cutoff
+        out(6) = input%translation_step
+        out(7) = input%rotation_step_angle
+        out(8) = merge(1.0_real64, 0.0_real64, input%recalibrate_moves)
+        out(9) = proba%translation
+        out(10) = proba%rotation
+        out(11) = proba%insertion_deletion
+        out(12) = proba%swap
+    end subroutine ref_get_input
+
+    subroutine ref_get_box_matrix(m, lo, hi) bind(C, name="ref_get_box_matrix")
+        real(c_double), intent(out) :: m(9), lo(3), hi(3)
+        m = reshape(primary%matrix, [9])
+        lo = primary%bounds(:, 1)
+        hi = primary%bounds(:, 2)
+    end subroutine ref_get_box_matrix
 
     ! Compile-time constants of the reference (constants.f90:7-20)
     subroutine ref_constants(out) bind(C, name="ref_constants")
