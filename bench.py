@@ -90,13 +90,18 @@ def main():
     ap.add_argument("--n-side", type=int, default=15, help="SPC/E lattice side (15 -> 10 125 atoms)")
     ap.add_argument("--host", choices=["fortran", "python"], default="fortran",
                     help="Metropolis driver: the Fortran farm (mc_farm.f90, two overlapped lanes) or the numpy one")
-    ap.add_argument("--host-threads", type=int, default=8, help="OpenMP threads of the Fortran driver (per GPU)")
+    ap.add_argument("--host-threads", type=int, default=0,
+                    help="OpenMP threads of the Fortran driver per GPU (0: min(16, cores available / ranks on the node))")
+    ap.add_argument("--lanes", type=int, default=2, help="submission lanes (chain groups in flight) of the Fortran driver")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
+    if args.host_threads <= 0:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        args.host_threads = max(1, min(16, len(os.sched_getaffinity(0)) // max(1, local_world)))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,7 +123,7 @@ def main():
         from maniac_mc_amd.fortran_host import FortranFarm as Farm
     else:
         from maniac_mc_amd.farm import ReplicaFarm as Farm
-    kw = dict(n_threads=args.host_threads) if args.host == "fortran" else {}
+    kw = dict(n_threads=args.host_threads, n_lanes=args.lanes) if args.host == "fortran" else {}
     farm = Farm(system, args.replicas, device=device, seed=1000 + rank,
                 translation_step=t_step, rotation_step=r_step, p_translation=0.5, **kw)
     eng = farm.eng
@@ -157,8 +162,9 @@ def main():
         # the 36 N part (x, y, z, q fp64 + int32 type per atom), the k sweep the 52 Nk part.
         bytes_pair_eval = 36.0 * N
         bytes_eval = 36.0 * N + 52.0 * Nk
-        # the Fortran driver splits the replicas over two lanes: each launch carries half of them
-        evals_per_launch = (2 * R) / (2 if args.host == "fortran" and R > 1 else 1)
+        # the Fortran driver splits the replicas over the engine's lanes: each launch carries one group
+        n_lanes = farm.n_lanes if args.host == "fortran" else 1
+        evals_per_launch = (2 * R) / n_lanes
         avg_pair_s = ms_pair / max(1, n_pair) * 1e-3
         achieved = bytes_pair_eval * evals_per_launch / avg_pair_s / 1e9 if n_pair else 0.0
         evals_total = 2.0 * tot_trials
@@ -169,7 +175,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"spce_{system.n_mol[0]}mol_{N}atoms_lj_cut_coul_long_ewald_Nk{Nk}",
-                       "replicas_per_gpu": R, "host_driver": args.host, "host_threads": args.host_threads if args.host == "fortran" else 1, "moves": "50% translation / 50% rotation, 0.3 A / 0.3 rad, 300 K",
+                       "replicas_per_gpu": R, "host_driver": args.host, "host_threads": args.host_threads if args.host == "fortran" else 1,
+                       "lanes": farm.n_lanes if args.host == "fortran" else 1, "moves": "50% translation / 50% rotation, 0.3 A / 0.3 rad, 300 K",
                        "trials_per_step": R * world, "dE_evals_per_step": 2 * R * world, "parallelism": f"replicas x{world}"},
             "trial_moves_per_s": tot_trials / elapsed,
             "acceptance": tot_acc / max(1.0, tot_trials),

@@ -215,7 +215,7 @@ int mgpu_commit_candidates(mgpu_engine *e, int n_candidates, const int *replica,
  * lane and returns the energies; a commit is ordered before any later submit on the same lane.
  * mgpu_commit_submit accepts sites = NULL when it commits the candidates of the lane's last
  * mgpu_trial_submit (same n_candidates, order and site_stride): their rows are still on the device. */
-#define MGPU_LANES 2
+#define MGPU_LANES 4
 int mgpu_trial_submit(mgpu_engine *e, int lane, int n_candidates, const int *replica, const int *t,
                       const int *m, const double *sites, int site_stride);
 int mgpu_trial_wait(mgpu_engine *e, int lane, double *old_energy, double *new_energy);

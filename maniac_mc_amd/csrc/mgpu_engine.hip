@@ -85,7 +85,7 @@ struct Lane {
         h_in.release(); h_commit.release(); h_out.release();
     }
 };
-constexpr int kLanes = 2;
+constexpr int kLanes = 4;
 
 }  // namespace mgpu
 
@@ -877,29 +877,27 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
         if (k == MGPU_DELETION) { ln.intra_idx[c] = n_intra; iit[n_intra++] = PairItem{replica[c], t[c], mc, -1, 0}; }
     }
     std::memcpy(h_sites, sites, site_bytes);
-    const size_t pit_bytes = (size_t)n_pair * sizeof(PairItem), iit_bytes = (size_t)n_intra * sizeof(PairItem);
+    const size_t iit_bytes = (size_t)n_intra * sizeof(PairItem);
     const size_t out_doubles = 2 * (size_t)n_pair + 3 * (size_t)n;
-    if ((rc = ln.d_items.reserve(pit_bytes + iit_bytes + 16))) return rc;
-    if ((rc = ln.d_items2.reserve(rit_bytes))) return rc;
-    if ((rc = ln.d_sites.reserve(site_bytes))) return rc;
+    // one staging block [sites | pair items (2n slots) | recip items | intra items] -> one H2D copy
+    const size_t in_bytes = site_bytes + pit_cap + rit_bytes + iit_bytes;
+    if ((rc = ln.d_sites.reserve(site_bytes + pit_cap + rit_bytes + iit_cap))) return rc;
     if ((rc = ln.d_out.reserve(out_doubles * sizeof(double)))) return rc;
     if ((rc = ln.h_out.reserve(out_doubles * sizeof(double)))) return rc;
-    HIP_TRY(hipMemcpyAsync(ln.d_sites.p, h_sites, site_bytes, hipMemcpyHostToDevice, ln.stream));
-    HIP_TRY(hipMemcpyAsync(ln.d_items.p, pit, pit_bytes, hipMemcpyHostToDevice, ln.stream));
-    HIP_TRY(hipMemcpyAsync(ln.d_items2.p, rit, rit_bytes, hipMemcpyHostToDevice, ln.stream));
-    PairItem *d_iit = (PairItem *)((char *)ln.d_items.p + pit_bytes);
-    if (n_intra) HIP_TRY(hipMemcpyAsync(d_iit, iit, iit_bytes, hipMemcpyHostToDevice, ln.stream));
+    HIP_TRY(hipMemcpyAsync(ln.d_sites.p, ln.h_in.p, in_bytes, hipMemcpyHostToDevice, ln.stream));
+    const PairItem *d_pit = (const PairItem *)((char *)ln.d_sites.p + site_bytes);
+    const RecipItem *d_rit = (const RecipItem *)((char *)ln.d_sites.p + site_bytes + pit_cap);
+    const PairItem *d_iit = (const PairItem *)((char *)ln.d_sites.p + site_bytes + pit_cap + rit_bytes);
     double *d_lj = (double *)ln.d_out.p, *d_c = d_lj + n_pair, *d_uo = d_c + n_pair, *d_un = d_uo + n, *d_in = d_un + n;
     if (n_pair) {
         const int nsplit = choose_nsplit(e, n_pair, replica[0]);
-        if ((rc = launch_pair(e, ln, (const PairItem *)ln.d_items.p, n_pair, std::max(common, 0), site_stride, nsplit, d_lj, d_c)))
-            return rc;
+        if ((rc = launch_pair(e, ln, d_pit, n_pair, std::max(common, 0), site_stride, nsplit, d_lj, d_c))) return rc;
     }
-    if ((rc = launch_recip(e, ln, (const RecipItem *)ln.d_items2.p, n, n1_max, site_stride, false, e->d_A, d_un, d_uo)))
+    if ((rc = launch_recip(e, ln, d_rit, n, n1_max, site_stride, false, e->d_A, d_un, d_uo)))
         return rc;
     if (n_intra) {
         hipLaunchKernelGGL(intra_kernel, dim3((n_intra + 63) / 64), dim3(64), 0, ln.stream, e->tp, e->bx, e->d_pos, e->d_res_q,
-                           (const PairItem *)d_iit, n_intra, (const double *)ln.d_sites.p, site_stride, d_in);
+                           d_iit, n_intra, (const double *)ln.d_sites.p, site_stride, d_in);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(ln.h_out.p, ln.d_out.p, out_doubles * sizeof(double), hipMemcpyDeviceToHost, ln.stream));

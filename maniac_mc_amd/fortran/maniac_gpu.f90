@@ -27,7 +27,7 @@ module maniac_gpu
 
     integer(c_int), parameter :: MGPU_OK = 0
     integer(c_int), parameter :: MGPU_MOVE = 0, MGPU_CREATION = 1, MGPU_DELETION = 2, MGPU_NONE = 3
-    integer(c_int), parameter :: MGPU_LANES = 2
+    integer(c_int), parameter :: MGPU_LANES = 4
 
     interface
         function mgpu_last_error() bind(C, name="mgpu_last_error") result(p)

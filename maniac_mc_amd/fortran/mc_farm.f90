@@ -26,8 +26,8 @@
 ! One chain is sequential, so the farm advances R chains in lock step: each step generates one
 ! trial move per chain, evaluates all of them in one batched call (old and new state of every
 ! candidate), applies the Metropolis test per chain and commits the accepted ones.  The chains are
-! split into two groups that alternate on the engine's two submission lanes, so the host prepares /
-! resolves one group while the GPU evaluates the other.
+! split into n_lanes groups (default two) that alternate on the engine's submission lanes, so the
+! host prepares / resolves one group while the GPU evaluates the others.
 !
 ! The per-chain loops (gathering a molecule from the host mirror, building the move, the
 ! Metropolis test) are independent across chains and run under OpenMP: with ~1000 chains the
@@ -75,8 +75,9 @@ module mc_farm
         integer :: n_replicas = 0, n_active = 0, max_n1 = 0, cap_total = 0
         integer, allocatable :: res_type(:), n1(:), cap(:), first(:)     ! per active type
         integer, allocatable :: cnt(:, :)                  ! (n_active, R)  primary%num_residues
-        real(real64), allocatable :: com(:, :, :)          ! (3, cap_total, R)    primary%mol_com
-        real(real64), allocatable :: off(:, :, :, :)       ! (3, max_n1, cap_total, R) primary%site_offset
+        ! host mirror of primary%mol_com / primary%site_offset: one contiguous record per molecule,
+        ! mol(1:3) = com, mol(3a+1:3a+3) = offset of site a -- one cache / TLB miss per random gather
+        real(real64), allocatable :: mol(:, :, :)          ! (3 + 3*max_n1, cap_total, R)
         real(real64), allocatable :: energy(:, :)          ! (5, R) non_coulomb, coulomb, recip, self, intra
         real(real64), allocatable :: fugacity(:, :)        ! (n_active, R) molecules per cubic Angstrom
         real(real64) :: lo(3), len(3), volume, temperature, translation_step, rotation_step
@@ -88,7 +89,7 @@ module mc_farm
         type(lane_buffers) :: lane(0:MGPU_LANES - 1)
         logical :: ready = .false.
         integer(int64) :: ticks(7) = 0                     ! generate, submit, wait, resolve, commit, rng, gather
-        integer :: rng_kind = 1, n_threads = 1
+        integer :: rng_kind = 1, n_threads = 1, n_lanes = 2
         integer(int64) :: xs(4) = 0                        ! xoshiro256+ state
     end type farm_state
 
@@ -148,14 +149,14 @@ contains
     !---------------------------------------------------------------------------
     function mfarm_create(engine, n_replicas, n_active, res_type, n1, n_mol, cap, max_n1, com, off, energy0, &
                           bounds_lo, box_len, temperature, translation_step, rotation_step, p_translation, seed, &
-                          rng_kind, n_threads) bind(C, name="mfarm_create") result(rc)
+                          rng_kind, n_threads, n_lanes) bind(C, name="mfarm_create") result(rc)
         type(c_ptr), value :: engine
-        integer(c_int), value :: n_replicas, n_active, max_n1, seed, rng_kind, n_threads
+        integer(c_int), value :: n_replicas, n_active, max_n1, seed, rng_kind, n_threads, n_lanes
         integer(c_int), intent(in) :: res_type(n_active), n1(n_active), n_mol(n_active), cap(n_active)
         real(c_double), intent(in) :: com(3, *), off(3, max_n1, *), energy0(5), bounds_lo(3), box_len(3)
         real(c_double), value :: temperature, translation_step, rotation_step, p_translation
         integer(c_int) :: rc
-        integer :: ia, r, g, per, tot, src
+        integer :: ia, r, g, per, tot, src, k
 
         call mfarm_destroy()
         rc = MGPU_OK
@@ -180,14 +181,15 @@ contains
             tot = tot + cap(ia)
         end do
         F%cap_total = tot
-        allocate(F%com(3, tot, n_replicas), F%off(3, max_n1, tot, n_replicas), F%energy(5, n_replicas))
-        F%com = 0.0_real64
-        F%off = 0.0_real64
+        allocate(F%mol(3 + 3 * max_n1, tot, n_replicas), F%energy(5, n_replicas))
+        F%mol = 0.0_real64
         src = 0
         do ia = 1, n_active
             do r = 1, n_replicas
-                F%com(:, F%first(ia) + 1:F%first(ia) + n_mol(ia), r) = com(:, src + 1:src + n_mol(ia))
-                F%off(:, :, F%first(ia) + 1:F%first(ia) + n_mol(ia), r) = off(:, :, src + 1:src + n_mol(ia))
+                do k = 1, n_mol(ia)
+                    F%mol(1:3, F%first(ia) + k, r) = com(:, src + k)
+                    F%mol(4:, F%first(ia) + k, r) = reshape(off(:, :, src + k), [3 * max_n1])
+                end do
                 F%cnt(ia, r) = n_mol(ia)
             end do
             src = src + n_mol(ia)
@@ -209,9 +211,12 @@ contains
         F%rng_kind = rng_kind
         F%n_threads = max(1, int(n_threads))
         call seed_farm_rng(int(seed))
-        ! two groups of replicas, one per engine lane (a single group if there is one replica)
-        per = (n_replicas + MGPU_LANES - 1) / MGPU_LANES
-        do g = 0, MGPU_LANES - 1
+        ! n_lanes groups of replicas, one per engine lane (<= 0: the default of two)
+        F%n_lanes = n_lanes
+        if (n_lanes <= 0) F%n_lanes = 2
+        F%n_lanes = max(1, min(F%n_lanes, int(MGPU_LANES), int(n_replicas)))
+        per = (n_replicas + F%n_lanes - 1) / F%n_lanes
+        do g = 0, F%n_lanes - 1
             F%lane(g)%first = min(g * per, n_replicas)
             F%lane(g)%n = max(0, min(per, n_replicas - g * per))
             F%lane(g)%nc = 0
@@ -259,7 +264,7 @@ contains
     subroutine mfarm_destroy() bind(C, name="mfarm_destroy")
         integer :: g
         if (allocated(F%res_type)) deallocate(F%res_type, F%n1, F%cap, F%first, F%cnt, F%fugacity)
-        if (allocated(F%com)) deallocate(F%com, F%off, F%energy)
+        if (allocated(F%mol)) deallocate(F%mol, F%energy)
         do g = 0, MGPU_LANES - 1
             if (allocated(F%lane(g)%rep)) then
                 deallocate(F%lane(g)%rep, F%lane(g)%t, F%lane(g)%m, F%lane(g)%kind, F%lane(g)%accept, &
@@ -364,26 +369,22 @@ contains
         end do
         L%nc = j
         F%skipped = F%skipped + skipped
-        ! pass 1: gather com / offsets from the host mirror.  Kept free of arithmetic so the
-        ! out-of-order cores overlap the cache misses of independent chains.
-        !$omp parallel do num_threads(F%n_threads) schedule(static) private(r, ia, slot)
+        call system_clock(c4)
+        F%ticks(6) = F%ticks(6) + (c3 - c0)
+        F%ticks(7) = F%ticks(7) + (c4 - c3)
+        ! pass 1 (one parallel region per lane and step: the fork/join is not free): gather com /
+        ! offsets from the host mirror -- one contiguous record, the random access is DRAM/TLB-latency
+        ! bound and the threads overlap the misses -- then build the move
+        !$omp parallel do num_threads(F%n_threads) schedule(static) private(i, n1, d, x, axis, a, r, ia, slot)
         do j = 1, L%nc
+            i = L%cidx(j)
             r = L%rep(j) + 1
             ia = L%ia(j)
             slot = L%m(j) + 1
             if (L%move(j) == MV_CREATION) slot = 1          ! geometry of molecule 1, create_molecule.f90:197-199
-            L%new_com(:, j) = F%com(:, F%first(ia) + slot, r)
-            L%new_off(:, :, j) = F%off(:, :, F%first(ia) + slot, r)
-        end do
-        !$omp end parallel do
-        call system_clock(c4)
-        F%ticks(6) = F%ticks(6) + (c3 - c0)
-        F%ticks(7) = F%ticks(7) + (c4 - c3)
-        ! pass 2: the moves themselves
-        !$omp parallel do num_threads(F%n_threads) schedule(static) private(i, n1, d, x, axis, a)
-        do j = 1, L%nc
-            i = L%cidx(j)
-            n1 = F%n1(L%ia(j))
+            L%new_com(:, j) = F%mol(1:3, F%first(ia) + slot, r)
+            L%new_off(:, :, j) = reshape(F%mol(4:, F%first(ia) + slot, r), [3, F%max_n1])
+            n1 = F%n1(ia)
             select case (L%move(j))
             case (MV_TRANSLATION)
                 ! translation.f90:104-110: rand_symmetric(3)*translation_step, then ApplyPBC
@@ -496,19 +497,18 @@ contains
                 slot = L%m(j) + 1
                 select case (L%move(j))
                 case (MV_CREATION)
-                    F%com(:, base + slot, r) = L%new_com(:, j)
-                    F%off(:, 1:n1, base + slot, r) = L%new_off(:, 1:n1, j)
+                    F%mol(1:3, base + slot, r) = L%new_com(:, j)
+                    F%mol(4:, base + slot, r) = reshape(L%new_off(:, :, j), [3 * F%max_n1])
                     F%cnt(ia, r) = F%cnt(ia, r) + 1
                     k_c = k_c + 1
                 case (MV_DELETION)
                     last = F%cnt(ia, r)                                    ! RemoveMolecule, delete_molecule.f90:107-114
-                    F%com(:, base + slot, r) = F%com(:, base + last, r)
-                    F%off(:, :, base + slot, r) = F%off(:, :, base + last, r)
+                    F%mol(:, base + slot, r) = F%mol(:, base + last, r)
                     F%cnt(ia, r) = last - 1
                     k_d = k_d + 1
                 case default
-                    F%com(:, base + slot, r) = L%new_com(:, j)
-                    F%off(:, 1:n1, base + slot, r) = L%new_off(:, 1:n1, j)
+                    F%mol(1:3, base + slot, r) = L%new_com(:, j)
+                    F%mol(4:, base + slot, r) = reshape(L%new_off(:, :, j), [3 * F%max_n1])
                     if (L%move(j) == MV_TRANSLATION) then
                         k_t = k_t + 1
                     else
@@ -552,12 +552,12 @@ contains
             return
         end if
         if (n_steps > 0) then
-            do g = 0, MGPU_LANES - 1
+            do g = 0, F%n_lanes - 1
                 rc = generate_and_submit(g)
                 if (rc /= MGPU_OK) return
             end do
             do step = 1, n_steps
-                do g = 0, MGPU_LANES - 1
+                do g = 0, F%n_lanes - 1
                     rc = resolve_and_commit(g)
                     if (rc /= MGPU_OK) return
                     if (step < n_steps) then
@@ -631,8 +631,8 @@ contains
     subroutine mfarm_get_molecule(replica, ia, slot, com, off) bind(C, name="mfarm_get_molecule")
         integer(c_int), value :: replica, ia, slot
         real(c_double), intent(out) :: com(3), off(3, F%max_n1)
-        com = F%com(:, F%first(ia + 1) + slot + 1, replica + 1)
-        off = F%off(:, :, F%first(ia + 1) + slot + 1, replica + 1)
+        com = F%mol(1:3, F%first(ia + 1) + slot + 1, replica + 1)
+        off = reshape(F%mol(4:, F%first(ia + 1) + slot + 1, replica + 1), [3, F%max_n1])
     end subroutine mfarm_get_molecule
 
 end module mc_farm

@@ -66,7 +66,8 @@ class FortranFarm:
 
     def __init__(self, system: System, n_replicas: int, device: int = 0, seed: int = 1,
                  translation_step: float = 0.3, rotation_step: float = 0.3, p_translation: float = 0.5,
-                 rng_kind: int = 1, n_threads: int = 8, mol_capacity=None, gcmc=None):
+                 rng_kind: int = 1, n_threads: int = 8, mol_capacity=None, gcmc=None,
+                 n_lanes: int = 2):
         self.H = lib()
         if system.is_triclinic():
             raise NotImplementedError("the Fortran farm generates moves for cubic / orthorhombic boxes only "
@@ -108,9 +109,10 @@ class FortranFarm:
                                  energy0.ctypes.data_as(_dp), lo.ctypes.data_as(_dp), length.ctypes.data_as(_dp),
                                  C.c_double(system.temperature), C.c_double(translation_step),
                                  C.c_double(rotation_step), C.c_double(p_translation), C.c_int(seed),
-                                 C.c_int(rng_kind), C.c_int(n_threads))
+                                 C.c_int(rng_kind), C.c_int(n_threads), C.c_int(n_lanes))
         _lib.check(rc)
         self.max_n1 = max_n1
+        self.n_lanes = max(1, min(int(n_lanes) if n_lanes > 0 else 2, 4, self.R))
         self.n_active = len(active)
         self.stats = np.zeros(3)
         if gcmc is not None:
