@@ -38,7 +38,7 @@ constexpr int kSiteChunk = 32;    // candidate sites staged in LDS per pass (gen
 #ifndef MGPU_PAIR_MINWAVES
 #define MGPU_PAIR_MINWAVES 4   // <= 128 VGPRs: two 8-wave workgroups per CU (measured best, tools/bench_kernels.py)
 #endif
-constexpr int kPairBlock = MGPU_PAIR_BLOCK;   // pair sweep: persistent waves share one LDS erfc table
+constexpr int kPairBlock = MGPU_PAIR_BLOCK;   // pair sweep: persistent waves share one LDS Coulomb table
 constexpr int kPairWaves = kPairBlock / 64;
 constexpr int kMaxTypes = 16;     // atom types (LDS pair table 16 x 16 x 16 B = 4 KiB)
 
@@ -202,7 +202,7 @@ __device__ __forceinline__ void pair_term(double dx, double dy, double dz, const
 //
 // Work unit = (item, split): ONE WAVE sweeps every nsplit-th unit of 64 atoms of the item's
 // replica and writes one partial {e_lj, e_coul}.  Waves are persistent: the grid is sized to the
-// chip and each wave strides over the n_items * nsplit work units, so the 24 KiB erfc table is
+// chip and each wave strides over the n_items * nsplit work units, so the ~30 KiB Coulomb table is
 // staged into LDS once per workgroup and no workgroup barrier sits inside the sweep.
 // NS > 0: every item has exactly NS sites, held in registers; NS = 0: any count, staged through a
 // per-wave LDS slab in chunks of kSiteChunk.  ORDERED selects SingleMolPairwiseEnergy semantics
