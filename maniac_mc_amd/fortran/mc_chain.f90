@@ -1,0 +1,658 @@
+!===============================================================================
+! mc_chain -- ONE Markov chain driven exactly like the reference's MonteCarloLoop, with the engine
+! behind the reference-named seams of module maniac_gpu (the B = 1 drop-in of INTEGRATION.md).
+!
+! The control flow, the bookkeeping and -- deliberately -- the ORDER in which random numbers are drawn
+! follow the reference statement by statement, so that with the same seed (seed_rng rule,
+! src/random_utils.f90:35-56) and the same Fortran runtime the chain visits the same states as the
+! reference and writes the same files:
+!   MonteCarloLoop                    src/monte_carlo.f90:26-88
+!   PickRandomResidueType / PickRandomMoleculeIndex   src/monte_carlo_utils.f90:136-182
+!   Translation / RandomTranslation   src/translation.f90:36-112
+!   Rotation / ApplyRandomRotation / ChooseRotationAngle   src/rotation.f90:34-75,
+!                                     src/monte_carlo_utils.f90:30-92
+!   CreateMolecule / InsertAndOrientMolecule / Accept / Reject   src/create_molecule.f90:41-207
+!   DeleteMolecule / RemoveMolecule / Accept / Reject            src/delete_molecule.f90:41-199
+!   ComputeOldEnergy / ComputeNewEnergy / AcceptMove             src/monte_carlo_utils.f90:275-422
+!   mc_acceptance_probability         src/monte_carlo_utils.f90:184-226
+!   AdjustMoveStepSizes               src/monte_carlo_utils.f90:99-130 (as written)
+!   ApplyPBC                          src/geometry_utils.f90:167-213
+! Differences from the reference, both deliberate (SURVEY F2 / F3): A(k) is initialised to S(k) by
+! ComputeSystemEnergy, and a deletion's new reciprocal energy removes the deleted molecule.
+! Energies are evaluated against the engine's resident state; nothing is saved or restored on
+! rejection (the reference's Save/RestoreSingleMolFourier have no counterpart).
+!===============================================================================
+module mc_chain
+
+    use, intrinsic :: iso_c_binding
+    use, intrinsic :: iso_fortran_env, only: real64
+    use maniac_gpu
+    use maniac_output
+
+    implicit none
+
+    private
+    public :: mchain_reset, mchain_set_box, mchain_set_residue, mchain_set_bonded, mchain_set_tables, &
+              mchain_set_moves, mchain_set_reservoir_box, mchain_set_reservoir_residue, mchain_run, &
+              mchain_get_energy, mchain_get_counters, mchain_get_counts, mchain_get_molecule, mchain_get_steps
+
+    real(real64), parameter :: PI = 3.14159265358979323846_real64, TWOPI = 2.0_real64 * PI
+    real(real64), parameter :: zero = 0.0_real64, one = 1.0_real64, half = 0.5_real64, three = 3.0_real64
+    ! src/parameters.f90:8, :14-21
+    integer, parameter :: NB_MAX_MOLECULE = 5000
+    real(real64), parameter :: TARGET_ACCEPTANCE = 0.40d0, TOL_ACCEPTANCE = 0.05d0
+    real(real64), parameter :: MIN_TRANSLATION_STEP = 1.0d-3, MAX_TRANSLATION_STEP = 3.0d0
+    real(real64), parameter :: MIN_ROTATION_ANGLE = 1.0d-3, MAX_ROTATION_ANGLE = 0.78d0
+    real(real64), parameter :: PROB_CREATE_DELETE = 0.5d0
+    integer, parameter :: MIN_TRIALS_FOR_RECALIBRATION = 500
+    integer, parameter :: TYPE_CREATION = 1, TYPE_DELETION = 2, TYPE_TRANSLATION = 3, TYPE_ROTATION = 4
+
+    type(chain_block), save, target :: S
+    integer, save :: status = 0          ! first engine error met (0 = none); the loop stops on it
+
+contains
+
+    ! rand_uniform / rand_symmetric (src/random_utils.f90:13-31)
+    function rand_uniform() result(v)
+        real(real64) :: v
+        call random_number(v)
+    end function rand_uniform
+
+    subroutine seed_rng(seed)
+        integer, intent(in) :: seed
+        integer :: n, i
+        integer, allocatable :: put(:)
+        call random_seed(size=n)
+        allocate(put(n))
+        put = seed + 37 * [(i - 1, i = 1, n)]
+        call random_seed(put=put)
+    end subroutine seed_rng
+
+    subroutine note(stat)
+        integer, intent(in) :: stat
+        if (stat /= 0 .and. status == 0) status = stat
+    end subroutine note
+
+    !---------------------------------------------------------------------------
+    ! Building the state (called from the host plumbing, in this order: reset, box, residues,
+    ! bonded tables, tables, moves, reservoir)
+    !---------------------------------------------------------------------------
+    subroutine mchain_reset(engine, n_res, n_atom_types, temperature) bind(C, name="mchain_reset")
+        type(c_ptr), value :: engine
+        integer(c_int), value :: n_res, n_atom_types
+        real(c_double), value :: temperature
+        call blank_chain(S)
+        S%engine = engine
+        S%n_res = n_res
+        S%n_atom_types = n_atom_types
+        S%temperature = temperature
+        allocate(S%res(n_res), S%rsv(n_res), S%masses(n_atom_types))
+        S%masses = zero
+        status = 0
+    end subroutine mchain_reset
+
+    subroutine blank_chain(c)
+        type(chain_block), intent(out) :: c            ! intent(out): every component back to its default
+        c%engine = c_null_ptr
+    end subroutine blank_chain
+
+    subroutine fill_box(b, matrix, reciprocal, lo, hi, tilt, is_triclinic, box_type, volume)
+        type(box_block), intent(out) :: b
+        real(c_double), intent(in) :: matrix(3, 3), reciprocal(3, 3), lo(3), hi(3), tilt(3), volume
+        integer(c_int), intent(in) :: is_triclinic, box_type
+        b%matrix = matrix
+        b%reciprocal = reciprocal
+        b%lo = lo
+        b%hi = hi
+        b%tilt = tilt
+        b%is_triclinic = is_triclinic /= 0
+        b%box_type = box_type
+        b%volume = volume
+        b%num_atoms = 0
+    end subroutine fill_box
+
+    ! matrix / reciprocal are the Fortran arrays box%matrix / box%reciprocal (column-major)
+    subroutine mchain_set_box(matrix, reciprocal, lo, hi, tilt, is_triclinic, box_type, volume) &
+            bind(C, name="mchain_set_box")
+        real(c_double), intent(in) :: matrix(3, 3), reciprocal(3, 3), lo(3), hi(3), tilt(3)
+        integer(c_int), value :: is_triclinic, box_type
+        real(c_double), value :: volume
+        call fill_box(S%box, matrix, reciprocal, lo, hi, tilt, is_triclinic, box_type, volume)
+    end subroutine mchain_set_box
+
+    subroutine mchain_set_reservoir_box(matrix, reciprocal, lo, hi, tilt, is_triclinic, box_type, volume, &
+                                        any_bonded) bind(C, name="mchain_set_reservoir_box")
+        real(c_double), intent(in) :: matrix(3, 3), reciprocal(3, 3), lo(3), hi(3), tilt(3)
+        integer(c_int), value :: is_triclinic, box_type
+        real(c_double), value :: volume
+        integer(c_int), intent(in) :: any_bonded(4)
+        call fill_box(S%rbox, matrix, reciprocal, lo, hi, tilt, is_triclinic, box_type, volume)
+        S%has_reservoir = .true.
+        S%any_bonded = any_bonded /= 0
+    end subroutine mchain_set_reservoir_box
+
+    subroutine fill_residue(r, n1, cap, count, com, off)
+        type(residue_block), intent(inout) :: r
+        integer, intent(in) :: n1, cap, count
+        real(c_double), intent(in) :: com(3, *), off(3, n1, *)
+        integer :: m
+        r%n1 = n1
+        r%cap = max(cap, count, 1)
+        r%count = count
+        if (allocated(r%com)) deallocate(r%com, r%off)
+        allocate(r%com(3, r%cap), r%off(3, n1, r%cap))
+        r%com = zero
+        r%off = zero
+        do m = 1, count
+            r%com(:, m) = com(:, m)
+            r%off(:, :, m) = off(:, :, m)
+        end do
+    end subroutine fill_residue
+
+    subroutine mchain_set_residue(t, name, n1, active, cap, count, atom_type, charge, com, off, fugacity) &
+            bind(C, name="mchain_set_residue")
+        integer(c_int), value :: t, n1, active, cap, count
+        character(kind=c_char), intent(in) :: name(*)
+        integer(c_int), intent(in) :: atom_type(n1)
+        real(c_double), intent(in) :: charge(n1), com(3, *), off(3, n1, *)
+        real(c_double), value :: fugacity
+        integer :: i
+        associate (r => S%res(t))
+            r%name = ''
+            do i = 1, 10
+                if (name(i) == c_null_char) exit
+                r%name(i:i) = name(i)
+            end do
+            r%active = active
+            r%atom_type = atom_type
+            r%charge = charge
+            r%fugacity = fugacity
+            call fill_residue(r, int(n1), int(cap), int(count), com, off)
+            S%box%num_atoms = S%box%num_atoms + count * n1
+        end associate
+    end subroutine mchain_set_residue
+
+    subroutine mchain_set_reservoir_residue(t, n1, cap, count, com, off) bind(C, name="mchain_set_reservoir_residue")
+        integer(c_int), value :: t, n1, cap, count
+        real(c_double), intent(in) :: com(3, *), off(3, n1, *)
+        call fill_residue(S%rsv(t), int(n1), int(cap), int(count), com, off)
+        S%rbox%num_atoms = S%rbox%num_atoms + count * n1
+    end subroutine mchain_set_reservoir_residue
+
+    ! kind 1 bonds, 2 angles, 3 dihedrals, 4 impropers; table(1, k) = type, table(2:, k) = local atom indices
+    subroutine mchain_set_bonded(t, kind, n, table) bind(C, name="mchain_set_bonded")
+        integer(c_int), value :: t, kind, n
+        integer(c_int), intent(in) :: table(5, *)
+        integer, allocatable :: grown(:, :, :)
+        integer :: k
+        associate (r => S%res(t))
+            if (.not. allocated(r%bonded)) then
+                allocate(r%bonded(5, max(1, n), 4))
+                r%bonded = 0
+            else if (size(r%bonded, 2) < n) then
+                allocate(grown(5, n, 4))
+                grown = 0
+                grown(:, 1:size(r%bonded, 2), :) = r%bonded
+                call move_alloc(grown, r%bonded)
+            end if
+            r%n_bonded(kind) = n
+            do k = 1, n
+                r%bonded(:, k, kind) = table(:, k)
+            end do
+        end associate
+    end subroutine mchain_set_bonded
+
+    subroutine mchain_set_tables(masses, n_bonded_types) bind(C, name="mchain_set_tables")
+        real(c_double), intent(in) :: masses(*)
+        integer(c_int), intent(in) :: n_bonded_types(4)
+        S%masses = masses(1:S%n_atom_types)
+        S%n_bonded_types = n_bonded_types
+    end subroutine mchain_set_tables
+
+    subroutine mchain_set_moves(translation_step, rotation_step, p_translation, p_rotation, recalibrate) &
+            bind(C, name="mchain_set_moves")
+        real(c_double), value :: translation_step, rotation_step, p_translation, p_rotation
+        integer(c_int), value :: recalibrate
+        S%translation_step = translation_step
+        S%rotation_step = rotation_step
+        S%p_translation = p_translation
+        S%p_rotation = p_rotation
+        S%recalibrate = recalibrate /= 0
+    end subroutine mchain_set_moves
+
+    !---------------------------------------------------------------------------
+    ! Geometry helpers
+    !---------------------------------------------------------------------------
+    subroutine apply_pbc(pos, box)
+        real(real64), intent(inout) :: pos(3)
+        type(box_block), intent(in) :: box
+        real(real64) :: frac(3)
+        integer :: d
+        if (.not. box%is_triclinic) then
+            do d = 1, 3
+                pos(d) = box%lo(d) + modulo(pos(d) - box%lo(d), box%matrix(d, d))
+            end do
+        else
+            frac = matmul(box%reciprocal, pos - box%lo)
+            do d = 1, 3
+                frac(d) = modulo(frac(d), one)
+            end do
+            pos = box%lo + matmul(box%matrix, frac)
+        end if
+    end subroutine apply_pbc
+
+    ! RotationMatrix (src/helper_utils.f90:39-77)
+    function axis_rotation(axis, theta) result(r)
+        integer, intent(in) :: axis
+        real(real64), intent(in) :: theta
+        real(real64) :: r(3, 3), c, sn
+        integer :: p, q
+        c = cos(theta)
+        sn = sin(theta)
+        r = zero
+        r(1, 1) = one; r(2, 2) = one; r(3, 3) = one
+        ! the plane (p, q) the axis leaves invariant: x -> (2,3), y -> (3,1), z -> (1,2)
+        p = mod(axis, 3) + 1
+        q = mod(axis + 1, 3) + 1
+        if (axis >= 1 .and. axis <= 3) then
+            r(p, p) = c; r(p, q) = -sn
+            r(q, p) = sn; r(q, q) = c
+        end if
+    end function axis_rotation
+
+    ! ApplyRandomRotation: the angle is drawn before the axis
+    subroutine random_rotation(t, m, full)
+        integer, intent(in) :: t, m
+        logical, intent(in) :: full
+        real(real64) :: theta, rot(3, 3)
+        integer :: axis, n1
+        n1 = S%res(t)%n1
+        if (n1 == 1) return
+        if (full) then
+            theta = rand_uniform() * TWOPI
+        else
+            theta = (rand_uniform() - half) * S%rotation_step
+        end if
+        axis = int(rand_uniform() * three) + 1
+        rot = axis_rotation(axis, theta)
+        S%res(t)%off(:, 1:n1, m) = matmul(rot, S%res(t)%off(:, 1:n1, m))
+    end subroutine random_rotation
+
+    !---------------------------------------------------------------------------
+    ! Energies of one molecule: e = non_coulomb, coulomb, recip, self, intra, total
+    !---------------------------------------------------------------------------
+    subroutine molecule_energy(t, m, e, creation, deletion, is_new)
+        integer, intent(in) :: t, m
+        real(real64), intent(out) :: e(6)
+        logical, intent(in) :: creation, deletion, is_new
+        integer :: n1, stat, exclude
+        n1 = S%res(t)%n1
+        e = zero
+        if (creation .and. .not. is_new) then
+            e(IE_RECIP) = S%energy(IE_RECIP)                              ! ComputeOldEnergy, creation branch
+        else if (deletion .and. is_new) then
+            ! ComputeNewEnergy, deletion branch: only the reciprocal energy of the system without the
+            ! molecule (the engine still holds it in slot m)
+            call ComputeRecipEnergySingleMol(S%engine, t, m, S%res(t)%com(:, m), S%res(t)%off(:, 1:n1, m), n1, &
+                                             e(IE_RECIP), is_deletion=.true., stat=stat)
+            call note(stat)
+        else
+            if (creation) then
+                call ComputeRecipEnergySingleMol(S%engine, t, m, S%res(t)%com(:, m), S%res(t)%off(:, 1:n1, m), n1, &
+                                                 e(IE_RECIP), is_creation=.true., stat=stat)
+            else if (deletion) then
+                e(IE_RECIP) = S%energy(IE_RECIP)                          ! ComputeOldEnergy, deletion branch
+                stat = 0
+            else
+                call ComputeRecipEnergySingleMol(S%engine, t, m, S%res(t)%com(:, m), S%res(t)%off(:, 1:n1, m), n1, &
+                                                 e(IE_RECIP), stat=stat)
+            end if
+            call note(stat)
+            exclude = m
+            if (creation) exclude = 0                                   ! the engine does not hold the molecule yet
+            call ComputePairInteractionEnergy_singlemol(S%engine, t, exclude, S%res(t)%com(:, m), &
+                                                        S%res(t)%off(:, 1:n1, m), n1, e(IE_NONC), e(IE_COUL), stat=stat)
+            call note(stat)
+            if (creation .or. deletion) then
+                call ComputeEwaldSelfInteractionSingleMol(S%engine, t, e(IE_SELF), stat=stat)
+                call note(stat)
+                call ComputeIntraResidueRealCoulombEnergySingleMol(S%engine, t, m, S%res(t)%com(:, m), &
+                                                                   S%res(t)%off(:, 1:n1, m), n1, e(IE_INTRA), stat=stat)
+                call note(stat)
+            end if
+        end if
+        if (creation .or. deletion) then
+            e(IE_TOTAL) = e(IE_NONC) + e(IE_COUL) + e(IE_RECIP) + e(IE_SELF) + e(IE_INTRA)
+        else
+            e(IE_TOTAL) = e(IE_NONC) + e(IE_COUL) + e(IE_RECIP)
+        end if
+    end subroutine molecule_energy
+
+    function acceptance_probability(old, new, t, move_type) result(p)
+        real(real64), intent(in) :: old(6), new(6)
+        integer, intent(in) :: t, move_type
+        real(real64) :: p, n, v, phi, temp, delta_e
+        n = real(S%res(t)%count)
+        v = S%box%volume
+        phi = S%res(t)%fugacity
+        temp = S%temperature
+        delta_e = new(IE_TOTAL) - old(IE_TOTAL)
+        select case (move_type)
+        case (TYPE_CREATION)
+            p = min(one, (phi * v / n) * exp(-delta_e / temp))
+        case (TYPE_DELETION)
+            p = min(one, ((n + one) / (phi * v)) * exp(-delta_e / temp))
+        case default
+            p = min(one, exp(-delta_e / temp))
+        end select
+    end function acceptance_probability
+
+    ! AcceptMove: running energies, then the engine applies the move
+    subroutine accept_move(t, m, old, new, which)
+        integer, intent(in) :: t, m, which
+        real(real64), intent(in) :: old(6), new(6)
+        integer :: stat, n1
+        S%energy(IE_RECIP) = S%energy(IE_RECIP) + new(IE_RECIP) - old(IE_RECIP)
+        S%energy(IE_NONC) = S%energy(IE_NONC) + new(IE_NONC) - old(IE_NONC)
+        S%energy(IE_COUL) = S%energy(IE_COUL) + new(IE_COUL) - old(IE_COUL)
+        S%energy(IE_TOTAL) = S%energy(IE_TOTAL) + new(IE_TOTAL) - old(IE_TOTAL)
+        S%counter(which) = S%counter(which) + 1
+        n1 = S%res(t)%n1
+        call GpuAcceptMove(S%engine, t, m, MGPU_MOVE, S%res(t)%com(:, m), S%res(t)%off(:, 1:n1, m), n1, stat=stat)
+        call note(stat)
+    end subroutine accept_move
+
+    subroutine translation(t, m)
+        integer, intent(in) :: t, m
+        real(real64) :: com_old(3), old(6), new(6), trial(3), p
+        if (m == 0) return
+        S%counter(C_TRIAL_T) = S%counter(C_TRIAL_T) + 1
+        com_old = S%res(t)%com(:, m)
+        call molecule_energy(t, m, old, .false., .false., .false.)
+        call random_number(trial)
+        trial = (trial - half) * S%translation_step
+        S%res(t)%com(:, m) = S%res(t)%com(:, m) + trial
+        call apply_pbc(S%res(t)%com(:, m), S%box)
+        call molecule_energy(t, m, new, .false., .false., .true.)
+        p = acceptance_probability(old, new, t, TYPE_TRANSLATION)
+        if (rand_uniform() <= p) then
+            call accept_move(t, m, old, new, C_T)
+        else
+            S%res(t)%com(:, m) = com_old
+        end if
+    end subroutine translation
+
+    subroutine rotation(t, m)
+        integer, intent(in) :: t, m
+        real(real64) :: old(6), new(6), p
+        real(real64), allocatable :: off_old(:, :)
+        if (S%res(t)%n1 == 1 .or. m == 0) return
+        S%counter(C_TRIAL_R) = S%counter(C_TRIAL_R) + 1
+        off_old = S%res(t)%off(:, :, m)
+        call molecule_energy(t, m, old, .false., .false., .false.)
+        call random_rotation(t, m, .false.)
+        call molecule_energy(t, m, new, .false., .false., .true.)
+        p = acceptance_probability(old, new, t, TYPE_ROTATION)
+        if (rand_uniform() <= p) then
+            call accept_move(t, m, old, new, C_R)
+        else
+            S%res(t)%off(:, :, m) = off_old
+        end if
+    end subroutine rotation
+
+    subroutine create_molecule(t, m)
+        integer, intent(in) :: t, m
+        real(real64) :: old(6), new(6), p, trial(3), u
+        integer :: n1, pick, last, stat
+        n1 = S%res(t)%n1
+        if (m > NB_MAX_MOLECULE .or. m > S%res(t)%cap) then            ! CheckMoleculeIndex aborts the reference here
+            call note(4)
+            return
+        end if
+        S%counter(C_TRIAL_C) = S%counter(C_TRIAL_C) + 1
+        call molecule_energy(t, m, old, .true., .false., .false.)
+        S%res(t)%count = S%res(t)%count + 1
+        S%box%num_atoms = S%box%num_atoms + n1
+        ! InsertAndOrientMolecule
+        call random_number(trial)
+        S%res(t)%com(:, m) = S%box%lo + matmul(S%box%matrix, trial)
+        pick = 0
+        if (S%has_reservoir) then
+            call random_number(u)
+            pick = int(u * S%rsv(t)%count) + 1
+            S%res(t)%off(:, 1:n1, m) = S%rsv(t)%off(:, 1:n1, pick)
+        else
+            S%res(t)%off(:, 1:n1, m) = S%res(t)%off(:, 1:n1, 1)
+            call random_rotation(t, m, .true.)
+        end if
+        call molecule_energy(t, m, new, .true., .false., .true.)
+        p = acceptance_probability(old, new, t, TYPE_CREATION)
+        if (rand_uniform() <= p) then
+            S%energy(IE_RECIP) = new(IE_RECIP)
+            S%energy(IE_NONC) = S%energy(IE_NONC) + new(IE_NONC) - old(IE_NONC)
+            S%energy(IE_COUL) = S%energy(IE_COUL) + new(IE_COUL) - old(IE_COUL)
+            S%energy(IE_SELF) = S%energy(IE_SELF) + new(IE_SELF) - old(IE_SELF)
+            S%energy(IE_INTRA) = S%energy(IE_INTRA) + new(IE_INTRA) - old(IE_INTRA)
+            S%energy(IE_TOTAL) = S%energy(IE_TOTAL) + new(IE_TOTAL) - old(IE_TOTAL)
+            S%counter(C_C) = S%counter(C_C) + 1
+            call GpuAcceptMove(S%engine, t, m, MGPU_CREATION, S%res(t)%com(:, m), S%res(t)%off(:, 1:n1, m), n1, stat=stat)
+            call note(stat)
+            if (S%has_reservoir) then
+                ! the copied molecule leaves the reservoir: its slot takes the reservoir's last molecule
+                last = S%rsv(t)%count
+                S%rsv(t)%com(:, pick) = S%rsv(t)%com(:, last)
+                S%rsv(t)%off(:, 1:n1, pick) = S%rsv(t)%off(:, 1:n1, last)
+                S%rsv(t)%count = S%rsv(t)%count - 1
+                S%rbox%num_atoms = S%rbox%num_atoms - n1
+            end if
+        else
+            S%box%num_atoms = S%box%num_atoms - n1
+            S%res(t)%count = S%res(t)%count - 1
+        end if
+    end subroutine create_molecule
+
+    subroutine delete_molecule(t, m)
+        integer, intent(in) :: t, m
+        real(real64) :: old(6), new(6), p, trial(3), com_old(3)
+        real(real64), allocatable :: off_old(:, :), off_last(:, :)
+        integer :: n1, last, stat
+        if (S%res(t)%count == 0) return
+        n1 = S%res(t)%n1
+        S%counter(C_TRIAL_D) = S%counter(C_TRIAL_D) + 1
+        call molecule_energy(t, m, old, .false., .true., .false.)
+        com_old = S%res(t)%com(:, m)
+        off_old = S%res(t)%off(:, :, m)
+        last = S%res(t)%count
+        ! the engine evaluates the removal of the molecule that sits in slot m, so the new energy is
+        ! taken before the host mirror is compacted (RemoveMolecule in the reference comes first)
+        call molecule_energy(t, m, new, .false., .true., .true.)
+        off_last = S%res(t)%off(:, :, last)
+        S%res(t)%com(:, m) = S%res(t)%com(:, last)
+        S%res(t)%off(:, :, m) = S%res(t)%off(:, :, last)
+        S%res(t)%count = S%res(t)%count - 1
+        S%box%num_atoms = S%box%num_atoms - n1
+        p = acceptance_probability(old, new, t, TYPE_DELETION)
+        if (rand_uniform() <= p) then
+            S%energy(IE_RECIP) = new(IE_RECIP)
+            S%energy(IE_NONC) = S%energy(IE_NONC) + new(IE_NONC) - old(IE_NONC)
+            S%energy(IE_COUL) = S%energy(IE_COUL) + new(IE_COUL) - old(IE_COUL)
+            S%energy(IE_SELF) = S%energy(IE_SELF) + new(IE_SELF) - old(IE_SELF)
+            S%energy(IE_INTRA) = S%energy(IE_INTRA) + new(IE_INTRA) - old(IE_INTRA)
+            S%energy(IE_TOTAL) = S%energy(IE_TOTAL) + new(IE_TOTAL) - old(IE_TOTAL)
+            S%counter(C_D) = S%counter(C_D) + 1
+            call GpuAcceptMove(S%engine, t, m, MGPU_DELETION, com_old, off_old(:, 1:n1), n1, stat=stat)
+            call note(stat)
+            if (S%has_reservoir) then
+                ! the reservoir receives the geometry stored in the primary box's last slot, at a random place
+                call random_number(trial)
+                trial = trial - half
+                associate (r => S%rsv(t))
+                    if (r%count + 1 <= r%cap) then
+                        r%com(:, r%count + 1) = trial(1) * S%rbox%matrix(:, 1) + trial(2) * S%rbox%matrix(:, 2) + &
+                                                trial(3) * S%rbox%matrix(:, 3)
+                        r%off(:, 1:n1, r%count + 1) = off_last(:, 1:n1)
+                        r%count = r%count + 1
+                        S%rbox%num_atoms = S%rbox%num_atoms + n1
+                    else
+                        call note(4)
+                    end if
+                end associate
+            end if
+        else
+            S%res(t)%count = S%res(t)%count + 1
+            S%box%num_atoms = S%box%num_atoms + n1
+            S%res(t)%com(:, m) = com_old
+            S%res(t)%off(:, :, m) = off_old
+        end if
+    end subroutine delete_molecule
+
+    ! AdjustMoveStepSizes, as written -- including the second branches that compare against +TOL and the
+    ! rotation step that is multiplied by 1.95 and clamped from above by MIN_ROTATION_ANGLE
+    subroutine adjust_move_step_sizes()
+        real(real64) :: acc
+        if (.not. S%recalibrate) return
+        if (S%counter(C_TRIAL_T) > MIN_TRIALS_FOR_RECALIBRATION) then
+            acc = real(S%counter(C_T)) / real(S%counter(C_TRIAL_T))
+            if (acc - TARGET_ACCEPTANCE > TOL_ACCEPTANCE) then
+                S%translation_step = min(S%translation_step * 1.05d0, MAX_TRANSLATION_STEP)
+            else if (acc - TARGET_ACCEPTANCE < TOL_ACCEPTANCE) then
+                S%translation_step = max(S%translation_step * 0.95d0, MIN_TRANSLATION_STEP)
+            end if
+        end if
+        if (S%counter(C_TRIAL_R) > MIN_TRIALS_FOR_RECALIBRATION) then
+            acc = real(S%counter(C_R)) / real(S%counter(C_TRIAL_R))
+            if (acc - TARGET_ACCEPTANCE > TOL_ACCEPTANCE) then
+                S%rotation_step = min(S%rotation_step * 1.05d0, MAX_ROTATION_ANGLE)
+            else if (acc - TARGET_ACCEPTANCE < TOL_ACCEPTANCE) then
+                S%rotation_step = min(S%rotation_step * 1.95d0, MIN_ROTATION_ANGLE)
+            end if
+        end if
+    end subroutine adjust_move_step_sizes
+
+    function pick_residue_type() result(t)
+        integer :: t, n_active, k, i
+        n_active = 0
+        do i = 1, S%n_res
+            if (S%res(i)%active == 1) n_active = n_active + 1
+        end do
+        t = 0
+        if (n_active == 0) return
+        k = int(rand_uniform() * n_active) + 1
+        do i = 1, S%n_res
+            if (S%res(i)%active == 1) then
+                k = k - 1
+                if (k == 0) then
+                    t = i
+                    return
+                end if
+            end if
+        end do
+    end function pick_residue_type
+
+    function pick_molecule_index(n) result(m)
+        integer, intent(in) :: n
+        integer :: m
+        if (n == 0) then
+            m = 0
+        else
+            m = int(rand_uniform() * n) + 1
+            if (m > n) m = n
+        end if
+    end function pick_molecule_index
+
+    !---------------------------------------------------------------------------
+    ! program MANIAC from ComputeSystemEnergy on (main.f90:26-33): initial energy, MonteCarloLoop,
+    ! FinalReport, with every output file.  outdir ends with '/'.  seed > 0 seeds the generator by the
+    ! reference's rule; seed <= 0 leaves it as it is.  Returns the first engine status met (0 = none).
+    !---------------------------------------------------------------------------
+    function mchain_run(nb_block, nb_step, seed, outdir) bind(C, name="mchain_run") result(rc)
+        integer(c_int), value :: nb_block, nb_step, seed
+        character(kind=c_char), intent(in) :: outdir(*)
+        integer(c_int) :: rc
+        integer :: i, t, m, stat, step
+        real(real64) :: draw, e6(6)
+
+        S%outdir = ''
+        do i = 1, len(S%outdir)
+            if (outdir(i) == c_null_char) exit
+            S%outdir(i:i) = outdir(i)
+        end do
+        S%nb_block = nb_block
+        S%nb_step = nb_step
+        S%counter = 0
+        open(unit=S%log_unit, file=trim(S%outdir) // 'log.maniac', status='replace')
+
+        call ComputeSystemEnergy(S%engine, e6, stat=stat)
+        call note(stat)
+        S%energy = e6
+        if (seed > 0) call seed_rng(int(seed))
+
+        S%current_block = 0
+        call log_start_mc(S)
+        call update_files(S, .false.)
+        do while (S%current_block < nb_block .and. status == 0)
+            S%current_block = S%current_block + 1
+            do step = 1, nb_step
+                t = pick_residue_type()
+                m = pick_molecule_index(S%res(t)%count)
+                draw = rand_uniform()
+                if (draw <= S%p_translation) then
+                    call translation(t, m)
+                else if (draw <= S%p_rotation + S%p_translation) then
+                    call rotation(t, m)
+                else
+                    if (rand_uniform() <= PROB_CREATE_DELETE) then
+                        m = S%res(t)%count + 1
+                        call create_molecule(t, m)
+                    else
+                        call delete_molecule(t, m)
+                    end if
+                end if
+                if (status /= 0) exit
+            end do
+            call adjust_move_step_sizes()
+            call log_status(S)
+            call update_files(S, .true.)
+        end do
+        ! a Fortran do variable ends one past its limit: FinalReport prints nb_block + 1
+        if (status == 0) S%current_block = nb_block + 1
+        call log_final_report(S)
+        close(S%log_unit)
+        rc = status
+    end function mchain_run
+
+    !---------------------------------------------------------------------------
+    ! Read-back for tests
+    !---------------------------------------------------------------------------
+    subroutine mchain_get_energy(e) bind(C, name="mchain_get_energy")
+        real(c_double), intent(out) :: e(6)
+        e = S%energy
+    end subroutine mchain_get_energy
+
+    subroutine mchain_get_counters(c) bind(C, name="mchain_get_counters")
+        integer(c_int), intent(out) :: c(8)
+        c = S%counter
+    end subroutine mchain_get_counters
+
+    subroutine mchain_get_counts(n) bind(C, name="mchain_get_counts")
+        integer(c_int), intent(out) :: n(*)
+        integer :: t
+        do t = 1, S%n_res
+            n(t) = S%res(t)%count
+        end do
+    end subroutine mchain_get_counts
+
+    subroutine mchain_get_steps(steps) bind(C, name="mchain_get_steps")
+        real(c_double), intent(out) :: steps(2)
+        steps(1) = S%translation_step
+        steps(2) = S%rotation_step
+    end subroutine mchain_get_steps
+
+    subroutine mchain_get_molecule(t, m, com, off) bind(C, name="mchain_get_molecule")
+        integer(c_int), value :: t, m
+        real(c_double), intent(out) :: com(3), off(3, *)
+        com = S%res(t)%com(:, m)
+        off(:, 1:S%res(t)%n1) = S%res(t)%off(:, :, m)
+    end subroutine mchain_get_molecule
+
+end module mc_chain

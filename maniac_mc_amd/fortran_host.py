@@ -18,7 +18,7 @@ from .system import System
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmaniac_host.so")
-FSRC = [os.path.join(_HERE, "fortran", f) for f in ("maniac_gpu.f90", "mc_farm.f90")]
+FSRC = [os.path.join(_HERE, "fortran", f) for f in ("maniac_gpu.f90", "mc_farm.f90", "maniac_output.f90", "mc_chain.f90")]
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)

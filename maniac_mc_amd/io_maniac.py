@@ -24,7 +24,7 @@ Several quirks of the reference are reproduced on purpose, because they decide t
   * site charges / types of a residue are those of the LAST molecule of that residue in the file;
   * epsilon / sigma are assigned by atom type, then unset pairs are filled by Lorentz-Berthelot.
 Fatal conditions raise ``ManiacInputError`` carrying the reference's stop code where it has one.
-Bonds / angles / dihedrals / impropers are validated for presence and line count only (the hot path
+Bonds / angles / dihedrals / impropers are parsed and matched per residue only for the data-file writer (the hot path
 never uses them).
 """
 from __future__ import annotations
@@ -369,13 +369,19 @@ def read_lammps_data(path, inp: ManiacInput):
         orig[k], typ[k] = vals_i[0], vals_i[2]
         q[k] = vals_f[0]
         xyz[k] = vals_f[1:4]
-    # bonded sections: presence and line count only (stop codes 24 / 25 in the reference)
+    # bonded sections (ReadLAMMPSBonds / Angles / Dihedrals / Impropers, data_parser.f90:673-1053): id, type, atom ids;
+    # a malformed section stops with codes 24 / 25 like the reference
+    bonded = {}
     for title, ncols in (("Bonds", 4), ("Angles", 5), ("Dihedrals", 6), ("Impropers", 6)):
         n = counts[title.lower()]
+        recs = []
         if n > 0:
             for toks in _section_lines(lines, title, n, ncols, 24, 25, title.lower()[:-1]):
-                if any(_read_int(t) is None for t in toks[:ncols]):
+                vals = [_read_int(t) for t in toks[:ncols]]
+                if any(v is None for v in vals):
                     raise ManiacInputError(f"Failed to parse {title.lower()[:-1]} line", 25)
+                recs.append(vals)
+        bonded[title.lower()] = recs
     # ---- SortAtomsByOriginalID (stable insertion sort on the original id)
     order = np.argsort(orig, kind="stable")
     orig, typ, q, xyz = orig[order], typ[order], q[order], xyz[order]
@@ -413,6 +419,34 @@ def read_lammps_data(path, inp: ManiacInput):
                 k += 1
         if n_mol[i] > NB_MAX_MOLECULE:
             raise ManiacInputError("The number of molecules exceeds the maximum allowed", 11)
+    # box%atom_ids(i, j): original ids of the LAST molecule detected for residue i (data_parser.f90:1249), which is
+    # what DetectBondPerResidue & co. (data_parser.f90:320-550) match the bonded records against
+    atom_ids = np.zeros((n_res, max_atom), dtype=np.int64)
+    for i, r in enumerate(inp.residues):
+        k = 0
+        while k < n_atoms:
+            if int(typ[k]) == pattern[i][0] and k + r.nb_atoms <= n_atoms:
+                atom_ids[i, : r.nb_atoms] = orig[k:k + r.nb_atoms]
+                k += r.nb_atoms
+            else:
+                k += 1
+    per_res = {}
+    for key, nat in (("bonds", 2), ("angles", 3), ("dihedrals", 4), ("impropers", 4)):
+        tables = []
+        for i, r in enumerate(inp.residues):
+            ids = [int(v) for v in atom_ids[i, : r.nb_atoms]]
+            rows_i = []
+            for rec in bonded[key]:
+                members = rec[2:2 + nat]
+                if all(a in ids for a in members):
+                    loc = [ids.index(a) + 1 for a in members]          # atomIndexInResidue: first match, 1-based
+                    if key == "bonds":
+                        loc = sorted(loc)                               # (min, max), data_parser.f90:361-367
+                    elif not (loc[0] < loc[-1]):
+                        loc = loc[::-1]                                 # reversed unless first < last (:414-422, :472-482)
+                    rows_i.append([rec[1]] + loc)
+            tables.append(rows_i)
+        per_res[key] = tables
     # box type and reciprocal as the reference computes them (geometry_utils.f90:68-154, :277-331)
     off_diag = [matrix[0, 1], matrix[0, 2], matrix[1, 0], matrix[1, 2], matrix[2, 0], matrix[2, 1]]
     if max(abs(v) for v in off_diag) > ERROR_TOL:
@@ -492,7 +526,9 @@ def read_lammps_data(path, inp: ManiacInput):
         off_all.append(np.array(offs).reshape(-1, r.nb_atoms, 3))
     return dict(n_atoms=n_atoms, n_atom_types=n_types, matrix=matrix, lo=lo, hi=hi, triclinic=triclinic,
                 box_type=box_type, atom_types=atom_types, charges=charges, n_mol=n_mol, com=com_all, off=off_all,
-                masses=masses)
+                masses=masses, tilt=tilt, atom_ids=atom_ids, bonded_per_residue=per_res,
+                type_counts={w: _header_count(lines, w[:-1] + " types") for w in ("bonds", "angles", "dihedrals", "impropers")},
+                bonded_counts=counts)
 
 
 # ---- .inc ---------------------------------------------------------------------------------------
@@ -537,8 +573,8 @@ def read_parameters(path, n_atom_types, present_types):
 
 # ---- everything ---------------------------------------------------------------------------------
 
-def load_system(maniac_path, data_path, inc_path):
-    """The reference's front end (main.f90:16-26) -> (System, ManiacInput)."""
+def load_system(maniac_path, data_path, inc_path, with_data=False):
+    """The reference's front end (main.f90:16-26) -> (System, ManiacInput) [, the parsed data-file dict]."""
     inp = read_maniac_input(maniac_path)
     dat = read_lammps_data(data_path, inp)
     present = sorted({int(t) for i, r in enumerate(inp.residues) for t in dat["atom_types"][i, : r.nb_atoms] if t > 0})
@@ -550,4 +586,85 @@ def load_system(maniac_path, data_path, inc_path):
     topo.atom_types[topo.atom_types == 0] = 0
     system = System(topo, dat["matrix"], dat["lo"], inp.real_space_cutoff, inp.ewald_tolerance, inp.temperature,
                     dat["com"], dat["off"], label="from_files")
+    if with_data:
+        return system, inp, dat
     return system, inp
+
+
+# ---- writing input files ------------------------------------------------------------------------
+
+def write_input_files(system: System, directory, *, nb_block, nb_step, translation_step, rotation_step_angle,
+                      translation_proba, rotation_proba, insertion_deletion_proba=0.0, fugacity_atm=None,
+                      recalibrate_moves=False, seed=None, atom_names=None, masses=None, stem="system"):
+    """Write `system` as the three files the reference reads (`.maniac`, LAMMPS `.data` atom_style full,
+    `.inc`); returns their paths.  Coordinates are printed with 17 significant digits, epsilon in
+    kcal/mol (the reference divides by KB_kcalmol when it reads them, parameters_parser.f90:89-98).
+    Residue types must already be ordered by their smallest atom type (SortResidues would reorder them).
+    """
+    import os
+    topo = system.topo
+    os.makedirs(directory, exist_ok=True)
+    n_res = topo.n_res
+    res_types = [[int(t) for t in topo.atom_types[i, : topo.atoms_in_res[i]]] for i in range(n_res)]
+    assert [min(r) for r in res_types] == sorted(min(r) for r in res_types), "order residues by smallest atom type"
+    names = list(topo.names) if topo.names else [f"res{i + 1}" for i in range(n_res)]
+    if fugacity_atm is None:
+        fugacity_atm = [1.0] * n_res
+    nt = topo.n_atom_types
+    if masses is None:
+        masses = [1.0] * nt
+    if atom_names is None:
+        atom_names = [f"A{t + 1}" for t in range(nt)]
+    p_maniac = os.path.join(directory, stem + ".maniac")
+    p_data = os.path.join(directory, stem + ".data")
+    p_inc = os.path.join(directory, stem + ".inc")
+    with open(p_maniac, "w") as f:
+        f.write("# generated input\n")
+        f.write(f"nb_block {int(nb_block)}\nnb_step {int(nb_step)}\ntemperature {float(system.temperature)!r}\n")
+        if seed is not None:
+            f.write(f"seed {int(seed)}\n")
+        f.write(f"ewald_tolerance {float(system.ewald_tolerance)!r}\nreal_space_cutoff {float(system.real_space_cutoff)!r}\n")
+        f.write(f"translation_step {float(translation_step)!r}\nrotation_step_angle {float(rotation_step_angle)!r}\n")
+        f.write(f"recalibrate_moves {'true' if recalibrate_moves else 'false'}\n")
+        f.write(f"translation_proba {float(translation_proba)!r}\nrotation_proba {float(rotation_proba)!r}\n")
+        f.write(f"insertion_deletion_proba {float(insertion_deletion_proba)!r}\n\n")
+        for i in range(n_res):
+            uniq = []
+            for t in res_types[i]:
+                if t not in uniq:
+                    uniq.append(t)
+            f.write("begin_residue\n")
+            f.write(f"  name {names[i]}\n  state {'actif' if topo.is_active[i] == 1 else 'inactif'}\n")
+            if topo.is_active[i] == 1:
+                f.write(f"  fugacity {float(fugacity_atm[i])!r}\n")
+            f.write("  types " + " ".join(str(t) for t in uniq) + "\n")
+            f.write("  names " + " ".join(atom_names[t - 1] for t in uniq) + "\n")
+            f.write(f"  nb-atoms {int(topo.atoms_in_res[i])}\n")
+            f.write("end_residue\n\n")
+    hi = system.bounds_lo + np.diag(system.box_matrix)
+    with open(p_data, "w") as f:
+        f.write("LAMMPS data file (atom_style full), generated\n\n")
+        f.write(f"{system.n_atoms} atoms\n{nt} atom types\n0 bonds\n0 bond types\n0 angles\n0 angle types\n")
+        f.write("0 dihedrals\n0 dihedral types\n0 impropers\n0 improper types\n\n")
+        for d, ax in enumerate("xyz"):
+            f.write(f"{float(system.bounds_lo[d])!r} {float(hi[d])!r} {ax}lo {ax}hi\n")
+        if system.is_triclinic():
+            m = system.box_matrix
+            f.write(f"{float(m[1, 0])!r} {float(m[2, 0])!r} {float(m[2, 1])!r} xy xz yz\n")
+        f.write("\nMasses\n\n")
+        for t in range(nt):
+            f.write(f"{t + 1} {float(masses[t])!r}\n")
+        f.write("\nAtoms\n\n")
+        atom_id = mol_id = 0
+        for i in range(n_res):
+            sites = system.all_sites(i)
+            for m in range(sites.shape[0]):
+                mol_id += 1
+                for a in range(int(topo.atoms_in_res[i])):
+                    atom_id += 1
+                    x, y, z = (float(v) for v in sites[m, a])
+                    f.write(f"{atom_id} {mol_id} {res_types[i][a]} {float(topo.charges[i, a])!r} {x!r} {y!r} {z!r}\n")
+    with open(p_inc, "w") as f:
+        for t in range(nt):
+            f.write(f"pair_coeff {t + 1} {t + 1} {float(topo.epsilon[t, t] * KB_KCALMOL)!r} {float(topo.sigma[t, t])!r}\n")
+    return p_maniac, p_data, p_inc

@@ -1,0 +1,126 @@
+"""One MANIAC run on the GPU engine: the reference's program flow (main.f90:16-33) for ONE chain.
+
+    run_simulation("input.maniac", "topology.data", "parameters.inc", "outputs/")
+
+reads the reference's three input files (io_maniac), creates the engine for one replica and hands
+the state to the Fortran chain driver (fortran/mc_chain.f90), which mirrors MonteCarloLoop move by
+move -- same random-number order -- and writes the reference's output files (fortran/
+maniac_output.f90): log.maniac (Monte Carlo part), energy.dat, number_<res>.dat, moves.dat,
+trajectory.lammpstrj, topology.data, and reservoir.lammpstrj when a reservoir topology is given
+(the reference's ``-r`` option, cli_utils.f90:60-63).  Python here is plumbing only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib, fortran_host, io_maniac
+from .engine import Engine, box_prepare
+from .system import NB_MAX_MOLECULE
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def _f(a):
+    """Fortran (column-major) view of a 2-D array as a flat double pointer."""
+    arr = np.asfortranarray(np.asarray(a, dtype=np.float64))
+    return arr, arr.ctypes.data_as(_dp)
+
+
+def _box_args(dat):
+    box_type, volume, reciprocal, _ = box_prepare(dat["matrix"])
+    m, mp = _f(dat["matrix"])
+    r, rp = _f(reciprocal)
+    lo = np.ascontiguousarray(dat["lo"], dtype=np.float64)
+    hi = np.ascontiguousarray(dat["hi"], dtype=np.float64)
+    tilt = np.ascontiguousarray(dat["tilt"], dtype=np.float64)
+    keep = (m, r, lo, hi, tilt)
+    return keep, (mp, rp, lo.ctypes.data_as(_dp), hi.ctypes.data_as(_dp), tilt.ctypes.data_as(_dp),
+                  C.c_int(1 if dat["triclinic"] else 0), C.c_int(box_type), C.c_double(volume))
+
+
+def _mol_arrays(com, off, n1):
+    """(n, 3) / (n, n1, 3) numpy -> the Fortran shapes com(3, n) / off(3, n1, n)."""
+    com = np.ascontiguousarray(np.asarray(com, dtype=np.float64).reshape(-1, 3))
+    off = np.ascontiguousarray(np.asarray(off, dtype=np.float64).reshape(-1, n1, 3))
+    return com, off
+
+
+def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoir_path=None, device=0,
+                   mol_capacity=None, nb_block=None, nb_step=None):
+    """Run the chain; returns a dict with the final energies (K), counters, molecule counts, step sizes.
+
+    ``seed``: None -> the input file's ``seed`` if present, else the generator is left unseeded
+    (as the reference leaves it when the input names a seed, input_parser.f90:597).
+    ``mol_capacity``: molecule slots per residue type (default: NB_MAX_MOLECULE for active types).
+    """
+    system, inp, dat = io_maniac.load_system(maniac_path, data_path, inc_path, with_data=True)
+    topo = system.topo
+    n_res = topo.n_res
+    if mol_capacity is None:
+        mol_capacity = [NB_MAX_MOLECULE if topo.is_active[t] == 1 else max(1, int(system.n_mol[t])) for t in range(n_res)]
+    eng = Engine.from_system(system, n_replicas=1, device=device, mol_capacity=mol_capacity)
+    H = fortran_host.lib()
+    H.mchain_run.restype = C.c_int
+    try:
+        H.mchain_reset(eng.h, C.c_int(n_res), C.c_int(topo.n_atom_types), C.c_double(system.temperature))
+        keep, args = _box_args(dat)
+        H.mchain_set_box(*args)
+        fug = inp.fugacity_per_A3()
+        hold = []
+        for t in range(n_res):
+            n1 = int(topo.atoms_in_res[t])
+            com, off = _mol_arrays(system.com[t], system.offsets[t], n1)
+            types = np.ascontiguousarray(topo.atom_types[t, :n1], dtype=np.int32)
+            q = np.ascontiguousarray(topo.charges[t, :n1], dtype=np.float64)
+            hold += [com, off, types, q]
+            H.mchain_set_residue(C.c_int(t + 1), inp.residues[t].name.encode(), C.c_int(n1), C.c_int(int(topo.is_active[t])),
+                                 C.c_int(int(mol_capacity[t])), C.c_int(com.shape[0]), types.ctypes.data_as(_ip),
+                                 q.ctypes.data_as(_dp), com.ctypes.data_as(_dp), off.ctypes.data_as(_dp),
+                                 C.c_double(float(fug[t])))
+            for kind, key in enumerate(("bonds", "angles", "dihedrals", "impropers"), start=1):
+                rows = dat["bonded_per_residue"][key][t]
+                tab = np.zeros((max(1, len(rows)), 5), dtype=np.int32)
+                for k, row in enumerate(rows):
+                    tab[k, : len(row)] = row
+                hold.append(tab)
+                H.mchain_set_bonded(C.c_int(t + 1), C.c_int(kind), C.c_int(len(rows)), tab.ctypes.data_as(_ip))
+        masses = np.ascontiguousarray(dat["masses"], dtype=np.float64)
+        ntypes = np.array([dat["type_counts"][k] for k in ("bonds", "angles", "dihedrals", "impropers")], dtype=np.int32)
+        H.mchain_set_tables(masses.ctypes.data_as(_dp), ntypes.ctypes.data_as(_ip))
+        H.mchain_set_moves(C.c_double(inp.translation_step), C.c_double(inp.rotation_step_angle),
+                           C.c_double(inp.translation_proba), C.c_double(inp.rotation_proba),
+                           C.c_int(1 if inp.recalibrate_moves else 0))
+        if reservoir_path:
+            rdat = io_maniac.read_lammps_data(reservoir_path, inp)
+            rkeep, rargs = _box_args(rdat)
+            any_bonded = np.array([1 if rdat["bonded_counts"][k] > 0 else 0
+                                   for k in ("bonds", "angles", "dihedrals", "impropers")], dtype=np.int32)
+            H.mchain_set_reservoir_box(*rargs, any_bonded.ctypes.data_as(_ip))
+            for t in range(n_res):
+                n1 = int(topo.atoms_in_res[t])
+                com, off = _mol_arrays(rdat["com"][t], rdat["off"][t], n1)
+                hold += [com, off]
+                H.mchain_set_reservoir_residue(C.c_int(t + 1), C.c_int(n1), C.c_int(NB_MAX_MOLECULE), C.c_int(com.shape[0]),
+                                               com.ctypes.data_as(_dp), off.ctypes.data_as(_dp))
+        if seed is None:
+            seed = inp.seed if inp.has_seed else 0
+        outdir = os.path.join(outdir, "")
+        os.makedirs(outdir, exist_ok=True)
+        rc = H.mchain_run(C.c_int(inp.nb_block if nb_block is None else nb_block),
+                          C.c_int(inp.nb_step if nb_step is None else nb_step), C.c_int(int(seed)), outdir.encode())
+        _lib.check(rc)
+        e = np.zeros(6); cnt = np.zeros(8, dtype=np.int32); nm = np.zeros(n_res, dtype=np.int32); st = np.zeros(2)
+        H.mchain_get_energy(e.ctypes.data_as(_dp))
+        H.mchain_get_counters(cnt.ctypes.data_as(_ip))
+        H.mchain_get_counts(nm.ctypes.data_as(_ip))
+        H.mchain_get_steps(st.ctypes.data_as(_dp))
+        e_final = eng.system_energy(0)
+    finally:
+        eng.close()
+    keys = ("non_coulomb", "coulomb", "recip_coulomb", "ewald_self", "intra_coulomb", "total")
+    return dict(energy=dict(zip(keys, e)), recomputed_energy=e_final, counters=cnt, n_mol=nm,
+                translation_step=st[0], rotation_step=st[1])

@@ -73,6 +73,12 @@ def main():
         kmax = np.zeros(3, np.int32); nk = C.c_int()
         L.ref_get_ewald(C.byref(alpha), C.byref(rc_), C.byref(tol), C.byref(scr), C.byref(fp), kmax.ctypes.data_as(_ip), C.byref(nk))
         d.update(alpha=alpha.value, rc_eff=rc_.value, tol_eff=tol.value, kmax=kmax, nk=nk.value)
+        for kind, key in ((1, "bonds"), (2, "angles"), (3, "dihedrals"), (4, "impropers")):
+            for t in range(n_res):
+                n = C.c_int(); ntyp = C.c_int(); tab = np.zeros((64, 5), np.int32)
+                L.ref_get_bonded(C.c_int(kind), C.c_int(t + 1), C.byref(n), tab.ctypes.data_as(_ip), C.byref(ntyp))
+                d[f"{key}_{t}"] = tab[: min(n.value, 64)].copy()
+                d[f"{key}_types"] = ntyp.value
         e6 = np.zeros(6)
         L.ref_system_energy(e6.ctypes.data_as(_dp))
         d["system_energy"] = e6

@@ -39,10 +39,14 @@ module ref_shim
     use input_parser
     use data_parser
     use parameters_parser
+    use tabulated_utils
+    use montecarlo_module
+    use random_utils
 
     implicit none
 
     logical, save :: is_setup = .false.
+    character(len=200), save :: pending_res_file = ''
 
 contains
 
@@ -546,7 +550,7 @@ contains
         data_file = cstr(data)
         inc_file = cstr(inc)
         output_path = cstr(outdir)
-        res_file = ''
+        res_file = pending_res_file
         call InitOutput()
         call ReadInput()
         if (stage > 1) then
@@ -568,6 +572,44 @@ contains
             end do
         end function cstr
     end function ref_load_files
+
+
+    !---------------------------------------------------------------------------
+    ! Reservoir topology (-r of the reference's command line, cli_utils.f90:60-63): call before
+    ! ref_load_files; an empty string means "no reservoir".
+    !---------------------------------------------------------------------------
+    subroutine ref_set_reservoir_file(path) bind(C, name="ref_set_reservoir_file")
+        character(kind=c_char), intent(in) :: path(*)
+        integer :: i
+        pending_res_file = ''
+        do i = 1, 200
+            if (path(i) == c_null_char) exit
+            pending_res_file(i:i) = path(i)
+        end do
+    end subroutine ref_set_reservoir_file
+
+    !---------------------------------------------------------------------------
+    ! The rest of program MANIAC (main.f90:26-33) after ref_load_files(stage = 2): PrecomputeTable,
+    ! ComputeSystemEnergy, MonteCarloLoop, FinalReport -- the reference's own loop, writers and log.
+    ! init_amplitude /= 0 sets A(k) <- S(k) first (the initialisation the reference omits, SURVEY
+    ! F2; without it the per-move reciprocal energies are computed from heap garbage).  seed > 0
+    ! re-seeds the intrinsic generator with the reference's own seed_rng (random_utils.f90:35-56);
+    ! the reference itself skips that call whenever the input gives a seed (input_parser.f90:597).
+    !---------------------------------------------------------------------------
+    function ref_run_mc(seed, init_amplitude) bind(C, name="ref_run_mc") result(rc)
+        integer(c_int), value :: seed, init_amplitude
+        integer(c_int) :: rc
+        rc = 1
+        if (.not. is_setup) return
+        call PrecomputeTable()
+        energy%ewald_self = zero
+        call ComputeSystemEnergy(primary)
+        if (init_amplitude /= 0) call ref_init_amplitude(1_c_int)
+        if (seed > 0) call seed_rng(int(seed))
+        call MonteCarloLoop()
+        call FinalReport()
+        rc = 0
+    end function ref_run_mc
 
     ! what ReadInput / ReadSystemData produced: sizes, then per-residue tables
     subroutine ref_get_sizes(n_res, max_atom, n_atom_types) bind(C, name="ref_get_sizes")
@@ -600,6 +642,38 @@ contains
         atom_types = primary%atom_types(t, :)
         charges = primary%atom_charges(t, :)
     end subroutine ref_get_template
+
+
+    ! bonded tables DetectBondPerResidue & co. built (data_parser.f90:320-550): kind 1 bonds (3 columns),
+    ! 2 angles (4), 3 dihedrals (5), 4 impropers (5); table(c, k) for k <= n; also the "<kind> types" header counts
+    subroutine ref_get_bonded(kind, t, n, table, n_types) bind(C, name="ref_get_bonded")
+        integer(c_int), value :: kind, t
+        integer(c_int), intent(out) :: n, table(5, 64), n_types
+        integer :: k
+        table = 0
+        select case (kind)
+        case (1)
+            n = nb%bonds_per_residue(t); n_types = primary%num_bondtypes
+            do k = 1, min(n, 64)
+                table(1:3, k) = res%bond_type_2d(t, k, 1:3)
+            end do
+        case (2)
+            n = nb%angles_per_residue(t); n_types = primary%num_angletypes
+            do k = 1, min(n, 64)
+                table(1:4, k) = res%angle_type_2d(t, k, 1:4)
+            end do
+        case (3)
+            n = nb%dihedrals_per_residue(t); n_types = primary%num_dihedraltypes
+            do k = 1, min(n, 64)
+                table(1:5, k) = res%dihedral_type_2d(t, k, 1:5)
+            end do
+        case default
+            n = nb%impropers_per_residue(t); n_types = primary%num_impropertypes
+            do k = 1, min(n, 64)
+                table(1:5, k) = res%improper_type_2d(t, k, 1:5)
+            end do
+        end select
+    end subroutine ref_get_bonded
 
     ! epsilon / sigma of a site pair (1-based), after ReadParameters + ApplyLorentzBerthelot
     subroutine ref_get_coeff(t1, a1, t2, a2, eps, sig) bind(C, name="ref_get_coeff")

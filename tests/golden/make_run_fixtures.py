@@ -1,0 +1,105 @@
+"""Whole-run fixtures: input files for small synthetic systems and the output files the REFERENCE writes
+for them (its own MonteCarloLoop, writers and log), run through oracle/_ref with A(k) initialised
+ and the generator seeded by the reference's seed_rng.
+
+    python tests/golden/make_run_fixtures.py
+
+Runs only where oracle/_ref exists (needs /root/reference + amdflang at build time).  Charged systems are
+run without insertion / deletion: the reference's deletion passes the wrong flag to its reciprocal
+update, so its charged GCMC trajectories are not the intended physics.
+Layout: tests/golden/runs/<case>/inputs/{system.maniac,system.data,system.inc[,reservoir.data]},
+        tests/golden/runs/<case>/expected/<the reference's output files>, log_mc.txt = log.maniac from the
+        "Started Monte Carlo Loop" box on, with the output path blanked.
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from maniac_mc_amd import io_maniac, synth  # noqa: E402
+from maniac_mc_amd.system import System, Topology  # noqa: E402
+
+RUNS = os.path.join(HERE, "runs")
+SEED = 20251017
+
+
+def dumbbell_box(n_mol=30, L=25.0, seed=5, rc=10.0, temperature=100.0, bond=1.10):
+    """Uncharged two-site Lennard-Jones dumbbells (N2-like textbook values, not from the reference)."""
+    rng = np.random.default_rng(seed)
+    eps, sig = synth.lorentz_berthelot([0.0725], [3.31])
+    topo = Topology(atoms_in_res=[2], atom_types=[[1, 1]], charges=[[0.0, 0.0]], is_active=[1], epsilon=eps, sigma=sig,
+                    names=["N2"])
+    com = synth._spread_points(rng, n_mol, L, min_sep=3.6)
+    rot = synth._random_rotations(rng, n_mol)
+    tmpl = np.array([[bond / 2, 0.0, 0.0], [-bond / 2, 0.0, 0.0]])
+    off = np.einsum("mij,aj->mai", rot, tmpl)
+    return System(topo, np.diag([L, L, L]), np.full(3, -L / 2), rc, 1e-5, temperature, [com], [off], label="dumbbell")
+
+
+def cases():
+    ar = synth.argon_box(n_cell=3, rc=8.0)
+    yield "argon_nvt", ar, dict(nb_block=4, nb_step=300, translation_step=0.5, rotation_step_angle=0.3,
+                                translation_proba=1.0, rotation_proba=0.0, recalibrate_moves=True,
+                                masses=[39.948], atom_names=["Ar"]), None
+    gas = synth.argon_box(n_cell=3, rho_star=0.3, rc=8.0, temperature=150.0)
+    yield "lj_gcmc", gas, dict(nb_block=5, nb_step=200, translation_step=1.0, rotation_step_angle=0.3,
+                               translation_proba=0.4, rotation_proba=0.0, insertion_deletion_proba=0.6,
+                               fugacity_atm=[30.0], recalibrate_moves=False, masses=[39.948], atom_names=["Ar"]), None
+    w = synth.spce_box(n_side=4, rc=6.0)
+    yield "spce_nvt", w, dict(nb_block=3, nb_step=200, translation_step=0.3, rotation_step_angle=0.3,
+                              translation_proba=0.5, rotation_proba=0.5, recalibrate_moves=False,
+                              masses=[15.9994, 1.008], atom_names=["OW", "HW"]), None
+    d = dumbbell_box()
+    kw = dict(nb_block=4, nb_step=300, translation_step=0.8, rotation_step_angle=0.5, translation_proba=0.3,
+              rotation_proba=0.3, insertion_deletion_proba=0.4, fugacity_atm=[20.0], recalibrate_moves=True,
+              masses=[14.0067], atom_names=["N"])
+    yield "dumbbell_gcmc", d, kw, None
+    yield "dumbbell_gcmc_reservoir", d, kw, dumbbell_box(n_mol=40, L=30.0, seed=9)
+
+
+def main():
+    if os.path.isdir(RUNS):
+        shutil.rmtree(RUNS)
+    summary = {}
+    for name, system, kw, reservoir in cases():
+        inputs = os.path.join(RUNS, name, "inputs")
+        expected = os.path.join(RUNS, name, "expected")
+        files = io_maniac.write_input_files(system, inputs, **kw)
+        args = list(files)
+        res_path = None
+        if reservoir is not None:
+            res_path = io_maniac.write_input_files(reservoir, inputs, stem="reservoir", **kw)[1]
+            for junk in ("reservoir.maniac", "reservoir.inc"):
+                os.remove(os.path.join(inputs, junk))
+        with tempfile.TemporaryDirectory() as tmp:
+            out = os.path.join(tmp, "out", "")
+            cmd = [sys.executable, os.path.join(ROOT, "oracle", "run_ref_mc.py"), *args, out, str(SEED)]
+            if res_path:
+                cmd.append(res_path)
+            p = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp)
+            assert "RUN_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+            os.makedirs(expected, exist_ok=True)
+            for f in sorted(os.listdir(out)):
+                if f == "log.maniac":
+                    lines = open(os.path.join(out, f)).read().split("\n")
+                    start = next(i for i, ln in enumerate(lines) if "Started Monte Carlo Loop" in ln) - 2
+                    tail = ["<output path>" if out.rstrip("/") in ln else ln for ln in lines[start:]]
+                    open(os.path.join(expected, "log_mc.txt"), "w").write("\n".join(tail))
+                else:
+                    shutil.copy(os.path.join(out, f), os.path.join(expected, f))
+        last = open(os.path.join(expected, "moves.dat")).read().strip().split("\n")[-1].split()
+        summary[name] = dict(seed=SEED, files=sorted(os.listdir(expected)), last_moves_record=last,
+                             reservoir=bool(reservoir))
+        print(name, last)
+    json.dump(summary, open(os.path.join(RUNS, "summary.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,14 @@ def test_good_data_files_match_reference_front_end(name, refcpu_mod):
     assert (P.alpha, P.nk, P.rc) == (float(g["alpha"]), int(g["nk"]), float(g["rc_eff"]))
     e = P.system_energy()
     assert np.array_equal(np.array([e[k] for k in E_KEYS]), g["system_energy"])
+    # bonded tables per residue (DetectBondPerResidue & co.), which only the data-file writer uses
+    _, _, dat = io_maniac.load_system(os.path.join(FIX, "input.maniac"), os.path.join(FIX, name + ".data"),
+                                      os.path.join(FIX, "parameters.inc"), with_data=True)
+    for key, ncol in (("bonds", 3), ("angles", 4), ("dihedrals", 5), ("impropers", 5)):
+        assert dat["type_counts"][key] == int(g[key + "_types"])
+        for t in range(topo.n_res):
+            mine = np.array(dat["bonded_per_residue"][key][t], dtype=np.int32).reshape(-1, ncol)
+            assert np.array_equal(mine, g[f"{key}_{t}"][:, :ncol]), (key, t)
 
 
 def test_reference_program_output_on_its_fixture():
