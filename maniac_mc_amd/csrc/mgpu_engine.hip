@@ -112,6 +112,9 @@ struct mgpu_engine {
     double2 *d_A = nullptr;       // [R][Nk]
     int *d_kpack = nullptr;
     double *d_kw = nullptr;
+    RecipTask *d_rtasks = nullptr;   // row form of the k list (recip_rows_kernel)
+    RecipRow *d_rrows = nullptr;
+    int n_rtasks = 0, n_rrows = 0;
     double2 *d_pair_tab = nullptr;
     char *d_coul_tab = nullptr;      // Coulomb table rows (build_coulomb_table), staged into LDS by the pair sweep
     size_t coul_bytes = 0;
@@ -286,10 +289,17 @@ size_t recip_lds_bytes(const mgpu_engine *e, int n1_max) {
     return (size_t)2 * n1_max * ktot * sizeof(double2) + (size_t)n1_max * sizeof(double);
 }
 
+size_t recip_rows_lds_bytes(const mgpu_engine *e, int n1_max) {
+    return recip_lds_bytes(e, n1_max) + (size_t)e->n_rrows * (2 * n1_max * sizeof(double2) + sizeof(RecipRow));
+}
+
 // d_u_old != nullptr: also return the energy of the unchanged A(k) from the same pass (trial moves)
 int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items, int n1_max, int site_stride,
                  bool commit, double2 *A_base, double *d_u, double *d_u_old = nullptr) {
-    const size_t lds = recip_lds_bytes(e, n1_max);
+    // row form while its XY table fits the LDS budget (molecules of a few sites), else the per-k form
+    static const bool force_per_k = getenv("MGPU_RECIP_PER_K") != nullptr;
+    const bool by_rows = !force_per_k && e->n_rtasks > 0 && recip_rows_lds_bytes(e, n1_max) <= 40 * 1024;
+    const size_t lds = by_rows ? recip_rows_lds_bytes(e, n1_max) : recip_lds_bytes(e, n1_max);
     if (lds > 64 * 1024)
         return set_error(MGPU_ERR_CAPACITY, "reciprocal update: molecule too large for the LDS phase tables (" +
                                                 std::to_string(lds) + " B > 64 KiB)");
@@ -298,9 +308,16 @@ int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items
     int rc = prof_begin(e, ln, slot, &a, &b);
     if (rc) return rc;
 #define MGPU_LAUNCH_RECIP(COMMIT, BOTH)                                                                              \
-    hipLaunchKernelGGL((recip_kernel<COMMIT, BOTH>), dim3(n_items), dim3(kBlock), lds, ln.stream, e->tp, e->bx,          \
-                       e->d_pos, e->d_nmol, e->d_res_q, e->d_kpack, e->d_kw, A_base, d_items,                            \
-                       (const double *)ln.d_sites.p, site_stride, d_u, d_u_old)
+    do {                                                                                                             \
+        if (by_rows)                                                                                                 \
+            hipLaunchKernelGGL((recip_rows_kernel<COMMIT, BOTH>), dim3(n_items), dim3(kBlock), lds, ln.stream, e->tp,   \
+                               e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_rtasks, e->n_rtasks, e->d_rrows, e->n_rrows, \
+                               e->d_kw, A_base, d_items, (const double *)ln.d_sites.p, site_stride, d_u, d_u_old);      \
+        else                                                                                                         \
+            hipLaunchKernelGGL((recip_kernel<COMMIT, BOTH>), dim3(n_items), dim3(kBlock), lds, ln.stream, e->tp,        \
+                               e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_kpack, e->d_kw, A_base, d_items,            \
+                               (const double *)ln.d_sites.p, site_stride, d_u, d_u_old);                               \
+    } while (0)
     if (commit) MGPU_LAUNCH_RECIP(true, false);
     else if (d_u_old) MGPU_LAUNCH_RECIP(false, true);
     else MGPU_LAUNCH_RECIP(false, false);
@@ -447,6 +464,30 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
         kpack[i] = e->kx[i] | ((e->ky[i] + 128) << 8) | ((e->kz[i] + 128) << 16);
         kw[i] = e->form_factor[i] * e->weights[i];  // ewald_energy.f90:266, (ff * W) * |A|^2
     }
+    // row form of the k list: rows (kx, ky) in order of first appearance, one task per (row, |kz|)
+    std::vector<RecipRow> rrows;
+    std::vector<RecipTask> rtasks;
+    {
+        std::vector<std::vector<int>> plus, minus;          // per row: k index of +j / -j, -1 if absent
+        for (int i = 0; i < e->nk; ++i) {
+            if (rrows.empty() || rrows.back().kx != e->kx[i] || rrows.back().ky != e->ky[i]) {
+                rrows.push_back(RecipRow{e->kx[i], e->ky[i]});
+                plus.emplace_back(e->kmax[2] + 1, -1);
+                minus.emplace_back(e->kmax[2] + 1, -1);
+            }
+            const int kz = e->kz[i];
+            (kz >= 0 ? plus : minus).back()[kz >= 0 ? kz : -kz] = i;
+        }
+        for (size_t r = 0; r < rrows.size(); ++r)
+            for (int j = 0; j <= e->kmax[2]; ++j)
+                if (plus[r][j] >= 0 || minus[r][j] >= 0) rtasks.push_back(RecipTask{plus[r][j], minus[r][j], (int)r, j});
+        // every k exactly once (the rows of the list are contiguous by construction; verify)
+        size_t covered = 0;
+        for (const auto &tk : rtasks) covered += (tk.kp >= 0) + (tk.km >= 0);
+        if (covered != (size_t)e->nk) { rrows.clear(); rtasks.clear(); }   // fall back to the per-k kernel
+    }
+    e->n_rrows = (int)rrows.size();
+    e->n_rtasks = (int)rtasks.size();
     std::vector<double2> ptab((size_t)n_types * n_types);
     for (int i = 0; i < n_types * n_types; ++i) ptab[i] = make_double2(4.0 * epsilon[i], sigma[i] * sigma[i]);
     std::vector<int> atype0((size_t)n_res * max_atom, 0);
@@ -511,6 +552,12 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     HIP_TRY_E(hipMalloc(&e->d_phase_tab, (size_t)ktot * ncap * sizeof(double2)));
     HIP_TRY_E(hipMalloc(&e->d_S, e->nk * sizeof(double2)));
     HIP_TRY_E(hipMemcpy(e->d_kpack, kpack.data(), e->nk * sizeof(int), hipMemcpyHostToDevice));
+    if (e->n_rtasks > 0) {
+        HIP_TRY_E(hipMalloc(&e->d_rtasks, rtasks.size() * sizeof(RecipTask)));
+        HIP_TRY_E(hipMalloc(&e->d_rrows, rrows.size() * sizeof(RecipRow)));
+        HIP_TRY_E(hipMemcpy(e->d_rtasks, rtasks.data(), rtasks.size() * sizeof(RecipTask), hipMemcpyHostToDevice));
+        HIP_TRY_E(hipMemcpy(e->d_rrows, rrows.data(), rrows.size() * sizeof(RecipRow), hipMemcpyHostToDevice));
+    }
     HIP_TRY_E(hipMemcpy(e->d_kw, kw.data(), e->nk * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY_E(hipMemcpy(e->d_pair_tab, ptab.data(), ptab.size() * sizeof(double2), hipMemcpyHostToDevice));
     HIP_TRY_E(hipMemcpy(e->d_res_q, e->charges.data(), e->charges.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -529,7 +576,8 @@ int mgpu_engine_destroy(mgpu_engine *e) {
     for (auto &ln : e->lanes) if (ln.stream) (void)hipStreamSynchronize(ln.stream);
     for (void *p : {(void *)e->d_pos, (void *)e->d_nmol, (void *)e->d_A, (void *)e->d_kpack, (void *)e->d_kw,
                     (void *)e->d_pair_tab, (void *)e->d_coul_tab, (void *)e->d_res_q, (void *)e->d_res_atype, (void *)e->d_atom_res,
-                    (void *)e->d_atom_mol, (void *)e->d_atom_q, (void *)e->d_phase_tab, (void *)e->d_S})
+                    (void *)e->d_atom_mol, (void *)e->d_atom_q, (void *)e->d_phase_tab, (void *)e->d_S, (void *)e->d_rtasks,
+                    (void *)e->d_rrows})
         if (p) (void)hipFree(p);
     e->h_stage.release();
     for (auto &ln : e->lanes) {

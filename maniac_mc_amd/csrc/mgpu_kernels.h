@@ -632,6 +632,170 @@ __global__ __launch_bounds__(kBlock) void recip_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Reciprocal-space update, row form (the fast path for molecules of a few sites).
+//
+// The k list is generated with kz innermost (ewald_kvectors.f90:150-246), so all k of one (kx, ky)
+// "row" are contiguous and come in +-kz pairs.  Work is organised around that:
+//   phase 1   1-D tables e^{i k theta} per site and axis, sincos(k * theta) as ComputePhaseFactors1D;
+//   phase 2   per row and site-state (new sites, old sites):  XY = +-q * X[kx] * Y[ky]  into LDS;
+//   phase 3   one TASK per (row, |kz|): with XY = (a, b), Z[|kz|] = (c, d) the four sums
+//             S_ac, S_bd, S_ad, S_bc over the site-states give both members of the pair,
+//                 delta(+kz) = (S_ac - S_bd,  S_ad + S_bc),   delta(-kz) = (S_ac + S_bd,  S_bc - S_ad),
+//             i.e. 4 FMAs and 2 LDS reads per site-state for TWO k-vectors (the per-k form above costs
+//             two complex products and three LDS reads per site-state for ONE).
+// Same semantics as recip_kernel: COMMIT = false returns u_new (and u_old with BOTH), COMMIT = true
+// applies A <- A + delta and then the coordinate / count update.
+// Dynamic LDS: 2 n1 ktot (1-D tables) + n_rows 2 n1 (XY) complex entries + n1 charges + the row table.
+// ------------------------------------------------------------------------------------------
+struct RecipTask {
+    int kp, km;                   // k index of (kx, ky, +j) and of (kx, ky, -j); -1: absent (j = 0 has no partner)
+    int row, j;                   // (kx, ky) row and |kz|
+};
+
+struct RecipRow {
+    int kx, ky;
+};
+
+constexpr int kRecipTaskChunk = 5;
+template <bool COMMIT, bool BOTH>
+__global__ __launch_bounds__(kBlock) void recip_rows_kernel(
+    Topo tp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
+    const RecipTask *__restrict__ tasks, int n_tasks, const RecipRow *__restrict__ rows, int n_rows,
+    const double *__restrict__ kw, double2 *__restrict__ A_base, const RecipItem *__restrict__ items,
+    const double *__restrict__ cand_sites, int site_stride, double *__restrict__ u_new, double *__restrict__ u_old) {
+    extern __shared__ double2 s_tab[];
+    __shared__ double s_red[2 * kWavesPerBlock];
+
+    const RecipItem it = items[blockIdx.x];
+    const int n1 = tp.n1[it.t], nss = 2 * n1;
+    const int kofs[3] = {0, bx.kmax[0] + 1, bx.kmax[0] + bx.kmax[1] + 2};
+    const int ktot = bx.kmax[0] + bx.kmax[1] + bx.kmax[2] + 3;
+    double2 *s_xy = s_tab + nss * ktot;
+    double *s_q = reinterpret_cast<double *>(s_xy + n_rows * nss);
+    RecipRow *s_rows = reinterpret_cast<RecipRow *>(s_q + n1);
+    double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
+    double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
+    const bool use_new = (it.kind == 0 /*MOVE*/ || it.kind == 1 /*CREATION*/);
+    const bool use_old = (it.kind == 0 /*MOVE*/ || it.kind == 2 /*DELETION*/);
+    double2 *A = A_base + (size_t)it.replica * bx.nk;
+
+    for (int r = threadIdx.x; r < n_rows; r += kBlock) s_rows[r] = rows[r];
+
+    // phase 1: entry (s = set * n1 + a, axis, k >= 0) at s_tab[s * ktot + kofs[axis] + k]
+    for (int e = threadIdx.x; e < nss * ktot; e += kBlock) {
+        const int s = e / ktot, kk = e - s * ktot;
+        const int set = s >= n1 ? 1 : 0, a = s - set * n1;
+        const int axis = (kk >= kofs[2]) ? 2 : (kk >= kofs[1] ? 1 : 0);
+        // an unused site set still gets finite entries: phase 3 multiplies them by XY = 0
+        if ((set == 0 && !use_new) || (set == 1 && !use_old)) { s_tab[e] = make_double2(0.0, 0.0); continue; }
+        double x, y, z;
+        if (set == 0) {
+            const double *c = cand_sites + ((size_t)it.src * site_stride + a) * 3;
+            x = c[0]; y = c[1]; z = c[2];
+        } else {
+            const int j = atom_slot(tp, it.t, it.m, a);
+            x = px[j]; y = py[j]; z = pz[j];
+        }
+        s_tab[e] = phase_entry(atom_phase(bx, axis, x, y, z), kk - kofs[axis]);
+    }
+    for (int a = threadIdx.x; a < n1; a += kBlock) s_q[a] = res_q[it.t * tp.max_atom + a];
+    __syncthreads();
+
+    // phase 2: XY[row][s] = (+q for the new sites, -q for the old ones) * X[kx] * Y[ky]   (ewald_energy.f90:241-256)
+    for (int e = threadIdx.x; e < n_rows * nss; e += kBlock) {
+        const int row = e / nss, s = e - row * nss;
+        const int set = s >= n1 ? 1 : 0, a = s - set * n1;
+        double2 v = make_double2(0.0, 0.0);
+        if (set == 0 ? use_new : use_old) {
+            const RecipRow r = s_rows[row];
+            const double2 *t = s_tab + s * ktot;
+            const int aky = r.ky < 0 ? -r.ky : r.ky;
+            double2 Y = t[kofs[1] + aky];
+            if (r.ky < 0) Y.y = -Y.y;
+            v = cmul(t[r.kx], Y);
+            const double q = set == 0 ? s_q[a] : -s_q[a];
+            v.x *= q; v.y *= q;
+        }
+        s_xy[e] = v;
+    }
+    __syncthreads();
+
+    const double2 *zt = s_tab + kofs[2];
+    double acc = 0.0, acc0 = 0.0;
+    // A(k) (16 B per k, the bulk of the kernel's memory traffic), ff*W and the task records of a whole
+    // chunk are requested before any of them is used
+    for (int t0 = threadIdx.x; t0 < n_tasks; t0 += kBlock * kRecipTaskChunk) {
+        int kp[kRecipTaskChunk], km[kRecipTaskChunk], rj[kRecipTaskChunk];
+        double2 Ap[kRecipTaskChunk], Am[kRecipTaskChunk];
+        double wp[kRecipTaskChunk], wm[kRecipTaskChunk];
+#pragma unroll
+        for (int c = 0; c < kRecipTaskChunk; ++c) {
+            const int t = t0 + c * kBlock;
+            const RecipTask tk = t < n_tasks ? tasks[t] : RecipTask{-1, -1, 0, 0};
+            kp[c] = tk.kp; km[c] = tk.km; rj[c] = (tk.row << 8) | tk.j;
+        }
+#pragma unroll
+        for (int c = 0; c < kRecipTaskChunk; ++c) {
+            Ap[c] = kp[c] >= 0 ? A[kp[c]] : make_double2(0.0, 0.0);
+            Am[c] = km[c] >= 0 ? A[km[c]] : make_double2(0.0, 0.0);
+            wp[c] = (kp[c] >= 0 && !COMMIT) ? kw[kp[c]] : 0.0;
+            wm[c] = (km[c] >= 0 && !COMMIT) ? kw[km[c]] : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < kRecipTaskChunk; ++c) {
+            const double2 *xy = s_xy + (rj[c] >> 8) * nss;
+            const double2 *z = zt + (rj[c] & 0xff);
+            double sac = 0.0, sbd = 0.0, sad = 0.0, sbc = 0.0;
+            for (int s = 0; s < nss; ++s) {
+                const double2 p = xy[s], q = z[s * ktot];
+                sac = fma(p.x, q.x, sac);
+                sbd = fma(p.y, q.y, sbd);
+                sad = fma(p.x, q.y, sad);
+                sbc = fma(p.y, q.x, sbc);
+            }
+            if (BOTH) acc0 += wp[c] * fma(Ap[c].x, Ap[c].x, Ap[c].y * Ap[c].y) + wm[c] * fma(Am[c].x, Am[c].x, Am[c].y * Am[c].y);
+            const double npx = Ap[c].x + (sac - sbd), npy = Ap[c].y + (sad + sbc);
+            const double nmx = Am[c].x + (sac + sbd), nmy = Am[c].y + (sbc - sad);
+            if (COMMIT) {
+                if (kp[c] >= 0) A[kp[c]] = make_double2(npx, npy);
+                if (km[c] >= 0) A[km[c]] = make_double2(nmx, nmy);
+            } else {
+                acc += wp[c] * fma(npx, npx, npy * npy) + wm[c] * fma(nmx, nmx, nmy * nmy);   // ewald_energy.f90:259-266
+            }
+        }
+    }
+
+    if (!COMMIT) {
+        acc = wave_sum(acc);
+        if (BOTH) acc0 = wave_sum(acc0);
+        if ((threadIdx.x & 63) == 0) { s_red[2 * (threadIdx.x >> 6)] = acc; s_red[2 * (threadIdx.x >> 6) + 1] = acc0; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double u = 0.0, u0 = 0.0;
+            for (int wv = 0; wv < kWavesPerBlock; ++wv) { u += s_red[2 * wv]; u0 += s_red[2 * wv + 1]; }
+            u_new[blockIdx.x] = u * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;   // ewald_energy.f90:272
+            if (BOTH) u_old[blockIdx.x] = u0 * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;
+        }
+    } else {
+        // every read of the old coordinates happened before the first barrier
+        if (it.kind == 0 || it.kind == 1) {
+            if (threadIdx.x < n1) {
+                const double *c = cand_sites + ((size_t)it.src * site_stride + threadIdx.x) * 3;
+                const int j = atom_slot(tp, it.t, it.m, threadIdx.x);
+                px[j] = c[0]; py[j] = c[1]; pz[j] = c[2];
+            }
+        } else if (it.kind == 2) {
+            const int last = it.aux;          // swap-with-last, delete_molecule.f90:107-114
+            if (threadIdx.x < n1 && last != it.m) {
+                const int j = atom_slot(tp, it.t, it.m, threadIdx.x), jl = atom_slot(tp, it.t, last, threadIdx.x);
+                px[j] = px[jl]; py[j] = py[jl]; pz[j] = pz[jl];
+            }
+        }
+        if (threadIdx.x == 0 && it.kind != 0) nmol[it.replica * tp.n_res + it.t] = it.aux;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Full structure factor S(k) (ComputeAllFourierTerms + ComputeRecipAmplitude,
 // ewald_phase.f90:340-360, ewald_energy.f90:40-77).
 // Step 1: per-atom 1-D phase tables, tab[axis][k][slot]; dead slots are skipped.
