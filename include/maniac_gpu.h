@@ -245,8 +245,9 @@ int mgpu_replica_set_num_molecules(mgpu_engine *e, int replica, int t, int n_mol
 
 /* The engine launches on its own HIP stream.  Block until everything queued so far is done. */
 int mgpu_synchronize(mgpu_engine *e);
-/* When enabled, every launch of the four main kernels is bracketed by HIP events on the engine
- * stream; mgpu_profile_get returns launches and total device milliseconds since the last reset. */
+/* When enabled, every launch of the four main kernels carries a start and a stop HIP event attached to
+ * the dispatch on the lane's own stream (the kernel's begin / end timestamps, no extra packets in the
+ * stream); mgpu_profile_get returns launches and total device milliseconds since the last reset. */
 int mgpu_profile_enable(mgpu_engine *e, int on);
 int mgpu_profile_reset(mgpu_engine *e);
 int mgpu_profile_get(mgpu_engine *e, int kernel, long long *launches, double *total_ms);

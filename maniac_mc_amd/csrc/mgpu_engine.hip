@@ -1,6 +1,7 @@
 // C-ABI entry points (include/maniac_gpu.h) and host-side orchestration of the HIP kernels.
 // One mgpu_engine = one HIP device + one stream + R replicas sharing box / force field / k table.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -151,13 +152,15 @@ int prof_begin(mgpu_engine *e, Lane &ln, int kernel, hipEvent_t *a, hipEvent_t *
         if (!e->ev_pool.empty()) { *ev = e->ev_pool.back(); e->ev_pool.pop_back(); }
         else HIP_TRY(hipEventCreate(ev));
     }
-    HIP_TRY(hipEventRecord(*a, ln.stream));
     (void)kernel;
+    (void)ln;
     return MGPU_OK;
 }
+// The events are attached to the dispatch itself (hipExtLaunchKernelGGL start / stop events): they carry
+// the kernel's own begin / end timestamps, as rocprofv3 reports them, and put no extra barrier packets
+// into the stream.  With profiling off both are null and the launch is an ordinary one.
 int prof_end(mgpu_engine *e, Lane &ln, int kernel, hipEvent_t a, hipEvent_t b) {
     if (!e->profiling) return MGPU_OK;
-    HIP_TRY(hipEventRecord(b, ln.stream));
     ln.pending.push_back({kernel, a, b});
     return MGPU_OK;
 }
@@ -246,8 +249,8 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
     rc = prof_begin(e, ln, MGPU_KERNEL_PAIR, &a, &b);
     if (rc) return rc;
 #define MGPU_LAUNCH_PAIR(NS, ORD, TRI)                                                                                  \
-    hipLaunchKernelGGL((pair_sweep_kernel<NS, ORD, TRI>), dim3(grid), dim3(kPairBlock), e->coul_bytes, ln.stream,       \
-                       e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab,     \
+    hipExtLaunchKernelGGL((pair_sweep_kernel<NS, ORD, TRI>), dim3(grid), dim3(kPairBlock), e->coul_bytes, ln.stream,    \
+                          a, b, 0, e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab,     \
                        d_items, (const double *)ln.d_sites.p, site_stride, nsplit, n_work, (double2 *)ln.d_partials.p)
     if (e->bx.triclinic) {
         if (ordered) MGPU_LAUNCH_PAIR(0, true, true);
@@ -266,6 +269,10 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
 #undef MGPU_LAUNCH_PAIR
     rc = prof_end(e, ln, MGPU_KERNEL_PAIR, a, b);
     if (rc) return rc;
+    // (The reduction stays a separate launch: letting the last wave of an item reduce the partials needs
+    //  agent-scope fences, and on the 8-XCD part those write back / invalidate the XCD's L2 -- measured:
+    //  pair sweep 110 -> 275 us.  Likewise results are copied out once rather than stored by the kernels
+    //  into pinned host memory: thousands of 8-byte PCIe writes were 3-7x slower than the blit.)
     hipLaunchKernelGGL(pair_finalize_kernel, dim3((n_items + 255) / 256), dim3(256), 0, ln.stream,
                        (const double2 *)ln.d_partials.p, n_items, nsplit, d_lj, d_c);
     HIP_TRY(hipGetLastError());
@@ -310,12 +317,12 @@ int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items
 #define MGPU_LAUNCH_RECIP(COMMIT, BOTH)                                                                              \
     do {                                                                                                             \
         if (by_rows)                                                                                                 \
-            hipLaunchKernelGGL((recip_rows_kernel<COMMIT, BOTH>), dim3(n_items), dim3(kBlock), lds, ln.stream, e->tp,   \
-                               e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_rtasks, e->n_rtasks, e->d_rrows, e->n_rrows, \
+            hipExtLaunchKernelGGL((recip_rows_kernel<COMMIT, BOTH>), dim3(n_items), dim3(kBlock), lds, ln.stream, a, b, \
+                                  0, e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_rtasks, e->n_rtasks, e->d_rrows, e->n_rrows, \
                                e->d_kw, A_base, d_items, (const double *)ln.d_sites.p, site_stride, d_u, d_u_old);      \
         else                                                                                                         \
-            hipLaunchKernelGGL((recip_kernel<COMMIT, BOTH>), dim3(n_items), dim3(kBlock), lds, ln.stream, e->tp,        \
-                               e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_kpack, e->d_kw, A_base, d_items,            \
+            hipExtLaunchKernelGGL((recip_kernel<COMMIT, BOTH>), dim3(n_items), dim3(kBlock), lds, ln.stream, a, b, 0,   \
+                                  e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_kpack, e->d_kw, A_base, d_items,            \
                                (const double *)ln.d_sites.p, site_stride, d_u, d_u_old);                               \
     } while (0)
     if (commit) MGPU_LAUNCH_RECIP(true, false);
@@ -336,8 +343,8 @@ int launch_sfactor(mgpu_engine *e, int replica, double2 *dst) {
     if (rc) return rc;
     hipLaunchKernelGGL(phase_table_kernel, dim3((ncap + 255) / 256), dim3(256), 0, e->stream, e->tp, e->bx, e->d_pos,
                        e->d_nmol, e->d_atom_res, e->d_atom_mol, replica, e->d_phase_tab);
-    hipLaunchKernelGGL(sfactor_kernel, dim3(e->nk), dim3(kBlock), 0, e->stream, e->tp, e->bx, e->d_nmol, e->d_atom_res,
-                       e->d_atom_mol, e->d_atom_q, e->d_kpack, replica, e->d_phase_tab, dst);
+    hipExtLaunchKernelGGL(sfactor_kernel, dim3(e->nk), dim3(kBlock), 0, e->stream, a, b, 0, e->tp, e->bx, e->d_nmol,
+                          e->d_atom_res, e->d_atom_mol, e->d_atom_q, e->d_kpack, replica, e->d_phase_tab, dst);
     rc = prof_end(e, e->lanes[0], MGPU_KERNEL_SFACTOR, a, b);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
