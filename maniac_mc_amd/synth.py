@@ -121,6 +121,26 @@ def co2_box(n_mol=64, L=50.0, seed=7, rc=12.0, tol=1e-5, temperature=300.0):
                   [com], [off], label=f"co2_{n_mol}mol_L{L:g}")
 
 
+def five_site_water_box(n_mol=24, L=20.0, seed=13, rc=9.0, tol=1e-5, temperature=298.0):
+    """Rigid five-site water (TIP5P-like textbook geometry, not from the reference): O carries the
+    Lennard-Jones site and no charge, two H (+0.241 e) and two lone-pair sites (-0.241 e).  Five sites per
+    molecule take the generic (site count not templated) pair sweep and the per-k reciprocal kernel."""
+    rng = np.random.default_rng(seed)
+    r_oh, r_ol = 0.9572, 0.70
+    a_h, a_l = np.deg2rad(104.52) / 2, np.deg2rad(109.47) / 2
+    tmpl = np.array([[0.0, 0.0, 0.0],
+                     [r_oh * np.sin(a_h), r_oh * np.cos(a_h), 0.0], [-r_oh * np.sin(a_h), r_oh * np.cos(a_h), 0.0],
+                     [0.0, -r_ol * np.cos(a_l), r_ol * np.sin(a_l)], [0.0, -r_ol * np.cos(a_l), -r_ol * np.sin(a_l)]])
+    tmpl = tmpl - tmpl.mean(0)
+    eps, sig = lorentz_berthelot([0.16, 0.0, 0.0], [3.12, 0.0, 0.0])
+    topo = Topology(atoms_in_res=[5], atom_types=[[1, 2, 2, 3, 3]], charges=[[0.0, 0.241, 0.241, -0.241, -0.241]],
+                    is_active=[1], epsilon=eps, sigma=sig, names=["W5"])
+    com = _spread_points(rng, n_mol, L, min_sep=3.0)
+    off = np.einsum("mij,aj->mai", _random_rotations(rng, n_mol), tmpl)
+    return System(topo, np.diag([L, L, L]), np.full(3, -L / 2), rc, tol, temperature, [com], [off],
+                  label=f"water5_{n_mol}mol")
+
+
 def _spread_points(rng, n, L, min_sep):
     """n points in [-L/2, L/2)^3 with pairwise minimum-image separation >= min_sep."""
     pts = np.empty((0, 3))

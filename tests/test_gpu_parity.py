@@ -110,7 +110,8 @@ def test_engine_vs_golden(name):
 @pytest.mark.parametrize("maker,nrep", [(lambda: synth.spce_box(6, seed=21), 4), (lambda: synth.mixture_box(seed=5), 3),
                                         (lambda: synth.co2_box(16, seed=2), 2),
                                         (lambda: synth.framework_water_box(n_water=10, n_frame=260, L=23.0, seed=9), 2),
-                                        (lambda: synth.mixture_box(seed=6, tilt=(1.5, -0.8, 0.6)), 2)])
+                                        (lambda: synth.mixture_box(seed=6, tilt=(1.5, -0.8, 0.6)), 2),
+                                        (lambda: synth.five_site_water_box(), 2)])
 def test_batched_candidates_vs_refcpu(maker, nrep, refcpu_mod):
     """Many candidates per launch, on replicas holding DIFFERENT configurations."""
     rng = np.random.default_rng(7)
@@ -326,3 +327,19 @@ def test_edge_cases_and_errors():
     assert tri.box_type == 3
     tri.close()
     eng.close()
+
+
+
+def test_per_k_reciprocal_kernel():
+    """The per-k form of the reciprocal update (fallback for molecules whose XY table exceeds the LDS
+    budget of the row form) is selected once per process by MGPU_RECIP_PER_K: re-run the golden-vector
+    test of two systems (moves, creation, deletion, commits) in a child process with the variable set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MGPU_RECIP_PER_K="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-q", "-x", "-m", "gpu", "-k",
+                        "test_engine_vs_golden and (co2_20 or mixture)"], capture_output=True, text=True, env=env,
+                       cwd=root, timeout=900)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
