@@ -45,7 +45,7 @@ module mc_farm
 
     private
     public :: mfarm_create, mfarm_run, mfarm_destroy, mfarm_get_energy, mfarm_get_molecule, mfarm_recalibrate
-    public :: mfarm_get_timers, mfarm_set_gcmc, mfarm_get_counts, mfarm_get_counters
+    public :: mfarm_get_timers, mfarm_set_gcmc, mfarm_get_counts, mfarm_get_counters, mfarm_set_triclinic
 
     real(real64), parameter :: PI = 3.14159265358979323846_real64
     real(real64), parameter :: TWOPI = 2.0_real64 * PI
@@ -81,6 +81,8 @@ module mc_farm
         real(real64), allocatable :: energy(:, :)          ! (5, R) non_coulomb, coulomb, recip, self, intra
         real(real64), allocatable :: fugacity(:, :)        ! (n_active, R) molecules per cubic Angstrom
         real(real64) :: lo(3), len(3), volume, temperature, translation_step, rotation_step
+        logical :: triclinic = .false.                     ! box%is_triclinic: wrap / insert through the cell matrix
+        real(real64) :: matrix(3, 3) = 0.0_real64, reciprocal(3, 3) = 0.0_real64
         real(real64) :: p_translation, p_rotation          ! the rest is insertion / deletion
         logical :: gcmc = .false.
         integer(int64) :: trials = 0, accepted = 0
@@ -201,6 +203,7 @@ contains
         F%lo = bounds_lo
         F%len = box_len
         F%volume = box_len(1) * box_len(2) * box_len(3)
+        F%triclinic = .false.
         F%temperature = temperature
         F%translation_step = translation_step
         F%rotation_step = rotation_step
@@ -224,6 +227,20 @@ contains
         end do
         F%ready = .true.
     end function mfarm_create
+
+    !---------------------------------------------------------------------------
+    ! Triclinic box (after mfarm_create): box%matrix and box%reciprocal as the Fortran arrays, and the cell
+    ! volume; translations then wrap through fractional coordinates and insertions are placed with the
+    ! cell matrix, as ApplyPBC / InsertAndOrientMolecule do for box%is_triclinic.
+    !---------------------------------------------------------------------------
+    subroutine mfarm_set_triclinic(matrix, reciprocal, volume) bind(C, name="mfarm_set_triclinic")
+        real(c_double), intent(in) :: matrix(3, 3), reciprocal(3, 3)
+        real(c_double), value :: volume
+        F%matrix = matrix
+        F%reciprocal = reciprocal
+        F%volume = volume
+        F%triclinic = .true.
+    end subroutine mfarm_set_triclinic
 
     !---------------------------------------------------------------------------
     ! Switch insertion / deletion on: move probabilities as in the .maniac input
@@ -303,7 +320,7 @@ contains
         integer(c_int) :: rc
         integer :: i, j, r, ia, slot, n1, axis, d, a, mv, n
         integer(int64) :: c0, c1, c2, c3, c4, skipped
-        real(real64) :: x, draw
+        real(real64) :: x, draw, v(3), frac(3)
         type(lane_buffers), pointer :: L
         L => F%lane(g)
         rc = MGPU_OK
@@ -375,7 +392,7 @@ contains
         ! pass 1 (one parallel region per lane and step: the fork/join is not free): gather com /
         ! offsets from the host mirror -- one contiguous record, the random access is DRAM/TLB-latency
         ! bound and the threads overlap the misses -- then build the move
-        !$omp parallel do num_threads(F%n_threads) schedule(static) private(i, n1, d, x, axis, a, r, ia, slot)
+        !$omp parallel do num_threads(F%n_threads) schedule(static) private(i, n1, d, x, axis, a, r, ia, slot, v, frac)
         do j = 1, L%nc
             i = L%cidx(j)
             r = L%rep(j) + 1
@@ -389,20 +406,43 @@ contains
             case (MV_TRANSLATION)
                 ! translation.f90:104-110: rand_symmetric(3)*translation_step, then ApplyPBC
                 ! (geometry_utils.f90:190: lo + modulo(pos - lo, L))
-                do d = 1, 3
-                    x = (L%new_com(d, j) + (L%u(3 + d, i) - 0.5_real64) * F%translation_step) - F%lo(d)
-                    if (x < 0.0_real64 .or. x >= F%len(d)) x = modulo(x, F%len(d))
-                    L%new_com(d, j) = F%lo(d) + x
-                end do
+                if (.not. F%triclinic) then
+                    do d = 1, 3
+                        x = (L%new_com(d, j) + (L%u(3 + d, i) - 0.5_real64) * F%translation_step) - F%lo(d)
+                        if (x < 0.0_real64 .or. x >= F%len(d)) x = modulo(x, F%len(d))
+                        L%new_com(d, j) = F%lo(d) + x
+                    end do
+                else
+                    ! geometry_utils.f90:196-211: s = H^-1 (r - r0), s <- modulo(s, 1), r <- r0 + H s
+                    do d = 1, 3
+                        v(d) = (L%new_com(d, j) + (L%u(3 + d, i) - 0.5_real64) * F%translation_step) - F%lo(d)
+                    end do
+                    do d = 1, 3
+                        frac(d) = modulo(F%reciprocal(d, 1) * v(1) + F%reciprocal(d, 2) * v(2) + F%reciprocal(d, 3) * v(3), &
+                                         1.0_real64)
+                    end do
+                    do d = 1, 3
+                        L%new_com(d, j) = F%lo(d) + (F%matrix(d, 1) * frac(1) + F%matrix(d, 2) * frac(2) + &
+                                                     F%matrix(d, 3) * frac(3))
+                    end do
+                end if
             case (MV_ROTATION)
                 ! monte_carlo_utils.f90:54-64: theta = (u - 1/2)*rotation_step_angle, random Cartesian axis
                 axis = int(L%u(8, i) * 3.0_real64) + 1
                 call rotate_offsets(L%new_off(:, :, j), n1, axis, (L%u(7, i) - 0.5_real64) * F%rotation_step)
             case (MV_CREATION)
                 ! create_molecule.f90:180-203: uniform position in the (orthorhombic) box, full rotation
-                do d = 1, 3
-                    L%new_com(d, j) = F%lo(d) + F%len(d) * L%u(3 + d, i)
-                end do
+                if (.not. F%triclinic) then
+                    do d = 1, 3
+                        L%new_com(d, j) = F%lo(d) + F%len(d) * L%u(3 + d, i)
+                    end do
+                else
+                    ! create_molecule.f90:183-184: bounds(:, 1) + matmul(matrix, trial_pos)
+                    do d = 1, 3
+                        L%new_com(d, j) = F%lo(d) + (F%matrix(d, 1) * L%u(4, i) + F%matrix(d, 2) * L%u(5, i) + &
+                                                     F%matrix(d, 3) * L%u(6, i))
+                    end do
+                end if
                 if (n1 > 1) then
                     axis = int(L%u(8, i) * 3.0_real64) + 1
                     call rotate_offsets(L%new_off(:, :, j), n1, axis, L%u(7, i) * TWOPI)

@@ -69,9 +69,6 @@ class FortranFarm:
                  rng_kind: int = 1, n_threads: int = 8, mol_capacity=None, gcmc=None,
                  n_lanes: int = 2):
         self.H = lib()
-        if system.is_triclinic():
-            raise NotImplementedError("the Fortran farm generates moves for cubic / orthorhombic boxes only "
-                                      "(the engine itself evaluates triclinic boxes)")
         self.sys = system
         self.R = int(n_replicas)
         topo = system.topo
@@ -111,6 +108,12 @@ class FortranFarm:
                                  C.c_double(rotation_step), C.c_double(p_translation), C.c_int(seed),
                                  C.c_int(rng_kind), C.c_int(n_threads), C.c_int(n_lanes))
         _lib.check(rc)
+        if system.is_triclinic():
+            from .engine import box_prepare
+            _, volume, reciprocal, _ = box_prepare(system.box_matrix)
+            mat = np.asfortranarray(system.box_matrix, dtype=np.float64)
+            rcp = np.asfortranarray(reciprocal, dtype=np.float64)
+            self.H.mfarm_set_triclinic(mat.ctypes.data_as(_dp), rcp.ctypes.data_as(_dp), C.c_double(volume))
         self.max_n1 = max_n1
         self.n_lanes = max(1, min(int(n_lanes) if n_lanes > 0 else 2, 4, self.R))
         self.n_active = len(active)

@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("maker,R,steps", [(lambda: synth.spce_box(6, seed=3), 7, 40), (lambda: synth.co2_box(24, seed=5), 4, 60),
-                                           (lambda: synth.mixture_box(seed=4), 5, 50)])
+                                           (lambda: synth.mixture_box(seed=4), 5, 50),
+                                           (lambda: synth.mixture_box(seed=4, tilt=(1.5, -0.8, 0.6)), 4, 50)])
 def test_fortran_farm_consistency(maker, R, steps):
     from maniac_mc_amd.fortran_host import FortranFarm
     s = maker()
@@ -112,4 +113,34 @@ def test_gcmc_farm_consistency_and_ideal_gas_limit():
     for g, target in enumerate([10.0, 20.0, 30.0]):
         mean_n = samples[:, g * (R // 3):(g + 1) * (R // 3)].mean()
         assert abs(mean_n - target) < 0.12 * target, (target, mean_n)
+    farm.close()
+
+
+def test_gcmc_farm_in_a_triclinic_box():
+    """Insertion / deletion / translation / rotation of both species of the small mixture in a tilted cell:
+    translations wrap through fractional coordinates and insertions are placed with the cell matrix
+    (ApplyPBC / InsertAndOrientMolecule for box%is_triclinic); bookkeeping as in the orthorhombic test."""
+    from maniac_mc_amd.engine import box_prepare
+    from maniac_mc_amd.fortran_host import FortranFarm
+    s = synth.mixture_box(seed=8, tilt=(1.5, -0.8, 0.6))
+    R = 6
+    _, volume, _, _ = box_prepare(s.box_matrix)
+    farm = FortranFarm(s, R, seed=5, translation_step=0.8, rotation_step=0.5, n_threads=2, mol_capacity=[40, 40],
+                       gcmc=dict(p_translation=0.3, p_rotation=0.3, fugacity=12.0 / volume))
+    farm.run(300)
+    c = farm.counters()
+    assert c["creations"] > 0 and c["deletions"] > 0 and c["translations"] > 0
+    eng = farm.eng
+    counts = farm.counts()
+    for r in range(R):
+        e = eng.system_energy(r)
+        run = farm.energy(r)
+        ref = np.array([e[k] for k in ("non_coulomb", "coulomb", "recip_coulomb", "ewald_self", "intra_coulomb")])
+        assert np.max(np.abs(run - ref)) < 2e-5 * max(1.0, np.max(np.abs(ref)) * 1e-6), (r, run - ref)
+        for ia in range(2):
+            assert eng.num_molecules(r, ia) == counts[r, ia]
+            dev = eng.get_molecules(r, ia)
+            for slot in range(counts[r, ia]):
+                com, off = farm.molecule(r, ia, slot)
+                assert np.array_equal(dev[slot], com[None, :] + off[: dev.shape[1]])
     farm.close()
