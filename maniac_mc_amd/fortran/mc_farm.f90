@@ -184,18 +184,22 @@ contains
         end do
         F%cap_total = tot
         allocate(F%mol(3 + 3 * max_n1, tot, n_replicas), F%energy(5, n_replicas))
-        F%mol = 0.0_real64
-        src = 0
-        do ia = 1, n_active
-            do r = 1, n_replicas
+        F%n_threads = max(1, int(n_threads))
+        ! first touch by the threads that will gather from it (the mirror is several hundred MB)
+        !$omp parallel do num_threads(F%n_threads) schedule(static) private(ia, k, src)
+        do r = 1, n_replicas
+            F%mol(:, :, r) = 0.0_real64
+            src = 0
+            do ia = 1, n_active
                 do k = 1, n_mol(ia)
                     F%mol(1:3, F%first(ia) + k, r) = com(:, src + k)
                     F%mol(4:, F%first(ia) + k, r) = reshape(off(:, :, src + k), [3 * max_n1])
                 end do
                 F%cnt(ia, r) = n_mol(ia)
+                src = src + n_mol(ia)
             end do
-            src = src + n_mol(ia)
         end do
+        !$omp end parallel do
         do r = 1, n_replicas
             F%energy(:, r) = energy0
         end do

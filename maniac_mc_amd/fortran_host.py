@@ -64,11 +64,17 @@ class FortranFarm:
     type, or (n_active, R) for an isotherm sweep; ``mol_capacity`` bounds the molecule count per type.
     """
 
+    _live = None          # the one farm the Fortran module holds (see __init__)
+
     def __init__(self, system: System, n_replicas: int, device: int = 0, seed: int = 1,
                  translation_step: float = 0.3, rotation_step: float = 0.3, p_translation: float = 0.5,
                  rng_kind: int = 1, n_threads: int = 8, mol_capacity=None, gcmc=None,
                  n_lanes: int = 2):
         self.H = lib()
+        # mc_farm.f90 keeps ONE farm in module state (as the reference keeps one simulation): a second live
+        # instance would silently take it over
+        if FortranFarm._live is not None:
+            raise RuntimeError("a FortranFarm is already active in this process: close() it first")
         self.sys = system
         self.R = int(n_replicas)
         topo = system.topo
@@ -118,6 +124,7 @@ class FortranFarm:
         self.n_lanes = max(1, min(int(n_lanes) if n_lanes > 0 else 2, 4, self.R))
         self.n_active = len(active)
         self.stats = np.zeros(3)
+        FortranFarm._live = self
         if gcmc is not None:
             fug = np.asarray(gcmc["fugacity"], dtype=np.float64)
             if fug.ndim == 0:
@@ -188,5 +195,7 @@ class FortranFarm:
         return int(self.stats[2])
 
     def close(self):
-        self.H.mfarm_destroy()
+        if FortranFarm._live is self:
+            self.H.mfarm_destroy()
+            FortranFarm._live = None
         self.eng.close()

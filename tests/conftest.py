@@ -43,3 +43,12 @@ def reflib_mod():
     if not reflib.available():
         pytest.skip("oracle/_ref/libmaniac_ref.so not built (needs /root/reference + amdflang)")
     return reflib
+
+
+@pytest.fixture(autouse=True)
+def _close_leftover_farm():
+    """A test that fails before farm.close() must not leave the process-wide Fortran farm occupied."""
+    yield
+    mod = sys.modules.get("maniac_mc_amd.fortran_host")
+    if mod is not None and mod.FortranFarm._live is not None:
+        mod.FortranFarm._live.close()
