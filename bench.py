@@ -81,6 +81,55 @@ def cpu_baseline(system, translation_step, rotation_step, budget_s=15.0, seed=3)
             "acceptance": accepted / max(1, trials)}
 
 
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            out += list(range(int(a), int(b) + 1))
+        elif part:
+            out.append(int(part))
+    return out
+
+
+def pin_host_threads(torch, device, local_rank, local_world, n_threads):
+    """Bind the OpenMP threads of the Fortran driver to physical cores of the NUMA node the GPU hangs off,
+    split among the ranks whose GPUs share that node (unpinned, the step time varied by +-10 % run to run
+    with where the threads happened to land).  Must run before the OpenMP runtime starts, i.e. before
+    libmaniac_host.so is used; does nothing when the topology cannot be read or the user set OMP_PLACES."""
+    if "OMP_PLACES" in os.environ or "OMP_PROC_BIND" in os.environ:
+        return None
+    try:
+        def node_of(dev):
+            p = torch.cuda.get_device_properties(dev)
+            bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+            return int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        n_dev = torch.cuda.device_count()
+        node = node_of(device)
+        if node < 0:
+            return None
+        peers = [j for j in range(local_world) if node_of(j % n_dev) == node] if local_world > 1 else [local_rank]
+        cpus = _cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
+        sib = set()
+        cores = []
+        for c in cpus:                       # one hardware thread per physical core
+            if c in sib:
+                continue
+            cores.append(c)
+            sib.update(_cpulist(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read()))
+        allowed = os.sched_getaffinity(0)
+        cores = [c for c in cores if c in allowed]
+        idx = peers.index(local_rank) if local_rank in peers else 0
+        share = cores[idx * len(cores) // len(peers):(idx + 1) * len(cores) // len(peers)][:n_threads]
+        if len(share) < n_threads:
+            return None
+        os.environ["OMP_PLACES"] = ",".join("{%d}" % c for c in share)
+        os.environ["OMP_PROC_BIND"] = "true"
+        return share
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,8 +140,11 @@ def main():
     ap.add_argument("--host", choices=["fortran", "python"], default="fortran",
                     help="Metropolis driver: the Fortran farm (mc_farm.f90, two overlapped lanes) or the numpy one")
     ap.add_argument("--host-threads", type=int, default=0,
-                    help="OpenMP threads of the Fortran driver per GPU (0: min(16, cores available / ranks on the node))")
-    ap.add_argument("--lanes", type=int, default=2, help="submission lanes (chain groups in flight) of the Fortran driver")
+                    help="OpenMP threads of the Fortran driver per GPU (0: min(8, cores available / ranks on the node))")
+    ap.add_argument("--no-pin", action="store_true", help="do not bind the host threads to the GPU's NUMA node")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="submission lanes (chain groups in flight) of the Fortran driver; 3 lanes x 1024 chains give ~20 %% more "
+                         "moves/s because kernels of different lanes overlap, at the price of stretched per-kernel durations")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,7 +153,7 @@ def main():
 
     if args.host_threads <= 0:
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-        args.host_threads = max(1, min(16, len(os.sched_getaffinity(0)) // max(1, local_world)))
+        args.host_threads = max(1, min(8, len(os.sched_getaffinity(0)) // max(1, local_world)))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,6 +167,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(args.dist_backend)
+
+    pinned = None
+    if args.host == "fortran" and not args.no_pin:
+        local_world_size = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        pinned = pin_host_threads(torch, device, local_rank, local_world_size, args.host_threads)
 
     from maniac_mc_amd import _lib, synth
     system = synth.spce_box(args.n_side)
@@ -155,6 +212,21 @@ def main():
     n_pair, ms_pair = eng.profile_get(_lib.KERNEL_PAIR)
     n_rec, ms_rec = eng.profile_get(_lib.KERNEL_RECIP)
     n_com, ms_com = eng.profile_get(_lib.KERNEL_COMMIT)
+
+    # The same pair-sweep batch launched alone (outside the timed region, rank 0): with several lanes in
+    # flight the kernels of different lanes share the CUs, which raises throughput but stretches every
+    # kernel's own duration; this gives the kernel's un-shared time for comparison.
+    iso_us = None
+    if rank == 0 and args.host == "fortran":
+        rng = np.random.default_rng(5)
+        n_l = max(1, R // farm.n_lanes)
+        m_iso = rng.integers(0, int(system.n_mol[0]), n_l).astype(np.int32)
+        sites_iso = system.all_sites(0)[m_iso] + rng.uniform(-0.15, 0.15, (n_l, 1, 3))
+        eng.profile_reset()
+        for _ in range(10):
+            eng.trial_energy_candidates(np.arange(n_l, dtype=np.int32), np.zeros(n_l, np.int32), m_iso, sites_iso)
+        n_iso, ms_iso = eng.profile_get(_lib.KERNEL_PAIR)
+        iso_us = ms_iso / max(1, n_iso) * 1e3
     eng.profile_enable(False)
 
     if rank == 0:
@@ -176,7 +248,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"spce_{system.n_mol[0]}mol_{N}atoms_lj_cut_coul_long_ewald_Nk{Nk}",
                        "replicas_per_gpu": R, "host_driver": args.host, "host_threads": args.host_threads if args.host == "fortran" else 1,
-                       "lanes": farm.n_lanes if args.host == "fortran" else 1, "moves": "50% translation / 50% rotation, 0.3 A / 0.3 rad, 300 K",
+                       "lanes": farm.n_lanes if args.host == "fortran" else 1, "host_cores": pinned, "moves": "50% translation / 50% rotation, 0.3 A / 0.3 rad, 300 K",
                        "trials_per_step": R * world, "dE_evals_per_step": 2 * R * world, "parallelism": f"replicas x{world}"},
             "trial_moves_per_s": tot_trials / elapsed,
             "acceptance": tot_acc / max(1.0, tot_trials),
@@ -188,6 +260,11 @@ def main():
                          "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
                          "algorithmic_bytes_per_launch": bytes_pair_eval * evals_per_launch,
                          "avg_launch_us": avg_pair_s * 1e6, "launches": n_pair,
+                         "isolated": None if not iso_us else {
+                             "avg_launch_us": iso_us, "achieved": bytes_pair_eval * evals_per_launch / (iso_us * 1e-6) / 1e9,
+                             "frac": bytes_pair_eval * evals_per_launch / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                             "note": "same batch launched alone after the timed region; in the timed region the "
+                                     "kernels of the lanes overlap on the device"},
                          "job_frac": (evals_total / world / elapsed) * bytes_eval / 1e9 / HBM_PEAK_GBS,
                          "recip_avg_launch_us": ms_rec / max(1, n_rec) * 1e3, "commit_avg_launch_us": ms_com / max(1, n_com) * 1e3},
         }

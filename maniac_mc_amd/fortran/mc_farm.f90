@@ -18,10 +18,11 @@
 ! Deliberate differences from the reference (SURVEY F2 / F3): A(k) is initialised to S(k) before
 ! the first move, and a deletion's new reciprocal energy is sum ff W |A - S_mol|^2.
 !
-! Random numbers: rng_kind 0 draws from the intrinsic random_number exactly like the reference
-! (src/random_utils.f90:13-56); rng_kind 1 (default of the bench) uses an inlined xoshiro256+
-! generator seeded by the same rule, because flang's random_number costs ~17 ns per number and the
-! farm consumes ten numbers per trial (measured: 40 % of the host time of a step).
+! Random numbers: rng_kind 0 draws from the intrinsic random_number like the reference
+! (src/random_utils.f90:13-56), serially; rng_kind 1 (default) gives every chain its own xoshiro256+
+! generator, seeded from the reference's rule and the chain index: flang's random_number costs ~17 ns
+! per number (ten per trial), and chain-local generators make a chain's trajectory independent of how
+! many chains run beside it and let the draw run inside the parallel loop.
 !
 ! One chain is sequential, so the farm advances R chains in lock step: each step generates one
 ! trial move per chain, evaluates all of them in one batched call (old and new state of every
@@ -64,6 +65,7 @@ module mc_farm
         integer :: nc = 0                                  ! candidates of the trial in flight (<= n)
         integer(c_int), allocatable :: rep(:), t(:), m(:), kind(:), accept(:)
         integer, allocatable :: ia(:), move(:), cidx(:)    ! active-type index, move code, chain index
+        integer, allocatable :: sel_ia(:), sel_mv(:), sel_slot(:)   ! per chain: the selection (slot 0 = no-op)
         real(real64), allocatable :: sites(:, :, :)        ! (3, max_n1, n)
         real(real64), allocatable :: new_com(:, :), new_off(:, :, :)
         real(real64), allocatable :: old_e(:), new_e(:)    ! (ne * nc) rows packed by the engine
@@ -92,54 +94,67 @@ module mc_farm
         logical :: ready = .false.
         integer(int64) :: ticks(7) = 0                     ! generate, submit, wait, resolve, commit, rng, gather
         integer :: rng_kind = 1, n_threads = 1, n_lanes = 2
-        integer(int64) :: xs(4) = 0                        ! xoshiro256+ state
+        integer(int64), allocatable :: cxs(:, :)           ! (4, R) xoshiro256+ state of every chain
     end type farm_state
 
     type(farm_state), save, target :: F
 
 contains
 
-    ! seed_rng (src/random_utils.f90:33-56): seed + 37*(i-1)
-    subroutine seed_farm_rng(seed)
-        integer, intent(in) :: seed
-        integer :: n, i
+    ! seed_rng (src/random_utils.f90:33-56): seed + 37*(i-1) for the intrinsic generator; every chain
+    ! additionally owns a xoshiro256+ generator (Blackman & Vigna) whose state is derived from the same
+    ! rule and the chain index, so a chain's random numbers do not depend on how many chains run beside it
+    subroutine seed_farm_rng(seed, n_chains)
+        integer, intent(in) :: seed, n_chains
+        integer :: n, i, r, k
         integer, allocatable :: s(:)
+        integer(int64) :: x, t, s1, s2, s3, s4
         call random_seed(size=n)
         allocate(s(n))
         s = seed + 37 * [(i - 1, i = 1, n)]
         call random_seed(put=s)
-        ! xoshiro256+ state from the same rule (seed + 37*(i-1)), scrambled by xorshift steps
-        do i = 1, 4
-            F%xs(i) = int(seed + 37 * (i - 1), int64) + 88172645463325252_int64 * int(i, int64)
-            F%xs(i) = ieor(F%xs(i), ishft(F%xs(i), 13))
-            F%xs(i) = ieor(F%xs(i), ishft(F%xs(i), -7))
-            F%xs(i) = ieor(F%xs(i), ishft(F%xs(i), 17))
-        end do
-        if (all(F%xs == 0_int64)) F%xs(1) = 1_int64
-    end subroutine seed_farm_rng
-
-    ! fill u with uniform numbers in [0, 1)
-    subroutine farm_random(u)
-        real(real64), intent(out) :: u(:, :)
-        integer :: i, j
-        integer(int64) :: t, s1, s2, s3, s4
-        if (F%rng_kind == 0) then
-            call random_number(u)
-            return
-        end if
-        s1 = F%xs(1); s2 = F%xs(2); s3 = F%xs(3); s4 = F%xs(4)
-        do j = 1, size(u, 2)
-            do i = 1, size(u, 1)
-                ! xoshiro256+ (Blackman & Vigna): top 53 bits of s1 + s4
-                u(i, j) = real(ishft(s1 + s4, -11), real64) * (1.0_real64 / 9007199254740992.0_real64)
+        if (allocated(F%cxs)) deallocate(F%cxs)
+        allocate(F%cxs(4, n_chains))
+        do r = 1, n_chains
+            do i = 1, 4
+                x = int(seed + 37 * (i - 1), int64) + 88172645463325252_int64 * int(i, int64) + &
+                    1000003_int64 * int(r, int64)
+                do k = 1, 3                                ! xorshift64 rounds: spread the small differences
+                    x = ieor(x, ishft(x, 13))
+                    x = ieor(x, ishft(x, -7))
+                    x = ieor(x, ishft(x, 17))
+                end do
+                F%cxs(i, r) = x
+            end do
+            if (all(F%cxs(:, r) == 0_int64)) F%cxs(1, r) = 1_int64
+            ! run the generator in: its first outputs still mirror the seeding rule
+            s1 = F%cxs(1, r); s2 = F%cxs(2, r); s3 = F%cxs(3, r); s4 = F%cxs(4, r)
+            do k = 1, 16
                 t = ishft(s2, 17)
                 s3 = ieor(s3, s1); s4 = ieor(s4, s2); s2 = ieor(s2, s3); s1 = ieor(s1, s4)
                 s3 = ieor(s3, t)
                 s4 = ior(ishft(s4, 45), ishft(s4, -19))
             end do
+            F%cxs(:, r) = [s1, s2, s3, s4]
         end do
-        F%xs = [s1, s2, s3, s4]
-    end subroutine farm_random
+    end subroutine seed_farm_rng
+
+    ! NRAND uniform numbers in [0, 1) from chain r's generator: top 53 bits of s1 + s4
+    subroutine chain_random(r, u)
+        integer, intent(in) :: r
+        real(real64), intent(out) :: u(NRAND)
+        integer :: i
+        integer(int64) :: t, s1, s2, s3, s4
+        s1 = F%cxs(1, r); s2 = F%cxs(2, r); s3 = F%cxs(3, r); s4 = F%cxs(4, r)
+        do i = 1, NRAND
+            u(i) = real(ishft(s1 + s4, -11), real64) * (1.0_real64 / 9007199254740992.0_real64)
+            t = ishft(s2, 17)
+            s3 = ieor(s3, s1); s4 = ieor(s4, s2); s2 = ieor(s2, s3); s1 = ieor(s1, s4)
+            s3 = ieor(s3, t)
+            s4 = ior(ishft(s4, 45), ishft(s4, -19))
+        end do
+        F%cxs(1, r) = s1; F%cxs(2, r) = s2; F%cxs(3, r) = s3; F%cxs(4, r) = s4
+    end subroutine chain_random
 
     !---------------------------------------------------------------------------
     ! Create the farm.  Every replica of `engine` must already hold the same configuration
@@ -158,7 +173,7 @@ contains
         real(c_double), intent(in) :: com(3, *), off(3, max_n1, *), energy0(5), bounds_lo(3), box_len(3)
         real(c_double), value :: temperature, translation_step, rotation_step, p_translation
         integer(c_int) :: rc
-        integer :: ia, r, g, per, tot, src, k
+        integer :: ia, r, g, per, tot, src, k, i, lane_first, lane_n
 
         call mfarm_destroy()
         rc = MGPU_OK
@@ -185,21 +200,32 @@ contains
         F%cap_total = tot
         allocate(F%mol(3 + 3 * max_n1, tot, n_replicas), F%energy(5, n_replicas))
         F%n_threads = max(1, int(n_threads))
-        ! first touch by the threads that will gather from it (the mirror is several hundred MB)
-        !$omp parallel do num_threads(F%n_threads) schedule(static) private(ia, k, src)
-        do r = 1, n_replicas
-            F%mol(:, :, r) = 0.0_real64
-            src = 0
-            do ia = 1, n_active
-                do k = 1, n_mol(ia)
-                    F%mol(1:3, F%first(ia) + k, r) = com(:, src + k)
-                    F%mol(4:, F%first(ia) + k, r) = reshape(off(:, :, src + k), [3 * max_n1])
+        ! n_lanes groups of replicas, one per engine lane (<= 0: the default of two)
+        F%n_lanes = n_lanes
+        if (n_lanes <= 0) F%n_lanes = 2
+        F%n_lanes = max(1, min(F%n_lanes, int(MGPU_LANES), int(n_replicas)))
+        per = (n_replicas + F%n_lanes - 1) / F%n_lanes
+        ! First touch of the mirror (several hundred MB) with the loop shape of generate_and_submit -- a static
+        ! split of each lane's chains -- so that a thread gathers from pages on its own NUMA node.
+        do g = 0, F%n_lanes - 1
+            lane_first = min(g * per, int(n_replicas))
+            lane_n = max(0, min(per, int(n_replicas) - g * per))
+            !$omp parallel do num_threads(F%n_threads) schedule(static) private(r, ia, k, src)
+            do i = 1, lane_n
+                r = lane_first + i
+                F%mol(:, :, r) = 0.0_real64
+                src = 0
+                do ia = 1, n_active
+                    do k = 1, n_mol(ia)
+                        F%mol(1:3, F%first(ia) + k, r) = com(:, src + k)
+                        F%mol(4:, F%first(ia) + k, r) = reshape(off(:, :, src + k), [3 * max_n1])
+                    end do
+                    F%cnt(ia, r) = n_mol(ia)
+                    src = src + n_mol(ia)
                 end do
-                F%cnt(ia, r) = n_mol(ia)
-                src = src + n_mol(ia)
             end do
+            !$omp end parallel do
         end do
-        !$omp end parallel do
         do r = 1, n_replicas
             F%energy(:, r) = energy0
         end do
@@ -217,12 +243,7 @@ contains
         F%trials = 0; F%accepted = 0; F%counters = 0; F%skipped = 0; F%ticks = 0
         F%rng_kind = rng_kind
         F%n_threads = max(1, int(n_threads))
-        call seed_farm_rng(int(seed))
-        ! n_lanes groups of replicas, one per engine lane (<= 0: the default of two)
-        F%n_lanes = n_lanes
-        if (n_lanes <= 0) F%n_lanes = 2
-        F%n_lanes = max(1, min(F%n_lanes, int(MGPU_LANES), int(n_replicas)))
-        per = (n_replicas + F%n_lanes - 1) / F%n_lanes
+        call seed_farm_rng(int(seed), int(n_replicas))
         do g = 0, F%n_lanes - 1
             F%lane(g)%first = min(g * per, n_replicas)
             F%lane(g)%n = max(0, min(per, n_replicas - g * per))
@@ -276,6 +297,7 @@ contains
         type(lane_buffers), intent(inout) :: L
         integer, intent(in) :: n, max_n1
         allocate(L%rep(n), L%t(n), L%m(n), L%kind(n), L%accept(n), L%ia(n), L%move(n), L%cidx(n))
+        allocate(L%sel_ia(n), L%sel_mv(n), L%sel_slot(n))
         allocate(L%sites(3, max_n1, n), L%new_com(3, n), L%new_off(3, max_n1, n))
         allocate(L%old_e(5 * n), L%new_e(5 * n), L%u(NRAND, n))
         L%sites = 0.0_real64
@@ -286,10 +308,12 @@ contains
         integer :: g
         if (allocated(F%res_type)) deallocate(F%res_type, F%n1, F%cap, F%first, F%cnt, F%fugacity)
         if (allocated(F%mol)) deallocate(F%mol, F%energy)
+        if (allocated(F%cxs)) deallocate(F%cxs)
         do g = 0, MGPU_LANES - 1
             if (allocated(F%lane(g)%rep)) then
                 deallocate(F%lane(g)%rep, F%lane(g)%t, F%lane(g)%m, F%lane(g)%kind, F%lane(g)%accept, &
-                           F%lane(g)%ia, F%lane(g)%move, F%lane(g)%cidx, F%lane(g)%sites, F%lane(g)%new_com, &
+                           F%lane(g)%ia, F%lane(g)%move, F%lane(g)%cidx, F%lane(g)%sel_ia, F%lane(g)%sel_mv, &
+                           F%lane(g)%sel_slot, F%lane(g)%sites, F%lane(g)%new_com, &
                            F%lane(g)%new_off, F%lane(g)%old_e, F%lane(g)%new_e, F%lane(g)%u)
             end if
         end do
@@ -323,7 +347,7 @@ contains
         integer, intent(in) :: g
         integer(c_int) :: rc
         integer :: i, j, r, ia, slot, n1, axis, d, a, mv, n
-        integer(int64) :: c0, c1, c2, c3, c4, skipped
+        integer(int64) :: c0, c1, c2, c3
         real(real64) :: x, draw, v(3), frac(3)
         type(lane_buffers), pointer :: L
         L => F%lane(g)
@@ -331,14 +355,22 @@ contains
         L%nc = 0
         if (L%n == 0) return
         call system_clock(c0)
-        call farm_random(L%u(:, 1:L%n))
+        ! rng_kind 0: one serial draw from the intrinsic generator, the reference's stream
+        if (F%rng_kind == 0) call random_number(L%u(:, 1:L%n))
         call system_clock(c3)
-        ! pass 0 (serial, cheap): which move each chain attempts (monte_carlo.f90:50-75); chains whose
-        ! selection is a no-op in the reference (empty type, molecule_index = 0) submit nothing
-        j = 0
-        skipped = 0
+        ! One parallel region per lane and step (the fork / join is not free):
+        !   phase 1  per chain: draw its numbers, select the move (monte_carlo.f90:50-75); selections that
+        !            are no-ops in the reference (empty type, molecule_index = 0, rotation of an atom, full
+        !            type) get slot 0;
+        !   phase 2  (one thread) pack the chains that do attempt a move into candidates 1..nc;
+        !   phase 3  per candidate: gather com / offsets from the host mirror -- one contiguous record, the
+        !            random access is DRAM / TLB-latency bound and the threads overlap the misses -- and
+        !            build the move.
+        !$omp parallel num_threads(F%n_threads) private(i, j, n1, d, x, axis, a, r, ia, slot, v, frac, n, mv, draw)
+        !$omp do schedule(static)
         do i = 1, L%n
             r = L%first + i
+            if (F%rng_kind /= 0) call chain_random(r, L%u(:, i))
             ia = min(int(L%u(1, i) * F%n_active) + 1, F%n_active)      ! PickRandomResidueType
             n = F%cnt(ia, r)
             draw = L%u(3, i)
@@ -352,34 +384,34 @@ contains
                 mv = MV_DELETION
             end if
             if (.not. F%gcmc .and. mv > MV_ROTATION) mv = MV_ROTATION
+            slot = 0
             if (mv == MV_ROTATION .and. F%n1(ia) == 1) then
-                if (F%gcmc) then
-                    skipped = skipped + 1                               ! rotation.f90:45 returns
-                    cycle
-                end if
-                mv = MV_TRANSLATION                                     ! NVT farm of atoms: always translate
-            end if
-            if (mv == MV_CREATION) then
-                if (n >= F%cap(ia)) then
-                    skipped = skipped + 1                               ! reference aborts past NB_MAX_MOLECULE
-                    cycle
-                end if
-                slot = n + 1                                            ! monte_carlo.f90:63
+                if (.not. F%gcmc) then
+                    mv = MV_TRANSLATION                                 ! NVT farm of atoms: always translate
+                    if (n > 0) slot = min(int(L%u(2, i) * n) + 1, n)
+                end if                                                  ! GCMC: rotation.f90:45 returns
+            else if (mv == MV_CREATION) then
+                if (n < F%cap(ia)) slot = n + 1                         ! monte_carlo.f90:63; full: the reference aborts
             else
-                if (n == 0) then
-                    skipped = skipped + 1                               ! molecule_index = 0: the drivers return
-                    cycle
-                end if
-                slot = min(int(L%u(2, i) * n) + 1, n)                   ! PickRandomMoleculeIndex
+                if (n > 0) slot = min(int(L%u(2, i) * n) + 1, n)        ! PickRandomMoleculeIndex; 0: the drivers return
             end if
+            L%sel_ia(i) = ia
+            L%sel_mv(i) = mv
+            L%sel_slot(i) = slot
+        end do
+        !$omp end do
+        !$omp single
+        j = 0
+        do i = 1, L%n
+            if (L%sel_slot(i) == 0) cycle
             j = j + 1
             L%cidx(j) = i
-            L%ia(j) = ia
-            L%move(j) = mv
-            L%rep(j) = r - 1
-            L%t(j) = F%res_type(ia)
-            L%m(j) = slot - 1
-            select case (mv)
+            L%ia(j) = L%sel_ia(i)
+            L%move(j) = L%sel_mv(i)
+            L%rep(j) = L%first + i - 1
+            L%t(j) = F%res_type(L%sel_ia(i))
+            L%m(j) = L%sel_slot(i) - 1
+            select case (L%sel_mv(i))
             case (MV_CREATION)
                 L%kind(j) = MGPU_CREATION
             case (MV_DELETION)
@@ -389,14 +421,9 @@ contains
             end select
         end do
         L%nc = j
-        F%skipped = F%skipped + skipped
-        call system_clock(c4)
-        F%ticks(6) = F%ticks(6) + (c3 - c0)
-        F%ticks(7) = F%ticks(7) + (c4 - c3)
-        ! pass 1 (one parallel region per lane and step: the fork/join is not free): gather com /
-        ! offsets from the host mirror -- one contiguous record, the random access is DRAM/TLB-latency
-        ! bound and the threads overlap the misses -- then build the move
-        !$omp parallel do num_threads(F%n_threads) schedule(static) private(i, n1, d, x, axis, a, r, ia, slot, v, frac)
+        F%skipped = F%skipped + (L%n - j)
+        !$omp end single
+        !$omp do schedule(static)
         do j = 1, L%nc
             i = L%cidx(j)
             r = L%rep(j) + 1
@@ -458,7 +485,8 @@ contains
                 L%sites(:, a, j) = L%new_com(:, j) + L%new_off(:, a, j)
             end do
         end do
-        !$omp end parallel do
+        !$omp end do
+        !$omp end parallel
         call system_clock(c1)
         if (L%nc > 0) then
             if (F%gcmc) then
@@ -472,6 +500,7 @@ contains
         call system_clock(c2)
         F%ticks(1) = F%ticks(1) + (c1 - c0)
         F%ticks(2) = F%ticks(2) + (c2 - c1)
+        F%ticks(6) = F%ticks(6) + (c3 - c0)                 ! serial draw of the intrinsic generator (rng_kind 0)
     end function generate_and_submit
 
     !---------------------------------------------------------------------------
