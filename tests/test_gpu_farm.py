@@ -144,3 +144,26 @@ def test_gcmc_farm_in_a_triclinic_box():
                 com, off = farm.molecule(r, ia, slot)
                 assert np.array_equal(dev[slot], com[None, :] + off[: dev.shape[1]])
     farm.close()
+
+
+def test_farm_at_benchmark_size_three_lanes():
+    """The bench workload itself (3375 SPC/E, N = 10 125, Nk = 2242) in miniature: 48 chains on three lanes,
+    150 steps; every chain's running energy equals a from-scratch evaluation of its final configuration and
+    A(k) equals a fresh S(k) -- the size-independent invariant of the whole submit / wait / commit pipeline."""
+    from maniac_mc_amd.fortran_host import FortranFarm
+    s = synth.spce_box(15)
+    R, steps = 48, 150
+    farm = FortranFarm(s, R, seed=29, translation_step=0.3, rotation_step=0.3, n_threads=4, n_lanes=3)
+    assert farm.n_lanes == 3
+    acc = farm.run(steps)
+    assert farm.trials == R * steps and 0.4 * farm.trials < acc < 0.95 * farm.trials
+    eng = farm.eng
+    for r in (0, 15, 16, 31, 32, R - 1):          # first / last chain of every lane
+        e = eng.system_energy(r)
+        run = farm.energy(r)
+        tol = TOL_K + 64 * np.finfo(float).eps * max(abs(e["recip_coulomb"]), abs(e["coulomb"])) * np.sqrt(steps)
+        assert abs(run[0] - e["non_coulomb"]) < tol and abs(run[1] - e["coulomb"]) < tol and abs(run[2] - e["recip_coulomb"]) < tol
+        A = eng.structure_factor(r)
+        eng.init_structure_factor(r, True)
+        assert np.max(np.abs(A - eng.structure_factor(r))) < 1e-9
+    farm.close()
