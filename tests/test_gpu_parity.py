@@ -343,3 +343,55 @@ def test_per_k_reciprocal_kernel():
                         "test_engine_vs_golden and (co2_20 or mixture)"], capture_output=True, text=True, env=env,
                        cwd=root, timeout=900)
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+def test_maximum_molecule_count(refcpu_mod):
+    """NB_MAX_MOLECULE = 5000 molecules of one residue type (src/parameters.f90:8), the reference's hard limit:
+    fill a 4913-molecule SPC/E box up to 5000 by committed insertions, check trial energies of the full box
+    against the oracle, and that molecule 5001 is refused."""
+    from maniac_mc_amd.system import NB_MAX_MOLECULE
+    rng = np.random.default_rng(11)
+    s = synth.spce_box(17, seed=31)
+    n0 = int(s.n_mol[0])
+    assert n0 == 4913
+    eng = Engine.from_system(s, n_replicas=1, mol_capacity=[NB_MAX_MOLECULE])
+    eng.init_structure_factor(0, True)
+    P = refcpu_mod.RefCPU(s, mol_capacity=NB_MAX_MOLECULE)
+    P.system_energy(); P.init_amplitude(True)
+    L = float(s.box_matrix[0, 0])
+    tmpl = s.offsets[0][0]
+    placed = s.com[0].copy()
+    for k in range(NB_MAX_MOLECULE - n0):
+        while True:                                         # roomy spots only: an overlap costs 1e7 K and its rounding
+            com = s.bounds_lo + rng.uniform(0.0, 1.0, 3) * L
+            d = placed - com[None, :]
+            d -= L * np.rint(d / L)
+            if np.min(np.einsum("ij,ij->i", d, d)) > 2.6 ** 2:
+                break
+        placed = np.vstack([placed, com[None, :]])
+        sites = (com[None, :] + tmpl @ P.rotation_matrix(int(rng.integers(1, 4)), float(rng.uniform(0, 6.28))).T)[None]
+        eng.commit_candidates([0], [0], [-1], [MGPU_CREATION], sites, [1])
+        slot = n0 + k
+        P.set_num_residues(0, slot + 1)
+        P.save_fourier(0, slot)
+        P.set_molecule(0, slot, sites[0, 0], sites[0] - sites[0, 0][None, :])
+        P.new_energy(0, slot, 1)                            # SingleMolFourierTerms + the creation update of A(k)
+    assert eng.num_molecules(0, 0) == NB_MAX_MOLECULE
+    amp_close(eng.structure_factor(0), P.amplitude(), "A(k) of the full box")
+    with pytest.raises(_lib.MgpuError) as ei:
+        eng.commit_candidates([0], [0], [-1], [MGPU_CREATION], sites, [1])
+    assert ei.value.code == 3
+    # trial moves of the first, a middle and the LAST molecule of the full box
+    for m in (0, 2500, NB_MAX_MOLECULE - 1):
+        com, off = P.get_molecule(0, m)
+        new_sites = (P.apply_pbc(com + rng.uniform(-0.3, 0.3, 3))[None, :] + off)[None]
+        old, new = eng.trial_energy_candidates([0], [0], [m], new_sites)
+        P.save_fourier(0, m)
+        exp_old = P.old_energy(0, m, 0)[:3]
+        P.set_molecule(0, m, new_sites[0, 0], new_sites[0] - new_sites[0, 0][None, :])
+        exp_new = P.new_energy(0, m, 0)[:3]
+        P.set_molecule(0, m, com, off)
+        P.restore_fourier(0, m)
+        close(old[0], exp_old, f"full box, molecule {m}, old")
+        close(new[0], exp_new, f"full box, molecule {m}, new")
+    eng.close()
