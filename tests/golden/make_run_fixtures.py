@@ -61,6 +61,15 @@ def cases():
               rotation_proba=0.3, insertion_deletion_proba=0.4, fugacity_atm=[20.0], recalibrate_moves=True,
               masses=[14.0067], atom_names=["N"])
     yield "dumbbell_gcmc", d, kw, None
+    tri = synth.spce_box(n_side=4, rc=5.5, seed=77)
+    tri.box_matrix[1, 0], tri.box_matrix[2, 0], tri.box_matrix[2, 1] = 0.8, -0.5, 0.4      # xy, xz, yz (readers_utils.f90:242-245)
+    yield "spce_triclinic_nvt", tri, dict(nb_block=3, nb_step=200, translation_step=0.3, rotation_step_angle=0.3,
+                                          translation_proba=0.5, rotation_proba=0.5, recalibrate_moves=False,
+                                          masses=[15.9994, 1.008], atom_names=["OW", "HW"]), None
+    fw = synth.framework_water_box(n_water=12, n_frame=150, L=21.0, seed=4, rc=9.0)
+    yield "framework_water_nvt", fw, dict(nb_block=3, nb_step=150, translation_step=0.3, rotation_step_angle=0.3,
+                                          translation_proba=0.5, rotation_proba=0.5, recalibrate_moves=False,
+                                          masses=[12.0] * 7 + [15.9994, 1.008, 1e-4], fugacity_atm=[1.0, 1.0]), None
     yield "dumbbell_gcmc_reservoir", d, kw, dumbbell_box(n_mol=40, L=30.0, seed=9)
 
 
