@@ -124,3 +124,33 @@ def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoi
     keys = ("non_coulomb", "coulomb", "recip_coulomb", "ewald_self", "intra_coulomb", "total")
     return dict(energy=dict(zip(keys, e)), recomputed_energy=e_final, counters=cnt, n_mol=nm,
                 translation_step=st[0], rotation_step=st[1])
+
+
+def main(argv=None):
+    """`python -m maniac_mc_amd.run -i input.maniac -d topology.data -p parameters.inc [-r reservoir.data] [-o outputs/]`
+    -- the reference's command line (cli_utils.f90:36-83: -i, -d, -p mandatory, -r optional, -o defaults to
+    outputs/), plus --seed and --device."""
+    import argparse
+    import sys
+    ap = argparse.ArgumentParser(prog="python -m maniac_mc_amd.run", description=main.__doc__)
+    ap.add_argument("-i", dest="maniac", required=True, help="MANIAC input file")
+    ap.add_argument("-d", dest="data", required=True, help="LAMMPS data file (atom_style full)")
+    ap.add_argument("-p", dest="inc", required=True, help="pair_coeff include file")
+    ap.add_argument("-r", dest="reservoir", default=None, help="reservoir data file")
+    ap.add_argument("-o", dest="out", default="outputs/", help="output directory")
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    for path, what in ((a.maniac, "Input"), (a.data, "Data"), (a.inc, "Parameter"), (a.reservoir, "Reservoir")):
+        if path is not None and not os.path.isfile(path):
+            print(f"{what} file not found: {path}", file=sys.stderr)
+            return 1
+    res = run_simulation(a.maniac, a.data, a.inc, a.out, seed=a.seed, reservoir_path=a.reservoir, device=a.device)
+    e = res["energy"]
+    print(f"final energy (K): total {e['total']:.6f}  non_coulomb {e['non_coulomb']:.6f}  coulomb {e['coulomb']:.6f}  "
+          f"recip {e['recip_coulomb']:.6f};  molecules {res['n_mol'].tolist()};  output in {os.path.join(a.out, '')}")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
