@@ -34,7 +34,8 @@ module mc_chain
     private
     public :: mchain_reset, mchain_set_box, mchain_set_residue, mchain_set_bonded, mchain_set_tables, &
               mchain_set_moves, mchain_set_reservoir_box, mchain_set_reservoir_residue, mchain_run, &
-              mchain_get_energy, mchain_get_counters, mchain_get_counts, mchain_get_molecule, mchain_get_steps
+              mchain_get_energy, mchain_get_counters, mchain_get_counts, mchain_get_molecule, mchain_get_steps, &
+              mchain_set_mode
 
     real(real64), parameter :: PI = 3.14159265358979323846_real64, TWOPI = 2.0_real64 * PI
     real(real64), parameter :: zero = 0.0_real64, one = 1.0_real64, half = 0.5_real64, three = 3.0_real64
@@ -49,6 +50,9 @@ module mc_chain
 
     type(chain_block), save, target :: S
     integer, save :: status = 0          ! first engine error met (0 = none); the loop stops on it
+    ! .true.: one batched engine call per move (mgpu_gcmc_trial_submit / wait with one candidate, resident-row
+    ! commit) instead of one call per reference seam -- same energies, a third of the launches and waits
+    logical, save :: fused = .true.
 
 contains
 
@@ -328,6 +332,65 @@ contains
         end if
     end subroutine molecule_energy
 
+    ! seams /= 0: call the reference-named seams one by one (the literal integration of INTEGRATION.md section 3)
+    subroutine mchain_set_mode(seams) bind(C, name="mchain_set_mode")
+        integer(c_int), value :: seams
+        fused = seams == 0
+    end subroutine mchain_set_mode
+
+    !---------------------------------------------------------------------------
+    ! Both energy states of a move from ONE engine call (fused mode): the candidate's sites are the
+    ! molecule's current com + offsets in the host state; `old` / `new` are filled exactly as
+    ! ComputeOldEnergy / ComputeNewEnergy fill them for that move type.
+    !---------------------------------------------------------------------------
+    subroutine fused_energies(t, m, kind, old, new)
+        integer, intent(in) :: t, m, kind
+        real(real64), intent(out) :: old(6), new(6)
+        integer :: n1
+        integer(c_int) :: rep(1), tt(1), mm(1), kk(1), rc
+        real(real64) :: o(5), w(5)
+        real(real64), allocatable :: sites(:, :)
+        n1 = S%res(t)%n1
+        allocate(sites(3, n1))
+        call MoleculeSites(S%res(t)%com(:, m), S%res(t)%off(:, 1:n1, m), n1, sites)
+        rep = 0; tt = t - 1; mm = m - 1; kk = int(kind, c_int)
+        if (kind == MGPU_CREATION) mm = -1
+        rc = mgpu_gcmc_trial_submit(S%engine, 0_c_int, 1_c_int, rep, tt, mm, kk, sites, int(n1, c_int))
+        if (rc == MGPU_OK) rc = mgpu_gcmc_trial_wait(S%engine, 0_c_int, o, w)
+        call note(int(rc))
+        old = zero
+        new = zero
+        select case (kind)
+        case (MGPU_CREATION)
+            old(IE_RECIP) = S%energy(IE_RECIP)
+            new(1:5) = w
+        case (MGPU_DELETION)
+            old(1:5) = o
+            old(IE_RECIP) = S%energy(IE_RECIP)
+            new(IE_RECIP) = w(IE_RECIP)
+        case default
+            old(1:3) = o(1:3)
+            new(1:3) = w(1:3)
+        end select
+        if (kind == MGPU_MOVE) then
+            old(IE_TOTAL) = old(IE_NONC) + old(IE_COUL) + old(IE_RECIP)
+            new(IE_TOTAL) = new(IE_NONC) + new(IE_COUL) + new(IE_RECIP)
+        else
+            old(IE_TOTAL) = old(IE_NONC) + old(IE_COUL) + old(IE_RECIP) + old(IE_SELF) + old(IE_INTRA)
+            new(IE_TOTAL) = new(IE_NONC) + new(IE_COUL) + new(IE_RECIP) + new(IE_SELF) + new(IE_INTRA)
+        end if
+    end subroutine fused_energies
+
+    ! apply the move the lane has just evaluated (fused mode): the rows are still on the device
+    subroutine fused_commit(t, m, kind)
+        integer, intent(in) :: t, m, kind
+        integer(c_int) :: rep(1), tt(1), mm(1), kk(1), acc(1), rc
+        rep = 0; tt = t - 1; mm = m - 1; kk = int(kind, c_int); acc = 1
+        if (kind == MGPU_CREATION) mm = -1
+        rc = mgpu_commit_submit(S%engine, 0_c_int, 1_c_int, rep, tt, mm, kk, c_null_ptr, int(S%res(t)%n1, c_int), acc)
+        call note(int(rc))
+    end subroutine fused_commit
+
     function acceptance_probability(old, new, t, move_type) result(p)
         real(real64), intent(in) :: old(6), new(6)
         integer, intent(in) :: t, move_type
@@ -358,8 +421,12 @@ contains
         S%energy(IE_TOTAL) = S%energy(IE_TOTAL) + new(IE_TOTAL) - old(IE_TOTAL)
         S%counter(which) = S%counter(which) + 1
         n1 = S%res(t)%n1
-        call GpuAcceptMove(S%engine, t, m, MGPU_MOVE, S%res(t)%com(:, m), S%res(t)%off(:, 1:n1, m), n1, stat=stat)
-        call note(stat)
+        if (fused) then
+            call fused_commit(t, m, MGPU_MOVE)
+        else
+            call GpuAcceptMove(S%engine, t, m, MGPU_MOVE, S%res(t)%com(:, m), S%res(t)%off(:, 1:n1, m), n1, stat=stat)
+            call note(stat)
+        end if
     end subroutine accept_move
 
     subroutine translation(t, m)
@@ -368,12 +435,16 @@ contains
         if (m == 0) return
         S%counter(C_TRIAL_T) = S%counter(C_TRIAL_T) + 1
         com_old = S%res(t)%com(:, m)
-        call molecule_energy(t, m, old, .false., .false., .false.)
+        if (.not. fused) call molecule_energy(t, m, old, .false., .false., .false.)
         call random_number(trial)
         trial = (trial - half) * S%translation_step
         S%res(t)%com(:, m) = S%res(t)%com(:, m) + trial
         call apply_pbc(S%res(t)%com(:, m), S%box)
-        call molecule_energy(t, m, new, .false., .false., .true.)
+        if (fused) then
+            call fused_energies(t, m, MGPU_MOVE, old, new)
+        else
+            call molecule_energy(t, m, new, .false., .false., .true.)
+        end if
         p = acceptance_probability(old, new, t, TYPE_TRANSLATION)
         if (rand_uniform() <= p) then
             call accept_move(t, m, old, new, C_T)
@@ -389,9 +460,13 @@ contains
         if (S%res(t)%n1 == 1 .or. m == 0) return
         S%counter(C_TRIAL_R) = S%counter(C_TRIAL_R) + 1
         off_old = S%res(t)%off(:, :, m)
-        call molecule_energy(t, m, old, .false., .false., .false.)
+        if (.not. fused) call molecule_energy(t, m, old, .false., .false., .false.)
         call random_rotation(t, m, .false.)
-        call molecule_energy(t, m, new, .false., .false., .true.)
+        if (fused) then
+            call fused_energies(t, m, MGPU_MOVE, old, new)
+        else
+            call molecule_energy(t, m, new, .false., .false., .true.)
+        end if
         p = acceptance_probability(old, new, t, TYPE_ROTATION)
         if (rand_uniform() <= p) then
             call accept_move(t, m, old, new, C_R)
@@ -410,7 +485,7 @@ contains
             return
         end if
         S%counter(C_TRIAL_C) = S%counter(C_TRIAL_C) + 1
-        call molecule_energy(t, m, old, .true., .false., .false.)
+        if (.not. fused) call molecule_energy(t, m, old, .true., .false., .false.)
         S%res(t)%count = S%res(t)%count + 1
         S%box%num_atoms = S%box%num_atoms + n1
         ! InsertAndOrientMolecule
@@ -425,7 +500,11 @@ contains
             S%res(t)%off(:, 1:n1, m) = S%res(t)%off(:, 1:n1, 1)
             call random_rotation(t, m, .true.)
         end if
-        call molecule_energy(t, m, new, .true., .false., .true.)
+        if (fused) then
+            call fused_energies(t, m, MGPU_CREATION, old, new)
+        else
+            call molecule_energy(t, m, new, .true., .false., .true.)
+        end if
         p = acceptance_probability(old, new, t, TYPE_CREATION)
         if (rand_uniform() <= p) then
             S%energy(IE_RECIP) = new(IE_RECIP)
@@ -435,8 +514,12 @@ contains
             S%energy(IE_INTRA) = S%energy(IE_INTRA) + new(IE_INTRA) - old(IE_INTRA)
             S%energy(IE_TOTAL) = S%energy(IE_TOTAL) + new(IE_TOTAL) - old(IE_TOTAL)
             S%counter(C_C) = S%counter(C_C) + 1
-            call GpuAcceptMove(S%engine, t, m, MGPU_CREATION, S%res(t)%com(:, m), S%res(t)%off(:, 1:n1, m), n1, stat=stat)
-            call note(stat)
+            if (fused) then
+                call fused_commit(t, m, MGPU_CREATION)
+            else
+                call GpuAcceptMove(S%engine, t, m, MGPU_CREATION, S%res(t)%com(:, m), S%res(t)%off(:, 1:n1, m), n1, stat=stat)
+                call note(stat)
+            end if
             if (S%has_reservoir) then
                 ! the copied molecule leaves the reservoir: its slot takes the reservoir's last molecule
                 last = S%rsv(t)%count
@@ -459,13 +542,17 @@ contains
         if (S%res(t)%count == 0) return
         n1 = S%res(t)%n1
         S%counter(C_TRIAL_D) = S%counter(C_TRIAL_D) + 1
-        call molecule_energy(t, m, old, .false., .true., .false.)
+        if (.not. fused) call molecule_energy(t, m, old, .false., .true., .false.)
         com_old = S%res(t)%com(:, m)
         off_old = S%res(t)%off(:, :, m)
         last = S%res(t)%count
         ! the engine evaluates the removal of the molecule that sits in slot m, so the new energy is
         ! taken before the host mirror is compacted (RemoveMolecule in the reference comes first)
-        call molecule_energy(t, m, new, .false., .true., .true.)
+        if (fused) then
+            call fused_energies(t, m, MGPU_DELETION, old, new)
+        else
+            call molecule_energy(t, m, new, .false., .true., .true.)
+        end if
         off_last = S%res(t)%off(:, :, last)
         S%res(t)%com(:, m) = S%res(t)%com(:, last)
         S%res(t)%off(:, :, m) = S%res(t)%off(:, :, last)
@@ -480,8 +567,12 @@ contains
             S%energy(IE_INTRA) = S%energy(IE_INTRA) + new(IE_INTRA) - old(IE_INTRA)
             S%energy(IE_TOTAL) = S%energy(IE_TOTAL) + new(IE_TOTAL) - old(IE_TOTAL)
             S%counter(C_D) = S%counter(C_D) + 1
-            call GpuAcceptMove(S%engine, t, m, MGPU_DELETION, com_old, off_old(:, 1:n1), n1, stat=stat)
-            call note(stat)
+            if (fused) then
+                call fused_commit(t, m, MGPU_DELETION)
+            else
+                call GpuAcceptMove(S%engine, t, m, MGPU_DELETION, com_old, off_old(:, 1:n1), n1, stat=stat)
+                call note(stat)
+            end if
             if (S%has_reservoir) then
                 ! the reservoir receives the geometry stored in the primary box's last slot, at a random place
                 call random_number(trial)
@@ -614,6 +705,7 @@ contains
             call log_status(S)
             call update_files(S, .true.)
         end do
+        call note(int(mgpu_synchronize(S%engine)))
         ! a Fortran do variable ends one past its limit: FinalReport prints nb_block + 1
         if (status == 0) S%current_block = nb_block + 1
         call log_final_report(S)

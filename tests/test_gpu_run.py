@@ -18,8 +18,9 @@ SUMMARY = json.load(open(os.path.join(RUNS, "summary.json")))
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("seams", [False, True], ids=["fused", "seams"])
 @pytest.mark.parametrize("case", sorted(SUMMARY))
-def test_run_writes_the_reference_files(case, tmp_path):
+def test_run_writes_the_reference_files(case, seams, tmp_path):
     from maniac_mc_amd import run
     inputs = os.path.join(RUNS, case, "inputs")
     expected = os.path.join(RUNS, case, "expected")
@@ -27,7 +28,7 @@ def test_run_writes_the_reference_files(case, tmp_path):
     reservoir = os.path.join(inputs, "reservoir.data") if SUMMARY[case]["reservoir"] else None
     res = run.run_simulation(os.path.join(inputs, "system.maniac"), os.path.join(inputs, "system.data"),
                              os.path.join(inputs, "system.inc"), out, seed=SUMMARY[case]["seed"],
-                             reservoir_path=reservoir)
+                             reservoir_path=reservoir, seams=seams)
     # running energies of the chain == a full recomputation of the final configuration
     for k, v in res["energy"].items():
         assert abs(v - res["recomputed_energy"][k]) <= 1e-9 * max(1.0, abs(v)) + 50 * TOL_K, k

@@ -101,5 +101,5 @@ def test_fortran_host_library_exports():
                  "mfarm_get_molecule", "mfarm_get_counts", "mfarm_get_counters", "mfarm_get_timers", "mfarm_recalibrate",
                  "mchain_reset", "mchain_set_box", "mchain_set_residue", "mchain_set_bonded", "mchain_set_tables",
                  "mchain_set_moves", "mchain_set_reservoir_box", "mchain_set_reservoir_residue", "mchain_run",
-                 "mchain_get_energy", "mchain_get_counters", "mchain_get_counts", "mchain_get_steps", "mchain_get_molecule"):
+                 "mchain_set_mode", "mchain_get_energy", "mchain_get_counters", "mchain_get_counts", "mchain_get_steps", "mchain_get_molecule"):
         assert hasattr(H, name), name
