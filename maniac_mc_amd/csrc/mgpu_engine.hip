@@ -78,9 +78,10 @@ struct Lane {
     std::vector<Pending> pending;
     int n_submitted = 0;          // candidates of the trial in flight (0 = none)
     int last_trial_n = 0, last_trial_stride = 0;   // shape of the site rows still resident in d_sites
-    int n_pair_items = 0;
+    int n_pair_items = 0, n_split = 1;
     std::vector<int> pair_old, pair_new, intra_idx, kinds;   // per-candidate rows of the trial in flight
     std::vector<double> self_of;                              // per-candidate Ewald self term (host constant)
+    std::vector<double> h_lj, h_cc;                           // pair energies of the trial being collected
     void release() {
         d_items.release(); d_items2.release(); d_sites.release(); d_partials.release(); d_out.release();
         h_in.release(); h_commit.release(); h_out.release();
@@ -235,11 +236,15 @@ int upload_sites(mgpu_engine *e, const double *sites, int n_rows, int site_strid
 
 // launch the pair sweep + finalize for items already on the device; results land in d_lj / d_c.
 // common_n1 = number of sites when every item has the same count (register path for <= 4), else 0.
+// host_partials != nullptr: the split partials are written there and NOT reduced on the device (the caller
+// copies them out with its results and adds them up in the same order on the host: one launch and one
+// inter-kernel gap less per batch; d_lj / d_c are unused).
 int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, int common_n1, int site_stride,
-                int nsplit, double *d_lj, double *d_c, bool ordered = false) {
+                int nsplit, double *d_lj, double *d_c, bool ordered = false, double2 *host_partials = nullptr) {
     const int n_work = n_items * nsplit;
-    int rc = ln.d_partials.reserve((size_t)n_work * sizeof(double2));
-    if (rc) return rc;
+    int rc = MGPU_OK;
+    if (!host_partials && (rc = ln.d_partials.reserve((size_t)n_work * sizeof(double2)))) return rc;
+    double2 *d_part = host_partials ? host_partials : (double2 *)ln.d_partials.p;
     // persistent waves: at most 3 workgroups of 8 waves per CU (LDS: 3 x ~31 KiB), never more
     // workgroups than there is work for
     int per_cu = e->pair_blocks_per_cu;
@@ -251,7 +256,7 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
 #define MGPU_LAUNCH_PAIR(NS, ORD, TRI)                                                                                  \
     hipExtLaunchKernelGGL((pair_sweep_kernel<NS, ORD, TRI>), dim3(grid), dim3(kPairBlock), e->coul_bytes, ln.stream,    \
                           a, b, 0, e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab,     \
-                       d_items, (const double *)ln.d_sites.p, site_stride, nsplit, n_work, (double2 *)ln.d_partials.p)
+                       d_items, (const double *)ln.d_sites.p, site_stride, nsplit, n_work, d_part)
     if (e->bx.triclinic) {
         if (ordered) MGPU_LAUNCH_PAIR(0, true, true);
         else MGPU_LAUNCH_PAIR(0, false, true);
@@ -273,8 +278,9 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
     //  agent-scope fences, and on the 8-XCD part those write back / invalidate the XCD's L2 -- measured:
     //  pair sweep 110 -> 275 us.  Likewise results are copied out once rather than stored by the kernels
     //  into pinned host memory: thousands of 8-byte PCIe writes were 3-7x slower than the blit.)
-    hipLaunchKernelGGL(pair_finalize_kernel, dim3((n_items + 255) / 256), dim3(256), 0, ln.stream,
-                       (const double2 *)ln.d_partials.p, n_items, nsplit, d_lj, d_c);
+    if (!host_partials)
+        hipLaunchKernelGGL(pair_finalize_kernel, dim3((n_items + 255) / 256), dim3(256), 0, ln.stream,
+                           (const double2 *)ln.d_partials.p, n_items, nsplit, d_lj, d_c);
     HIP_TRY(hipGetLastError());
     return MGPU_OK;
 }
@@ -933,7 +939,10 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     }
     std::memcpy(h_sites, sites, site_bytes);
     const size_t iit_bytes = (size_t)n_intra * sizeof(PairItem);
-    const size_t out_doubles = 2 * (size_t)n_pair + 3 * (size_t)n;
+    // results in device memory, copied out once: [split partials of the pair sweep (n_pair * nsplit complex-sized
+    // records, reduced on the host in trial_wait) | u_old | u_new | intra]
+    const int nsplit = n_pair ? choose_nsplit(e, n_pair, replica[0]) : 1;
+    const size_t out_doubles = 2 * (size_t)n_pair * nsplit + 3 * (size_t)n;
     // one staging block [sites | pair items (2n slots) | recip items | intra items] -> one H2D copy
     const size_t in_bytes = site_bytes + pit_cap + rit_bytes + iit_bytes;
     if ((rc = ln.d_sites.reserve(site_bytes + pit_cap + rit_bytes + iit_cap))) return rc;
@@ -943,10 +952,11 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     const PairItem *d_pit = (const PairItem *)((char *)ln.d_sites.p + site_bytes);
     const RecipItem *d_rit = (const RecipItem *)((char *)ln.d_sites.p + site_bytes + pit_cap);
     const PairItem *d_iit = (const PairItem *)((char *)ln.d_sites.p + site_bytes + pit_cap + rit_bytes);
-    double *d_lj = (double *)ln.d_out.p, *d_c = d_lj + n_pair, *d_uo = d_c + n_pair, *d_un = d_uo + n, *d_in = d_un + n;
+    double2 *d_part = (double2 *)ln.d_out.p;
+    double *d_uo = (double *)ln.d_out.p + 2 * (size_t)n_pair * nsplit, *d_un = d_uo + n, *d_in = d_un + n;
     if (n_pair) {
-        const int nsplit = choose_nsplit(e, n_pair, replica[0]);
-        if ((rc = launch_pair(e, ln, d_pit, n_pair, std::max(common, 0), site_stride, nsplit, d_lj, d_c))) return rc;
+        if ((rc = launch_pair(e, ln, d_pit, n_pair, std::max(common, 0), site_stride, nsplit, nullptr, nullptr, false, d_part)))
+            return rc;
     }
     if ((rc = launch_recip(e, ln, d_rit, n, n1_max, site_stride, false, e->d_A, d_un, d_uo)))
         return rc;
@@ -958,6 +968,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     HIP_TRY(hipMemcpyAsync(ln.h_out.p, ln.d_out.p, out_doubles * sizeof(double), hipMemcpyDeviceToHost, ln.stream));
     ln.n_submitted = n;
     ln.n_pair_items = n_pair;
+    ln.n_split = nsplit;
     ln.last_trial_n = n;
     ln.last_trial_stride = site_stride;
     return MGPU_OK;
@@ -970,9 +981,21 @@ static int trial_wait_impl(mgpu_engine *e, Lane &ln, double *old_energy, double 
     ln.n_submitted = 0;
     int rc = sync_lane(e, ln);
     if (rc) return rc;
-    const int np = ln.n_pair_items;
+    const int np = ln.n_pair_items, ns = ln.n_split;
     const double *h = (const double *)ln.h_out.p;
-    const double *lj = h, *cc = h + np, *uo = cc + np, *un = uo + n, *in = un + n;
+    const double *uo = h + 2 * (size_t)np * ns, *un = uo + n, *in = un + n;
+    // the ordered sum of the split partials and the Coulomb rescale e_coulomb * EPS0_INV_eVA / KB_eVK
+    // (energy_utils.f90:440), exactly as pair_finalize_kernel does them
+    ln.h_lj.resize(np);
+    ln.h_cc.resize(np);
+    for (int i = 0; i < np; ++i) {
+        double a = 0.0, b = 0.0;
+        const double *p = h + 2 * (size_t)i * ns;
+        for (int s2 = 0; s2 < ns; ++s2) { a += p[2 * s2]; b += p[2 * s2 + 1]; }
+        ln.h_lj[i] = a;
+        ln.h_cc[i] = b * kEps0InvEvA / kKbEvK;
+    }
+    const double *lj = ln.h_lj.data(), *cc = ln.h_cc.data();
     for (int c = 0; c < n; ++c) {
         double *o = old_energy + (size_t)ncomp * c, *w = new_energy + (size_t)ncomp * c;
         for (int k = 0; k < ncomp; ++k) { o[k] = 0.0; w[k] = 0.0; }
