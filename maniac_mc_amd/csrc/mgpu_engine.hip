@@ -79,6 +79,9 @@ struct Lane {
     int n_submitted = 0;          // candidates of the trial in flight (0 = none)
     int last_trial_n = 0, last_trial_stride = 0;   // shape of the site rows still resident in d_sites
     int n_pair_items = 0, n_split = 1;
+    const RecipItem *d_trial_items = nullptr;   // RecipItems of the last trial, resident while last_trial_n != 0
+    const RecipItem *h_trial_items = nullptr;   // their host image in h_in (valid until the next trial_submit)
+    int trial_n1_max = 1;
     std::vector<int> pair_old, pair_new, intra_idx, kinds;   // per-candidate rows of the trial in flight
     std::vector<double> self_of;                              // per-candidate Ewald self term (host constant)
     std::vector<double> h_lj, h_cc;                           // pair energies of the trial being collected
@@ -307,11 +310,21 @@ size_t recip_rows_lds_bytes(const mgpu_engine *e, int n1_max) {
 }
 
 // d_u_old != nullptr: also return the energy of the unchanged A(k) from the same pass (trial moves)
-int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items, int n1_max, int site_stride,
-                 bool commit, double2 *A_base, double *d_u, double *d_u_old = nullptr) {
-    // row form while its XY table fits the LDS budget (molecules of a few sites), else the per-k form
+// row form while its XY table fits the LDS budget (molecules of a few sites), else the per-k form
+bool recip_by_rows(const mgpu_engine *e, int n1_max) {
     static const bool force_per_k = getenv("MGPU_RECIP_PER_K") != nullptr;
-    const bool by_rows = !force_per_k && e->n_rtasks > 0 && recip_rows_lds_bytes(e, n1_max) <= 40 * 1024;
+    return !force_per_k && e->n_rtasks > 0 && recip_rows_lds_bytes(e, n1_max) <= 40 * 1024;
+}
+
+// accept != nullptr (commit, row form only): d_items are the candidates of the lane's last trial and only
+// those whose bit is set are applied
+int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items, int n1_max, int site_stride,
+                 bool commit, double2 *A_base, double *d_u, double *d_u_old = nullptr, const AcceptBits *accept = nullptr) {
+    const bool by_rows = recip_by_rows(e, n1_max);
+    static const AcceptBits no_bits{};
+    const AcceptBits &bits = accept ? *accept : no_bits;
+    const int use_accept = accept ? 1 : 0;
+    if (accept && !by_rows) return set_error(MGPU_ERR_STATE, "commit by accept mask needs the row-form kernel");
     const size_t lds = by_rows ? recip_rows_lds_bytes(e, n1_max) : recip_lds_bytes(e, n1_max);
     if (lds > 64 * 1024)
         return set_error(MGPU_ERR_CAPACITY, "reciprocal update: molecule too large for the LDS phase tables (" +
@@ -325,7 +338,8 @@ int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items
         if (by_rows)                                                                                                 \
             hipExtLaunchKernelGGL((recip_rows_kernel<COMMIT, BOTH>), dim3(n_items), dim3(kBlock), lds, ln.stream, a, b, \
                                   0, e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_rtasks, e->n_rtasks, e->d_rrows, e->n_rrows, \
-                               e->d_kw, A_base, d_items, (const double *)ln.d_sites.p, site_stride, d_u, d_u_old);      \
+                               e->d_kw, A_base, d_items, (const double *)ln.d_sites.p, site_stride, d_u, d_u_old,      \
+                                  bits, use_accept);                                                                \
         else                                                                                                         \
             hipExtLaunchKernelGGL((recip_kernel<COMMIT, BOTH>), dim3(n_items), dim3(kBlock), lds, ln.stream, a, b, 0,   \
                                   e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_kpack, e->d_kw, A_base, d_items,            \
@@ -971,6 +985,9 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     ln.n_split = nsplit;
     ln.last_trial_n = n;
     ln.last_trial_stride = site_stride;
+    ln.d_trial_items = d_rit;
+    ln.h_trial_items = rit;
+    ln.trial_n1_max = n1_max;
     return MGPU_OK;
 }
 
@@ -1058,16 +1075,34 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
     }
     if (n_items == 0) return MGPU_OK;
     if (any_sites && !sites && !reuse_sites) return set_error(MGPU_ERR_INVALID_ARG, "commit_candidates: sites is null");
-    if ((rc = ln.d_items2.reserve((size_t)n_items * sizeof(RecipItem)))) return rc;
-    HIP_TRY(hipMemcpyAsync(ln.d_items2.p, items, (size_t)n_items * sizeof(RecipItem), hipMemcpyHostToDevice, ln.stream));
-    if (any_sites && sites) {
-        ln.last_trial_n = 0;
-        std::memcpy(ln.h_commit.p, sites, site_bytes);
-        if ((rc = ln.d_sites.reserve(site_bytes))) return rc;
-        HIP_TRY(hipMemcpyAsync(ln.d_sites.p, ln.h_commit.p, site_bytes, hipMemcpyHostToDevice, ln.stream));
+    // Committing the lane's last trial from its resident rows: the trial's items are still on the device too,
+    // so the accept flags travel as a kernel argument and nothing is uploaded.
+    if (!sites && reuse_sites && n == ln.last_trial_n && ln.d_trial_items && n <= 32 * kAcceptWords &&
+        recip_by_rows(e, ln.trial_n1_max)) {
+        AcceptBits bits{};
+        bool same = true;       // the caller promises the trial's candidates in the trial's order: verify
+        for (int c = 0; c < n; ++c) {
+            if (!accept[c]) continue;
+            const RecipItem &ti = ln.h_trial_items[c];
+            same = same && ti.replica == replica[c] && ti.t == t[c] && ti.kind == kind[c] &&
+                   (kind[c] == MGPU_CREATION || ti.m == m[c]);
+            bits.w[c >> 5] |= 1u << (c & 31);
+        }
+        if (!same) return set_error(MGPU_ERR_INVALID_ARG, "commit_submit: candidates differ from the lane's last trial");
+        if ((rc = launch_recip(e, ln, ln.d_trial_items, n, ln.trial_n1_max, site_stride, true, e->d_A, nullptr, nullptr, &bits)))
+            return rc;
+    } else {
+        if ((rc = ln.d_items2.reserve((size_t)n_items * sizeof(RecipItem)))) return rc;
+        HIP_TRY(hipMemcpyAsync(ln.d_items2.p, items, (size_t)n_items * sizeof(RecipItem), hipMemcpyHostToDevice, ln.stream));
+        if (any_sites && sites) {
+            ln.last_trial_n = 0;
+            std::memcpy(ln.h_commit.p, sites, site_bytes);
+            if ((rc = ln.d_sites.reserve(site_bytes))) return rc;
+            HIP_TRY(hipMemcpyAsync(ln.d_sites.p, ln.h_commit.p, site_bytes, hipMemcpyHostToDevice, ln.stream));
+        }
+        if ((rc = launch_recip(e, ln, (const RecipItem *)ln.d_items2.p, n_items, n1_max, site_stride, true, e->d_A, nullptr)))
+            return rc;
     }
-    if ((rc = launch_recip(e, ln, (const RecipItem *)ln.d_items2.p, n_items, n1_max, site_stride, true, e->d_A, nullptr)))
-        return rc;
     for (size_t i = 0; i < new_counts.size(); i += 2) e->h_nmol[new_counts[i]] = new_counts[i + 1];
     return MGPU_OK;
 }

@@ -656,17 +656,34 @@ struct RecipRow {
     int kx, ky;
 };
 
+// Commit by accept mask: the launch covers the candidates of the lane's last trial (their RecipItems are still
+// on the device) and every workgroup whose bit is clear leaves at once -- no item list has to be uploaded.
+constexpr int kAcceptWords = 128;                     // 4096 candidates per launch
+struct AcceptBits {
+    unsigned w[kAcceptWords];
+};
+
 constexpr int kRecipTaskChunk = 5;
 template <bool COMMIT, bool BOTH>
 __global__ __launch_bounds__(kBlock) void recip_rows_kernel(
     Topo tp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
     const RecipTask *__restrict__ tasks, int n_tasks, const RecipRow *__restrict__ rows, int n_rows,
     const double *__restrict__ kw, double2 *__restrict__ A_base, const RecipItem *__restrict__ items,
-    const double *__restrict__ cand_sites, int site_stride, double *__restrict__ u_new, double *__restrict__ u_old) {
+    const double *__restrict__ cand_sites, int site_stride, double *__restrict__ u_new, double *__restrict__ u_old,
+    AcceptBits accept, int use_accept) {
     extern __shared__ double2 s_tab[];
     __shared__ double s_red[2 * kWavesPerBlock];
 
-    const RecipItem it = items[blockIdx.x];
+    RecipItem it = items[blockIdx.x];
+    if (COMMIT && use_accept) {
+        if (!((accept.w[blockIdx.x >> 5] >> (blockIdx.x & 31)) & 1u)) return;        // uniform per workgroup
+        if (it.kind != 0) {
+            // the trial's item carries no target slot / new count: take them from the replica's live count
+            const int nm = nmol[it.replica * tp.n_res + it.t];
+            if (it.kind == 1) { it.m = nm; it.aux = nm + 1; }     // appended (monte_carlo.f90:63, create_molecule.f90:64)
+            else it.aux = nm - 1;                                 // swap-with-last target
+        }
+    }
     const int n1 = tp.n1[it.t], nss = 2 * n1;
     const int kofs[3] = {0, bx.kmax[0] + 1, bx.kmax[0] + bx.kmax[1] + 2};
     const int ktot = bx.kmax[0] + bx.kmax[1] + bx.kmax[2] + 3;
