@@ -968,6 +968,10 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     const PairItem *d_iit = (const PairItem *)((char *)ln.d_sites.p + site_bytes + pit_cap + rit_bytes);
     double2 *d_part = (double2 *)ln.d_out.p;
     double *d_uo = (double *)ln.d_out.p + 2 * (size_t)n_pair * nsplit, *d_un = d_uo + n, *d_in = d_un + n;
+    // Pair sweep first, k sweep second.  The persistent pair sweep owns every CU (16 waves x 128 VGPRs), so
+    // the memory-bound kernels never run beside it; what does overlap is this lane's k sweep with the other
+    // lane's commit, in the window between two pair sweeps.  (k sweep first was measured: 5.6 -> 5.0 M moves/s,
+    // the commit then queues behind two kernels instead of sharing that window.)
     if (n_pair) {
         if ((rc = launch_pair(e, ln, d_pit, n_pair, std::max(common, 0), site_stride, nsplit, nullptr, nullptr, false, d_part)))
             return rc;
