@@ -38,5 +38,6 @@ int main() {
     run<3>(d, 256); run<8>(d, 256);
     // 3 waves per SIMD (2 workgroups of 6 waves per CU) with 6 chains; 2 waves per SIMD with 6
     run<6, 384>(d, 512); run<6, 512>(d, 256); run<6, 512>(d, 512); run<5, 512>(d, 512);
+    run<6, 256>(d, 768); run<6, 256>(d, 1024); run<3, 256>(d, 1024); run<6, 256>(d, 512);
     return 0;
 }
