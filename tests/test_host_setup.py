@@ -103,3 +103,25 @@ def test_fortran_host_library_exports():
                  "mchain_set_moves", "mchain_set_reservoir_box", "mchain_set_reservoir_residue", "mchain_run",
                  "mchain_set_mode", "mchain_get_energy", "mchain_get_counters", "mchain_get_counts", "mchain_get_steps", "mchain_get_molecule"):
         assert hasattr(H, name), name
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/maniac_gpu.h is the C ABI: it must compile as C99 (no C++-isms), and a C caller must link."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "caller.c"
+    src.write_text('#include "maniac_gpu.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '    int n = -1;\n'
+                   '    int rc = mgpu_device_count(&n);\n'
+                   '    printf("abi %d rc %d devices %d lanes %d\\n", mgpu_abi_version(), rc, n, MGPU_LANES);\n'
+                   '    return 0;\n}\n')
+    exe = tmp_path / "caller"
+    lib = os.path.join(root, "maniac_mc_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src),
+                           "-L" + lib, "-lmaniac_hip", "-Wl,-rpath," + lib, "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("abi "), out.stdout + out.stderr
