@@ -247,7 +247,9 @@ int mgpu_replica_set_num_molecules(mgpu_engine *e, int replica, int t, int n_mol
 int mgpu_synchronize(mgpu_engine *e);
 /* When enabled, every launch of the four main kernels carries a start and a stop HIP event attached to
  * the dispatch on the lane's own stream (the kernel's begin / end timestamps, no extra packets in the
- * stream); mgpu_profile_get returns launches and total device milliseconds since the last reset. */
+ * stream); mgpu_profile_get returns launches and total device milliseconds since the last reset.
+ * Enabling pays the one-time costs up front (event pool, one empty profiled dispatch per lane: the first
+ * such dispatch switches the stream's queue into profiling mode, ~7 ms), so call it outside a timed region. */
 int mgpu_profile_enable(mgpu_engine *e, int on);
 int mgpu_profile_reset(mgpu_engine *e);
 int mgpu_profile_get(mgpu_engine *e, int kernel, long long *launches, double *total_ms);

@@ -910,6 +910,9 @@ __global__ void intra_kernel(Topo tp, BoxDev bx, const double *__restrict__ pos,
     u_out[i] = u * kEps0InvEvA / kKbEvK;
 }
 
+// empty dispatch used by mgpu_profile_enable to switch a stream's queue into profiling mode ahead of time
+__global__ void prime_kernel(const int *p) { (void)p; }
+
 }  // namespace mgpu
 
 #endif

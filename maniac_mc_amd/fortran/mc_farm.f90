@@ -617,18 +617,25 @@ contains
         integer(c_int), value :: n_steps
         real(c_double), intent(out) :: out(3)
         integer(c_int) :: rc
-        integer :: step, g
+        integer :: step, g, lu, ios, nlen
+        integer(int64), allocatable :: slog(:, :)
+        integer(int64) :: rate
+        character(len=512) :: logpath
         rc = MGPU_OK
         out = 0.0_real64
         if (.not. F%ready) then
             rc = 5
             return
         end if
+        ! diagnostic: MFARM_STEPLOG=<file> appends the host timers (microseconds) after every step
+        call get_environment_variable("MFARM_STEPLOG", logpath, nlen, ios)
+        if (ios == 0 .and. nlen > 0 .and. n_steps > 0) allocate(slog(7, 0:n_steps))
         if (n_steps > 0) then
             do g = 0, F%n_lanes - 1
                 rc = generate_and_submit(g)
                 if (rc /= MGPU_OK) return
             end do
+            if (allocated(slog)) slog(:, 0) = F%ticks
             do step = 1, n_steps
                 do g = 0, F%n_lanes - 1
                     rc = resolve_and_commit(g)
@@ -638,8 +645,20 @@ contains
                         if (rc /= MGPU_OK) return
                     end if
                 end do
+                if (allocated(slog)) slog(:, step) = F%ticks
             end do
             rc = mgpu_synchronize(F%engine)
+        end if
+        if (allocated(slog)) then
+            call system_clock(count_rate=rate)
+            open(newunit=lu, file=logpath(1:nlen), position="append", action="write", iostat=ios)
+            if (ios == 0) then
+                write(lu, '(a, i0)') "# mfarm_run steps=", n_steps
+                do step = 1, n_steps
+                    write(lu, '(i6, 7f10.1)') step, real(slog(:, step) - slog(:, step - 1), real64) * 1.0d6 / real(rate, real64)
+                end do
+                close(lu)
+            end if
         end if
         out(1) = real(F%trials, real64)
         out(2) = real(F%accepted, real64)
