@@ -78,14 +78,18 @@ struct Lane {
     std::vector<Pending> pending;
     int n_submitted = 0;          // candidates of the trial in flight (0 = none)
     int last_trial_n = 0, last_trial_stride = 0;   // shape of the site rows still resident in d_sites
-    int n_pair_items = 0, n_split = 1;
+    int n_pair_items = 0, n_split = 1;   // reduced pair-energy entries of the trial in flight (2 per fused item + 1 per single)
+    int n_fused = 0;                      // of which the first 2 * n_fused belong to fused (old + new) items
     const RecipItem *d_trial_items = nullptr;   // RecipItems of the last trial, resident while last_trial_n != 0
     const RecipItem *h_trial_items = nullptr;   // their host image in h_in (valid until the next trial_submit)
     int trial_n1_max = 1;
     std::vector<int> pair_old, pair_new, intra_idx, kinds;   // per-candidate rows of the trial in flight
     std::vector<double> self_of;                              // per-candidate Ewald self term (host constant)
     std::vector<double> h_lj, h_cc;                           // pair energies of the trial being collected
+    hipEvent_t commit_staged_ev = nullptr;                    // recorded behind the H2D copies that read h_commit
+    bool commit_staged = false;
     void release() {
+        if (commit_staged_ev) { (void)hipEventDestroy(commit_staged_ev); commit_staged_ev = nullptr; }
         d_items.release(); d_items2.release(); d_sites.release(); d_partials.release(); d_out.release();
         h_in.release(); h_commit.release(); h_out.release();
     }
@@ -125,6 +129,8 @@ struct mgpu_engine {
     size_t coul_bytes = 0;
     int n_cu = 256;                  // compute units of the device
     int pair_blocks_per_cu = 2;      // resident pair-sweep workgroups per CU (VGPR / LDS bound)
+    int pair_nsplit = 1;             // waves per pair-sweep item: an engine constant (see engine_nsplit)
+    bool pair_fuse = true;           // trial moves sweep old + new together (MGPU_PAIR_NO_FUSE=1: tuning / A-B only)
     double *d_res_q = nullptr;
     int *d_res_atype = nullptr;
     int *d_atom_res = nullptr, *d_atom_mol = nullptr;
@@ -202,26 +208,23 @@ int check_candidate(const mgpu_engine *e, int c, int replica, int t, int m, bool
     return MGPU_OK;
 }
 
-// number of 64-atom sweep units of one replica (for choosing nsplit)
-int replica_units(const mgpu_engine *e, int replica) {
+// Waves per pair-sweep item.  One wave sweeps every nsplit-th 64-atom unit of the item's replica and the split
+// partials are added in split order, so the last bits of a pair energy depend on nsplit: it is therefore an
+// ENGINE CONSTANT (a function of the topology's capacity only) -- never of how many candidates share a launch
+// or of another replica's state -- and a chain's trajectory does not depend on what runs beside it.  Waves are
+// persistent and stride over the n_items * nsplit work units, so a constant costs nothing when a launch has
+// more work units than resident waves.  Policy: never fewer than ~8 sweep units per wave, at most 8 splits
+// (measured at 1024 fused trial items of the 10 125-atom box: 4, 8 and 16 within 2 %; 8 keeps a single
+// chain's latency low).  MGPU_PAIR_NSPLIT overrides it (tuning only; read once at engine creation).
+int engine_nsplit(const mgpu_engine *e) {
     int units = 0;
     for (int t = 0; t < e->tp.n_res; ++t) {
-        const int nm = e->h_nmol[replica * e->tp.n_res + t], n1 = e->tp.n1[t];
-        if (e->tp.site_major[t]) units += nm * ((n1 + 63) / 64);
-        else units += n1 * ((nm + 63) / 64);
+        const int cap = e->tp.cap[t], n1 = e->tp.n1[t];
+        units += e->tp.site_major[t] ? cap * ((n1 + 63) / 64) : n1 * ((cap + 63) / 64);
     }
-    return units;
-}
-
-int choose_nsplit(const mgpu_engine *e, int n_items, int replica_hint) {
-    // one wave per (item, split).  Aim at one work unit per resident wave (n_cu x 16): fewer, longer
-    // sweeps amortise the per-plane setup (measured at 2048 items: nsplit 2 beats 1 and 4-32), but
-    // never give a wave fewer than ~8 sweep units of 64 atoms.
-    const int units = std::max(1, replica_units(e, replica_hint));
-    const int max_split = std::max(1, units / 8);
-    const int want = (e->n_cu * 16 + n_items - 1) / std::max(1, n_items);
-    if (const char *ov = std::getenv("MGPU_PAIR_NSPLIT")) return std::max(1, std::min(std::atoi(ov), std::max(1, units)));
-    return std::max(1, std::min(want, max_split));
+    int ns = std::max(1, std::min(units / 8, 8));
+    if (const char *ov = std::getenv("MGPU_PAIR_NSPLIT")) ns = std::max(1, std::min(std::atoi(ov), std::max(1, units)));
+    return ns;
 }
 
 int upload_sites(Lane &ln, const double *sites, int n_rows, int site_stride) {
@@ -243,24 +246,32 @@ int upload_sites(mgpu_engine *e, const double *sites, int n_rows, int site_strid
 // copies them out with its results and adds them up in the same order on the host: one launch and one
 // inter-kernel gap less per batch; d_lj / d_c are unused).
 int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, int common_n1, int site_stride,
-                int nsplit, double *d_lj, double *d_c, bool ordered = false, double2 *host_partials = nullptr) {
+                int nsplit, double *d_lj, double *d_c, bool ordered = false, double2 *host_partials = nullptr,
+                bool fused = false) {
     const int n_work = n_items * nsplit;
     int rc = MGPU_OK;
+    if (fused && (!host_partials || ordered || e->bx.triclinic || common_n1 < 1 || common_n1 > kMaxFusedSites))
+        return set_error(MGPU_ERR_STATE, "launch_pair: fused sweep needs register sites, an orthorhombic box and a partials buffer");
     if (!host_partials && (rc = ln.d_partials.reserve((size_t)n_work * sizeof(double2)))) return rc;
     double2 *d_part = host_partials ? host_partials : (double2 *)ln.d_partials.p;
-    // persistent waves: at most 3 workgroups of 8 waves per CU (LDS: 3 x ~31 KiB), never more
+    // persistent waves: 2 workgroups of 8 waves per CU (VGPRs: 4 waves per SIMD at <= 128), never more
     // workgroups than there is work for
-    int per_cu = e->pair_blocks_per_cu;
-    if (const char *ov = std::getenv("MGPU_PAIR_BLOCKS_PER_CU")) per_cu = std::max(1, std::atoi(ov));
+    const int per_cu = e->pair_blocks_per_cu;
     const int grid = std::max(1, std::min((n_work + kPairWaves - 1) / kPairWaves, e->n_cu * per_cu));
     hipEvent_t a = nullptr, b = nullptr;
     rc = prof_begin(e, ln, MGPU_KERNEL_PAIR, &a, &b);
     if (rc) return rc;
-#define MGPU_LAUNCH_PAIR(NS, ORD, TRI)                                                                                  \
-    hipExtLaunchKernelGGL((pair_sweep_kernel<NS, ORD, TRI>), dim3(grid), dim3(kPairBlock), e->coul_bytes, ln.stream,    \
+#define MGPU_LAUNCH_PAIR(NS, ORD, TRI, ...)                                                                             \
+    hipExtLaunchKernelGGL((pair_sweep_kernel<NS, ORD, TRI, ##__VA_ARGS__>), dim3(grid), dim3(kPairBlock), e->coul_bytes, ln.stream, \
                           a, b, 0, e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab,     \
                        d_items, (const double *)ln.d_sites.p, site_stride, nsplit, n_work, d_part)
-    if (e->bx.triclinic) {
+    if (fused) {
+        switch (common_n1) {
+            case 1: MGPU_LAUNCH_PAIR(1, false, false, true); break;
+            case 2: MGPU_LAUNCH_PAIR(2, false, false, true); break;
+            default: MGPU_LAUNCH_PAIR(3, false, false, true); break;   // kMaxFusedSites (4 sites x 2 states spills)
+        }
+    } else if (e->bx.triclinic) {
         if (ordered) MGPU_LAUNCH_PAIR(0, true, true);
         else MGPU_LAUNCH_PAIR(0, false, true);
     } else if (ordered) {
@@ -473,6 +484,8 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
         off += atoms_in_res[t] * mol_capacity[t];
     }
     tp.n_cap_atoms = off;
+    e->pair_nsplit = engine_nsplit(e);
+    e->pair_fuse = std::getenv("MGPU_PAIR_NO_FUSE") == nullptr;
 
     BoxDev &bx = e->bx;
     for (int d = 0; d < 3; ++d) { bx.L[d] = box_matrix[d * 3 + d]; bx.invL[d] = 1.0 / bx.L[d]; bx.kmax[d] = e->kmax[d]; }
@@ -570,6 +583,7 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
         hipDeviceProp_t prop;
         HIP_TRY_E(hipGetDeviceProperties(&prop, device));
         e->n_cu = std::max(1, prop.multiProcessorCount);
+        if (const char *ov = std::getenv("MGPU_PAIR_BLOCKS_PER_CU")) e->pair_blocks_per_cu = std::max(1, std::atoi(ov));   // tuning only
     }
     HIP_TRY_E(hipMalloc(&e->d_res_q, e->charges.size() * sizeof(double)));
     HIP_TRY_E(hipMalloc(&e->d_res_atype, atype0.size() * sizeof(int)));
@@ -822,7 +836,7 @@ int mgpu_pair_energy_candidates(mgpu_engine *e, int n, const int *replica, const
     HIP_TRY(hipMemcpyAsync(e->d_items.p, items.data(), n * sizeof(PairItem), hipMemcpyHostToDevice, e->stream));
     if (any_sites && (rc = upload_sites(e, sites, n, site_stride))) return rc;
     double *d_lj = (double *)e->d_out.p, *d_c = d_lj + n;
-    const int nsplit = choose_nsplit(e, n, replica[0]);
+    const int nsplit = e->pair_nsplit;
     if ((rc = launch_pair(e, e->lanes[0], (const PairItem *)e->d_items.p, n, common_site_count(e, items), site_stride, nsplit, d_lj, d_c))) return rc;
     HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_out.p, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     if ((rc = sync_stream(e))) return rc;
@@ -920,6 +934,11 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
                              const int *kind, const double *sites, int site_stride) {
     if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "trial_submit: the lane still holds an un-waited trial");
     int rc;
+    // from here on the rows of the lane's previous trial are gone (the staging block below may be regrown and is
+    // overwritten): a failed submit must not leave them committable "from the lane's resident rows"
+    ln.last_trial_n = 0;
+    ln.d_trial_items = nullptr;
+    ln.h_trial_items = nullptr;
     const size_t site_bytes = (size_t)n * site_stride * 3 * sizeof(double);
     const size_t pit_cap = 2 * (size_t)n * sizeof(PairItem), rit_bytes = (size_t)n * sizeof(RecipItem);
     const size_t iit_cap = (size_t)n * sizeof(PairItem);
@@ -933,29 +952,48 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     ln.intra_idx.assign(n, -1);
     ln.kinds.assign(n, MGPU_MOVE);
     ln.self_of.assign(n, 0.0);
-    int n1_max = 1, common = -1, n_pair = 0, n_intra = 0;
+    int n1_max = 1, common = -1, n_intra = 0, n_moves = 0;
     for (int c = 0; c < n; ++c) {
         const int k = kind ? kind[c] : MGPU_MOVE;
         if (k < MGPU_MOVE || k > MGPU_DELETION) return set_error(MGPU_ERR_INVALID_ARG, "trial_submit: unknown candidate kind");
+        if (t[c] < 0 || t[c] >= e->tp.n_res) return set_error(MGPU_ERR_INVALID_ARG, "trial_submit: residue type out of range");
+        const int n1 = e->tp.n1[t[c]];
+        common = (common == -1 || common == n1) ? n1 : 0;
+        n_moves += (k == MGPU_MOVE);
+    }
+    // Trial moves of molecules with a few sites are swept old + new together (fused items, two entries each);
+    // insertions, deletions and everything else are single-state items.  Entry layout of the reduced pair
+    // energies: [2 i + {0 old, 1 new} for fused item i | 2 n_fused + j for single item j].
+    const bool fuse = e->pair_fuse && !e->bx.triclinic && common >= 1 && common <= kMaxFusedSites;
+    const int n_fused = fuse ? n_moves : 0;
+    int i_fused = 0, i_single = 0;
+    PairItem *pit_single = pit + n_fused;
+    for (int c = 0; c < n; ++c) {
+        const int k = kind ? kind[c] : MGPU_MOVE;
         const int mc = (k == MGPU_CREATION) ? -1 : m[c];
         if ((rc = check_candidate(e, c, replica[c], t[c], mc, k != MGPU_CREATION))) return rc;
         const int n1 = e->tp.n1[t[c]];
         if (n1 > site_stride) return set_error(MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res");
         n1_max = std::max(n1_max, n1);
-        common = (common == -1 || common == n1) ? n1 : 0;
         ln.kinds[c] = k;
         if (k != MGPU_MOVE) ln.self_of[c] = self_energy_host(e, t[c]);
-        if (k != MGPU_CREATION) { ln.pair_old[c] = n_pair; pit[n_pair++] = PairItem{replica[c], t[c], mc, -1, 0}; }
-        if (k != MGPU_DELETION) { ln.pair_new[c] = n_pair; pit[n_pair++] = PairItem{replica[c], t[c], mc, c, 0}; }
+        if (k == MGPU_MOVE && fuse) {
+            ln.pair_old[c] = 2 * i_fused; ln.pair_new[c] = 2 * i_fused + 1;
+            pit[i_fused++] = PairItem{replica[c], t[c], mc, c, 0};
+        } else {
+            if (k != MGPU_CREATION) { ln.pair_old[c] = 2 * n_fused + i_single; pit_single[i_single++] = PairItem{replica[c], t[c], mc, -1, 0}; }
+            if (k != MGPU_DELETION) { ln.pair_new[c] = 2 * n_fused + i_single; pit_single[i_single++] = PairItem{replica[c], t[c], mc, c, 0}; }
+        }
         rit[c] = RecipItem{replica[c], t[c], mc, k, k == MGPU_DELETION ? -1 : c, 0};   // one k sweep: old and new
         if (k == MGPU_CREATION) { ln.intra_idx[c] = n_intra; iit[n_intra++] = PairItem{replica[c], t[c], -1, c, 0}; }
         if (k == MGPU_DELETION) { ln.intra_idx[c] = n_intra; iit[n_intra++] = PairItem{replica[c], t[c], mc, -1, 0}; }
     }
+    const int n_single = i_single, n_pair = 2 * n_fused + n_single;     // reduced pair-energy entries
     std::memcpy(h_sites, sites, site_bytes);
     const size_t iit_bytes = (size_t)n_intra * sizeof(PairItem);
     // results in device memory, copied out once: [split partials of the pair sweep (n_pair * nsplit complex-sized
     // records, reduced on the host in trial_wait) | u_old | u_new | intra]
-    const int nsplit = n_pair ? choose_nsplit(e, n_pair, replica[0]) : 1;
+    const int nsplit = e->pair_nsplit;
     const size_t out_doubles = 2 * (size_t)n_pair * nsplit + 3 * (size_t)n;
     // one staging block [sites | pair items (2n slots) | recip items | intra items] -> one H2D copy
     const size_t in_bytes = site_bytes + pit_cap + rit_bytes + iit_bytes;
@@ -972,8 +1010,13 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     // the memory-bound kernels never run beside it; what does overlap is this lane's k sweep with the other
     // lane's commit, in the window between two pair sweeps.  (k sweep first was measured: 5.6 -> 5.0 M moves/s,
     // the commit then queues behind two kernels instead of sharing that window.)
-    if (n_pair) {
-        if ((rc = launch_pair(e, ln, d_pit, n_pair, std::max(common, 0), site_stride, nsplit, nullptr, nullptr, false, d_part)))
+    if (n_fused) {
+        if ((rc = launch_pair(e, ln, d_pit, n_fused, common, site_stride, nsplit, nullptr, nullptr, false, d_part, true)))
+            return rc;
+    }
+    if (n_single) {
+        if ((rc = launch_pair(e, ln, d_pit + n_fused, n_single, std::max(common, 0), site_stride, nsplit, nullptr, nullptr, false,
+                              d_part + 2 * (size_t)n_fused * nsplit)))
             return rc;
     }
     if ((rc = launch_recip(e, ln, d_rit, n, n1_max, site_stride, false, e->d_A, d_un, d_uo)))
@@ -986,6 +1029,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     HIP_TRY(hipMemcpyAsync(ln.h_out.p, ln.d_out.p, out_doubles * sizeof(double), hipMemcpyDeviceToHost, ln.stream));
     ln.n_submitted = n;
     ln.n_pair_items = n_pair;
+    ln.n_fused = n_fused;
     ln.n_split = nsplit;
     ln.last_trial_n = n;
     ln.last_trial_stride = site_stride;
@@ -1002,17 +1046,20 @@ static int trial_wait_impl(mgpu_engine *e, Lane &ln, double *old_energy, double 
     ln.n_submitted = 0;
     int rc = sync_lane(e, ln);
     if (rc) return rc;
-    const int np = ln.n_pair_items, ns = ln.n_split;
+    const int np = ln.n_pair_items, ns = ln.n_split, nf = ln.n_fused;
     const double *h = (const double *)ln.h_out.p;
     const double *uo = h + 2 * (size_t)np * ns, *un = uo + n, *in = un + n;
     // the ordered sum of the split partials and the Coulomb rescale e_coulomb * EPS0_INV_eVA / KB_eVK
-    // (energy_utils.f90:440), exactly as pair_finalize_kernel does them
+    // (energy_utils.f90:440), exactly as pair_finalize_kernel does them.  Partials of a fused item are laid out
+    // [split][state], those of a single item [split].
     ln.h_lj.resize(np);
     ln.h_cc.resize(np);
     for (int i = 0; i < np; ++i) {
         double a = 0.0, b = 0.0;
-        const double *p = h + 2 * (size_t)i * ns;
-        for (int s2 = 0; s2 < ns; ++s2) { a += p[2 * s2]; b += p[2 * s2 + 1]; }
+        const bool fz = i < 2 * nf;
+        const double *p = fz ? h + 2 * ((size_t)(i >> 1) * ns * 2 + (i & 1)) : h + 2 * ((size_t)2 * nf * ns + (size_t)(i - 2 * nf) * ns);
+        const int stride = fz ? 4 : 2;
+        for (int s2 = 0; s2 < ns; ++s2) { a += p[stride * s2]; b += p[stride * s2 + 1]; }
         ln.h_lj[i] = a;
         ln.h_cc[i] = b * kEps0InvEvA / kKbEvK;
     }
@@ -1043,8 +1090,13 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
                               bool reuse_sites = false) {
     int rc;
     const size_t site_bytes = sites ? (size_t)n * site_stride * 3 * sizeof(double) : 0;
-    if ((rc = ln.h_commit.reserve(site_bytes + (size_t)n * sizeof(RecipItem)))) return rc;
     if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "commit_submit: wait for the lane's trial first");
+    // the pinned staging block may still feed the H2D copy of the lane's previous commit
+    if (ln.commit_staged) {
+        HIP_TRY(hipEventSynchronize(ln.commit_staged_ev));
+        ln.commit_staged = false;
+    }
+    if ((rc = ln.h_commit.reserve(site_bytes + (size_t)n * sizeof(RecipItem)))) return rc;
     RecipItem *items = (RecipItem *)((char *)ln.h_commit.p + site_bytes);
     int n_items = 0;
     std::vector<char> seen(e->n_replicas, 0);
@@ -1095,6 +1147,10 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
         if (!same) return set_error(MGPU_ERR_INVALID_ARG, "commit_submit: candidates differ from the lane's last trial");
         if ((rc = launch_recip(e, ln, ln.d_trial_items, n, ln.trial_n1_max, site_stride, true, e->d_A, nullptr, nullptr, &bits)))
             return rc;
+        // applied once: a second commit_submit(sites = NULL) must not find these rows "resident" again
+        ln.last_trial_n = 0;
+        ln.d_trial_items = nullptr;
+        ln.h_trial_items = nullptr;
     } else {
         if ((rc = ln.d_items2.reserve((size_t)n_items * sizeof(RecipItem)))) return rc;
         HIP_TRY(hipMemcpyAsync(ln.d_items2.p, items, (size_t)n_items * sizeof(RecipItem), hipMemcpyHostToDevice, ln.stream));
@@ -1104,6 +1160,9 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
             if ((rc = ln.d_sites.reserve(site_bytes))) return rc;
             HIP_TRY(hipMemcpyAsync(ln.d_sites.p, ln.h_commit.p, site_bytes, hipMemcpyHostToDevice, ln.stream));
         }
+        if (!ln.commit_staged_ev) HIP_TRY(hipEventCreateWithFlags(&ln.commit_staged_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ln.commit_staged_ev, ln.stream));
+        ln.commit_staged = true;
         if ((rc = launch_recip(e, ln, (const RecipItem *)ln.d_items2.p, n_items, n1_max, site_stride, true, e->d_A, nullptr)))
             return rc;
     }
@@ -1207,7 +1266,7 @@ int mgpu_system_energy(mgpu_engine *e, int replica, double out[6]) {
         if ((rc = e->d_items.reserve(n * sizeof(PairItem)))) return rc;
         HIP_TRY(hipMemcpyAsync(e->d_items.p, items.data(), n * sizeof(PairItem), hipMemcpyHostToDevice, e->stream));
         double *d_lj = (double *)e->d_out.p, *d_c = d_lj + n, *d_in = d_c + n;
-        const int nsplit = choose_nsplit(e, n, replica);
+        const int nsplit = e->pair_nsplit;
         if ((rc = launch_pair(e, e->lanes[0], (const PairItem *)e->d_items.p, n, 0, 1, nsplit, d_lj, d_c, true))) return rc;
         hipLaunchKernelGGL(intra_kernel, dim3((n + 63) / 64), dim3(64), 0, e->stream, e->tp, e->bx, e->d_pos, e->d_res_q,
                            (const PairItem *)e->d_items.p, n, (const double *)nullptr, 1, d_in);

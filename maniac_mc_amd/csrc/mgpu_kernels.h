@@ -41,6 +41,7 @@ constexpr int kSiteChunk = 32;    // candidate sites staged in LDS per pass (gen
 constexpr int kPairBlock = MGPU_PAIR_BLOCK;   // pair sweep: persistent waves share one LDS Coulomb table
 constexpr int kPairWaves = kPairBlock / 64;
 constexpr int kMaxTypes = 16;     // atom types (LDS pair table 16 x 16 x 16 B = 4 KiB)
+constexpr int kMaxFusedSites = 3; // trial moves of molecules up to this size sweep old + new together (2 NS register sites)
 
 struct Topo {
     int n_res;
@@ -208,14 +209,22 @@ __device__ __forceinline__ void pair_term(double dx, double dy, double dz, const
 // per-wave LDS slab in chunks of kSiteChunk.  ORDERED selects SingleMolPairwiseEnergy semantics
 // (only molecules after the item's, plus CoulombEnergy's r < 1e-10 guard) for the static total.
 // TRI selects the triclinic 27-image distance (generic NS = 0 path only).
+// FUSED (NS > 0): the item is a trial MOVE of the resident molecule (replica, t, m) to the candidate row
+// `src`: the OLD state (resident sites) and the NEW state (candidate sites) are swept together, 2 NS
+// register sites against every atom -- one set of coordinate loads, masks and loop bookkeeping for both
+// ComputeOldEnergy and ComputeNewEnergy (monte_carlo_utils.f90:380-395 / :275-330); each state's sums are
+// formed exactly as the unfused sweep forms them, and the work unit writes two partials {old, new}.
 // ------------------------------------------------------------------------------------------
-template <int NS, bool ORDERED, bool TRI>
+template <int NS, bool ORDERED, bool TRI, bool FUSED = false>
 __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_kernel(
     Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
     const char *__restrict__ coul_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
     int site_stride, int nsplit, int n_work, double2 *__restrict__ partials) {
-    constexpr int NREG = NS > 0 ? NS : 1;                 // register-resident sites
+    static_assert(!FUSED || (NS > 0 && !ORDERED && !TRI), "the fused old + new sweep is a register-site, unordered, orthorhombic path");
+    constexpr int NTY = NS > 0 ? NS : 1;                  // sites of the molecule (charge / type per site)
+    constexpr int NST = FUSED ? 2 : 1;                    // states swept together (old, new)
+    constexpr int NREG = NTY * NST;                       // register-resident sites: state-major, [state][site]
     constexpr int NSLAB = NS > 0 ? 1 : kPairWaves * kSiteChunk;
     extern __shared__ __attribute__((aligned(16))) char s_coul[];     // (coul_last_row + 1) x 48 B
     __shared__ double2 s_pair[kMaxTypes * kMaxTypes];
@@ -252,12 +261,21 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                 x = c[0]; y = c[1]; z = c[2];
             }
         };
-        double rx[NREG], ry[NREG], rz[NREG], rq[NREG];
-        int rty[NREG];
+        double rx[NREG], ry[NREG], rz[NREG], rq[NTY];
+        int rty[NTY];
         if constexpr (NS > 0) {
 #pragma unroll
-            for (int a = 0; a < NREG; ++a) {
-                load_site(a, rx[a], ry[a], rz[a]);
+            for (int a = 0; a < NTY; ++a) {
+                if constexpr (FUSED) {
+                    // old state: the resident slot; new state: the candidate row
+                    const int j = atom_slot(tp, it.t, it.m, a);
+                    rx[a] = px[j]; ry[a] = py[j]; rz[a] = pz[j];
+                    const double *c = cand_sites + ((size_t)it.src * site_stride + a) * 3;
+                    rx[NTY + a] = c[0]; ry[NTY + a] = c[1]; rz[NTY + a] = c[2];
+                    asm volatile("" : "+v"(rx[NTY + a]), "+v"(ry[NTY + a]), "+v"(rz[NTY + a]));
+                } else {
+                    load_site(a, rx[a], ry[a], rz[a]);
+                }
                 rq[a] = res_q[it.t * tp.max_atom + a];
                 rty[a] = res_atype[it.t * tp.max_atom + a];
                 // wave-uniform values, but parked in VGPRs: the sweep already needs ~100 SGPRs for box,
@@ -266,7 +284,9 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
             }
         }
 
-        double elj = 0.0, ec = 0.0;
+        double elj[NST], ec[NST];
+#pragma unroll
+        for (int st = 0; st < NST; ++st) { elj[st] = 0.0; ec[st] = 0.0; }
         for (int sb = 0; sb < n1; sb += kSiteChunk) {
             const int ns = NS > 0 ? NS : min(kSiteChunk, n1 - sb);
             if constexpr (NS == 0) {
@@ -304,11 +324,11 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                             const double qj = res_q[t2 * tp.max_atom + a2];
                             const int tyj = res_atype[t2 * tp.max_atom + a2];
                             const bool qj_on = fabs(qj) >= kErrorTol;
-                            double e4[NREG], sg2[NREG], qq[NREG];
-                            bool lj[NREG], c_on[NREG];
+                            double e4[NTY], sg2[NTY], qq[NTY];
+                            bool lj[NTY], c_on[NTY];
                             bool any_c = false, all_c = true, any_lj = false;
 #pragma unroll
-                            for (int s = 0; s < NREG; ++s) {
+                            for (int s = 0; s < NTY; ++s) {
                                 const double2 pt = pair_tab[rty[s] * nt + tyj];     // scalar load
                                 e4[s] = pt.x; sg2[s] = pt.y;
                                 lj[s] = pt.x != 0.0;                               // epsilon = 0 contributes 0
@@ -355,7 +375,7 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                                     }
 #pragma unroll
                                     for (int s = 0; s < NREG; ++s) {
-                                        if (!ALL_C && !c_on[s]) { g[s] = 0.0; continue; }
+                                        if (!ALL_C && !c_on[s % NTY]) { g[s] = 0.0; continue; }
                                         bool below;
                                         g[s] = coul_lds(r2[s], s_coul, bx.coul_idx_base, bx.coul_last_row, below);
                                         any_below = any_below || below;
@@ -363,18 +383,18 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                                     if (any_below) {   // r < 0.5 A somewhere in the wave: rare slow path
 #pragma unroll
                                         for (int s = 0; s < NREG; ++s)
-                                            if ((ALL_C || c_on[s]) && r2[s] < 0.25) g[s] = coul_slow(r2[s], bx.alpha, ORDERED);
+                                            if ((ALL_C || c_on[s % NTY]) && r2[s] < 0.25) g[s] = coul_slow(r2[s], bx.alpha, ORDERED);
                                     }
 #pragma unroll
                                     for (int s = 0; s < NREG; ++s) acc[s] = MASKED ? fma(wgt, g[s], acc[s]) : acc[s] + g[s];
                                     if (any_lj) {
 #pragma unroll
                                         for (int s = 0; s < NREG; ++s) {
-                                            if (!lj[s]) continue;
-                                            const double s2 = sg2[s] * fast_rcp(r2[s]);
+                                            if (!lj[s % NTY]) continue;
+                                            const double s2 = sg2[s % NTY] * fast_rcp(r2[s]);
                                             const double s6 = s2 * s2 * s2;
-                                            const double e = e4[s] * fma(s6, s6, -s6);  // energy_utils.f90:421-423
-                                            elj += (r2[s] < rc2l) ? e : 0.0;            // energy_utils.f90:417
+                                            const double e = e4[s % NTY] * fma(s6, s6, -s6);  // energy_utils.f90:421-423
+                                            elj[s / NTY] += (r2[s] < rc2l) ? e : 0.0;            // energy_utils.f90:417
                                         }
                                     }
                                 };
@@ -395,7 +415,7 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                             if (all_c) sweep_plane(std::true_type{});
                             else sweep_plane(std::false_type{});
 #pragma unroll
-                            for (int s = 0; s < NREG; ++s) ec = fma(qq[s], acc[s], ec);
+                            for (int s = 0; s < NREG; ++s) ec[s / NTY] = fma(qq[s % NTY], acc[s], ec[s / NTY]);
                         }
                     } else {
                         const int units = n2 * cpp;
@@ -418,7 +438,7 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                                 const bool do_lj = pt.x != 0.0;                        // epsilon = 0 contributes 0
                                 if ((do_c || do_lj) && valid)
                                     pair_term<ORDERED, TRI>(xj - w_site[s * 4 + 0], yj - w_site[s * 4 + 1], zj - w_site[s * 4 + 2],
-                                                       bx, qs * qj, pt.x, pt.y, do_lj, do_c, s_coul, elj, ec);
+                                                       bx, qs * qj, pt.x, pt.y, do_lj, do_c, s_coul, elj[0], ec[0]);
                             }
                         }
                     }
@@ -438,30 +458,32 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                             tyj = res_atype[t2 * tp.max_atom + a2];
                         }
                         const bool qj_on = fabs(qj) >= kErrorTol;
-                        auto one_site = [&](double sx, double sy, double sz, double qs, int tys) {
+                        auto one_site = [&](double sx, double sy, double sz, double qs, int tys, double &elj_s, double &ec_s) {
                             const double2 pt = s_pair[tys * nt + tyj];
                             const bool do_c = qj_on && (fabs(qs) >= kErrorTol);
                             if (valid) {
                                 double e1 = 0.0, e2 = 0.0;
                                 pair_term<ORDERED, TRI>(xj - sx, yj - sy, zj - sz, bx, qs * qj, pt.x, pt.y, true, true, s_coul, e1, e2);
-                                elj += (pt.x != 0.0) ? e1 : 0.0;
-                                ec += do_c ? e2 : 0.0;
+                                elj_s += (pt.x != 0.0) ? e1 : 0.0;
+                                ec_s += do_c ? e2 : 0.0;
                             }
                         };
                         if constexpr (NS > 0) {
 #pragma unroll
-                            for (int s = 0; s < NREG; ++s) one_site(rx[s], ry[s], rz[s], rq[s], rty[s]);
+                            for (int s = 0; s < NREG; ++s) one_site(rx[s], ry[s], rz[s], rq[s % NTY], rty[s % NTY], elj[s / NTY], ec[s / NTY]);
                         } else {
                             for (int s = 0; s < ns; ++s)
-                                one_site(w_site[s * 4 + 0], w_site[s * 4 + 1], w_site[s * 4 + 2], w_site[s * 4 + 3], w_sty[s]);
+                                one_site(w_site[s * 4 + 0], w_site[s * 4 + 1], w_site[s * 4 + 2], w_site[s * 4 + 3], w_sty[s], elj[0], ec[0]);
                         }
                     }
                 }
             }
         }
-        elj = wave_sum(elj);
-        ec = wave_sum(ec);
-        if (lane == 0) partials[w] = make_double2(elj, ec);
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const double a = wave_sum(elj[st]), b = wave_sum(ec[st]);
+            if (lane == 0) partials[(size_t)w * NST + st] = make_double2(a, b);     // fused: {old, new} per work unit
+        }
     }
 }
 
