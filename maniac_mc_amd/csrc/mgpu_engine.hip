@@ -121,7 +121,11 @@ struct mgpu_engine {
     double2 *d_A = nullptr;       // [R][Nk]
     int *d_kpack = nullptr;
     double *d_kw = nullptr;
-    RecipTask *d_rtasks = nullptr;   // row form of the k list (recip_rows_kernel)
+    int *d_trj = nullptr;            // row form of the k list (recip_rows_kernel): packed task words,
+    double2 *d_tw = nullptr;         // task weights {ff W (+j), ff W (-j)}
+    int *d_kslot = nullptr;          // k (reference order) -> slot of A(k)
+    std::vector<int> kslot;
+    int n_slots = 0;                 // complex entries of A(k) per replica
     RecipRow *d_rrows = nullptr;
     int n_rtasks = 0, n_rrows = 0;
     double2 *d_pair_tab = nullptr;
@@ -213,16 +217,18 @@ int check_candidate(const mgpu_engine *e, int c, int replica, int t, int m, bool
 // ENGINE CONSTANT (a function of the topology's capacity only) -- never of how many candidates share a launch
 // or of another replica's state -- and a chain's trajectory does not depend on what runs beside it.  Waves are
 // persistent and stride over the n_items * nsplit work units, so a constant costs nothing when a launch has
-// more work units than resident waves.  Policy: never fewer than ~8 sweep units per wave, at most 8 splits
-// (measured at 1024 fused trial items of the 10 125-atom box: 4, 8 and 16 within 2 %; 8 keeps a single
-// chain's latency low).  MGPU_PAIR_NSPLIT overrides it (tuning only; read once at engine creation).
+// more work units than resident waves.  Policy: never fewer than ~8 sweep units per wave; at most 4 splits for a
+// farm engine (>= 256 replicas: launches carry hundreds of items, and 4 splits x 1024 fused items = one work unit
+// per resident wave; measured at the 10 125-atom box: 4 -> 98.9 us, 8 -> 104.6 us, 16 -> 116 us per launch), at
+// most 16 for a small engine (single chains are latency-bound: a trial is swept by up to 16 waves).
+// MGPU_PAIR_NSPLIT overrides it (tuning only; read once at engine creation).
 int engine_nsplit(const mgpu_engine *e) {
     int units = 0;
     for (int t = 0; t < e->tp.n_res; ++t) {
         const int cap = e->tp.cap[t], n1 = e->tp.n1[t];
         units += e->tp.site_major[t] ? cap * ((n1 + 63) / 64) : n1 * ((cap + 63) / 64);
     }
-    int ns = std::max(1, std::min(units / 8, 8));
+    int ns = std::max(1, std::min(units / 8, e->n_replicas >= 256 ? 4 : 16));
     if (const char *ov = std::getenv("MGPU_PAIR_NSPLIT")) ns = std::max(1, std::min(std::atoi(ov), std::max(1, units)));
     return ns;
 }
@@ -348,12 +354,12 @@ int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items
     do {                                                                                                             \
         if (by_rows)                                                                                                 \
             hipExtLaunchKernelGGL((recip_rows_kernel<COMMIT, BOTH>), dim3(n_items), dim3(kBlock), lds, ln.stream, a, b, \
-                                  0, e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_rtasks, e->n_rtasks, e->d_rrows, e->n_rrows, \
-                               e->d_kw, A_base, d_items, (const double *)ln.d_sites.p, site_stride, d_u, d_u_old,      \
+                                  0, e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_trj, e->d_tw, e->n_rtasks, e->d_rrows, e->n_rrows, \
+                               A_base, d_items, (const double *)ln.d_sites.p, site_stride, d_u, d_u_old,      \
                                   bits, use_accept);                                                                \
         else                                                                                                         \
             hipExtLaunchKernelGGL((recip_kernel<COMMIT, BOTH>), dim3(n_items), dim3(kBlock), lds, ln.stream, a, b, 0,   \
-                                  e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_kpack, e->d_kw, A_base, d_items,            \
+                                  e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_kpack, e->d_kslot, e->d_kw, A_base, d_items,  \
                                (const double *)ln.d_sites.p, site_stride, d_u, d_u_old);                               \
     } while (0)
     if (commit) MGPU_LAUNCH_RECIP(true, false);
@@ -375,7 +381,7 @@ int launch_sfactor(mgpu_engine *e, int replica, double2 *dst) {
     hipLaunchKernelGGL(phase_table_kernel, dim3((ncap + 255) / 256), dim3(256), 0, e->stream, e->tp, e->bx, e->d_pos,
                        e->d_nmol, e->d_atom_res, e->d_atom_mol, replica, e->d_phase_tab);
     hipExtLaunchKernelGGL(sfactor_kernel, dim3(e->nk), dim3(kBlock), 0, e->stream, a, b, 0, e->tp, e->bx, e->d_nmol,
-                          e->d_atom_res, e->d_atom_mol, e->d_atom_q, e->d_kpack, replica, e->d_phase_tab, dst);
+                          e->d_atom_res, e->d_atom_mol, e->d_atom_q, e->d_kpack, e->d_kslot, replica, e->d_phase_tab, dst);
     rc = prof_end(e, e->lanes[0], MGPU_KERNEL_SFACTOR, a, b);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
@@ -528,6 +534,24 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     }
     e->n_rrows = (int)rrows.size();
     e->n_rtasks = (int)rtasks.size();
+    // A(k) in task order: slots 2t / 2t + 1 hold the +j / -j member of task t (zero where the list has none)
+    e->kslot.assign(e->nk, 0);
+    std::vector<int> trj(rtasks.size());
+    std::vector<double2> tw(rtasks.size());
+    if (e->n_rtasks > 0) {
+        e->n_slots = 2 * e->n_rtasks;
+        for (size_t ti = 0; ti < rtasks.size(); ++ti) {
+            const RecipTask &tk = rtasks[ti];
+            trj[ti] = (tk.row << 8) | tk.j | (tk.kp >= 0 ? kTaskHasP : 0) | (tk.km >= 0 ? kTaskHasM : 0);
+            tw[ti] = make_double2(tk.kp >= 0 ? kw[tk.kp] : 0.0, tk.km >= 0 ? kw[tk.km] : 0.0);
+            if (tk.kp >= 0) e->kslot[tk.kp] = 2 * (int)ti;
+            if (tk.km >= 0) e->kslot[tk.km] = 2 * (int)ti + 1;
+        }
+    } else {
+        e->n_slots = e->nk;
+        for (int i = 0; i < e->nk; ++i) e->kslot[i] = i;
+    }
+    bx.n_slots = e->n_slots;
     std::vector<double2> ptab((size_t)n_types * n_types);
     for (int i = 0; i < n_types * n_types; ++i) ptab[i] = make_double2(4.0 * epsilon[i], sigma[i] * sigma[i]);
     std::vector<int> atype0((size_t)n_res * max_atom, 0);
@@ -557,8 +581,8 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     HIP_TRY_E(hipMemset(e->d_pos, 0, R * 3 * ncap * sizeof(double)));
     HIP_TRY_E(hipMalloc(&e->d_nmol, R * n_res * sizeof(int)));
     HIP_TRY_E(hipMemset(e->d_nmol, 0, R * n_res * sizeof(int)));
-    HIP_TRY_E(hipMalloc(&e->d_A, R * e->nk * sizeof(double2)));
-    HIP_TRY_E(hipMemset(e->d_A, 0, R * e->nk * sizeof(double2)));
+    HIP_TRY_E(hipMalloc(&e->d_A, R * e->n_slots * sizeof(double2)));
+    HIP_TRY_E(hipMemset(e->d_A, 0, R * e->n_slots * sizeof(double2)));
     HIP_TRY_E(hipMalloc(&e->d_kpack, e->nk * sizeof(int)));
     HIP_TRY_E(hipMalloc(&e->d_kw, e->nk * sizeof(double)));
     HIP_TRY_E(hipMalloc(&e->d_pair_tab, ptab.size() * sizeof(double2)));
@@ -591,12 +615,17 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     HIP_TRY_E(hipMalloc(&e->d_atom_mol, ncap * sizeof(int)));
     HIP_TRY_E(hipMalloc(&e->d_atom_q, ncap * sizeof(double)));
     HIP_TRY_E(hipMalloc(&e->d_phase_tab, (size_t)ktot * ncap * sizeof(double2)));
-    HIP_TRY_E(hipMalloc(&e->d_S, e->nk * sizeof(double2)));
+    HIP_TRY_E(hipMalloc(&e->d_S, e->n_slots * sizeof(double2)));
+    HIP_TRY_E(hipMemset(e->d_S, 0, e->n_slots * sizeof(double2)));
+    HIP_TRY_E(hipMalloc(&e->d_kslot, e->nk * sizeof(int)));
+    HIP_TRY_E(hipMemcpy(e->d_kslot, e->kslot.data(), e->nk * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY_E(hipMemcpy(e->d_kpack, kpack.data(), e->nk * sizeof(int), hipMemcpyHostToDevice));
     if (e->n_rtasks > 0) {
-        HIP_TRY_E(hipMalloc(&e->d_rtasks, rtasks.size() * sizeof(RecipTask)));
+        HIP_TRY_E(hipMalloc(&e->d_trj, trj.size() * sizeof(int)));
+        HIP_TRY_E(hipMalloc(&e->d_tw, tw.size() * sizeof(double2)));
         HIP_TRY_E(hipMalloc(&e->d_rrows, rrows.size() * sizeof(RecipRow)));
-        HIP_TRY_E(hipMemcpy(e->d_rtasks, rtasks.data(), rtasks.size() * sizeof(RecipTask), hipMemcpyHostToDevice));
+        HIP_TRY_E(hipMemcpy(e->d_trj, trj.data(), trj.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY_E(hipMemcpy(e->d_tw, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice));
         HIP_TRY_E(hipMemcpy(e->d_rrows, rrows.data(), rrows.size() * sizeof(RecipRow), hipMemcpyHostToDevice));
     }
     HIP_TRY_E(hipMemcpy(e->d_kw, kw.data(), e->nk * sizeof(double), hipMemcpyHostToDevice));
@@ -617,8 +646,8 @@ int mgpu_engine_destroy(mgpu_engine *e) {
     for (auto &ln : e->lanes) if (ln.stream) (void)hipStreamSynchronize(ln.stream);
     for (void *p : {(void *)e->d_pos, (void *)e->d_nmol, (void *)e->d_A, (void *)e->d_kpack, (void *)e->d_kw,
                     (void *)e->d_pair_tab, (void *)e->d_coul_tab, (void *)e->d_res_q, (void *)e->d_res_atype, (void *)e->d_atom_res,
-                    (void *)e->d_atom_mol, (void *)e->d_atom_q, (void *)e->d_phase_tab, (void *)e->d_S, (void *)e->d_rtasks,
-                    (void *)e->d_rrows})
+                    (void *)e->d_atom_mol, (void *)e->d_atom_q, (void *)e->d_phase_tab, (void *)e->d_S, (void *)e->d_trj,
+                    (void *)e->d_tw, (void *)e->d_kslot, (void *)e->d_rrows})
         if (p) (void)hipFree(p);
     e->h_stage.release();
     for (auto &ln : e->lanes) {
@@ -745,7 +774,7 @@ int mgpu_replica_copy(mgpu_engine *e, int dst, int src) {
                            (size_t)3 * tp.n_cap_atoms * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->d_nmol + dst * tp.n_res, e->d_nmol + src * tp.n_res, tp.n_res * sizeof(int),
                            hipMemcpyDeviceToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->d_A + (size_t)dst * e->nk, e->d_A + (size_t)src * e->nk, e->nk * sizeof(double2),
+    HIP_TRY(hipMemcpyAsync(e->d_A + (size_t)dst * e->n_slots, e->d_A + (size_t)src * e->n_slots, e->n_slots * sizeof(double2),
                            hipMemcpyDeviceToDevice, e->stream));
     for (int t = 0; t < tp.n_res; ++t) e->h_nmol[dst * tp.n_res + t] = e->h_nmol[src * tp.n_res + t];
     return sync_stream(e);
@@ -779,9 +808,9 @@ int mgpu_init_structure_factor(mgpu_engine *e, int replica, int mode) {
     int rc = check_replica_t(e, replica, 0);
     if (rc) return rc;
     if ((rc = use_device(e))) return rc;
-    double2 *A = e->d_A + (size_t)replica * e->nk;
+    double2 *A = e->d_A + (size_t)replica * e->n_slots;
     if (mode == 0) {
-        HIP_TRY(hipMemsetAsync(A, 0, e->nk * sizeof(double2), e->stream));
+        HIP_TRY(hipMemsetAsync(A, 0, e->n_slots * sizeof(double2), e->stream));
     } else {
         if ((rc = launch_sfactor(e, replica, A))) return rc;
     }
@@ -794,7 +823,10 @@ int mgpu_get_structure_factor(mgpu_engine *e, int replica, double *a) {
     if (!a) return set_error(MGPU_ERR_INVALID_ARG, "null buffer");
     if ((rc = use_device(e))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(a, e->d_A + (size_t)replica * e->nk, e->nk * sizeof(double2), hipMemcpyDeviceToHost));
+    // the device keeps A(k) in task order; hand it out in the reference's k order
+    std::vector<double2> slots(e->n_slots);
+    HIP_TRY(hipMemcpy(slots.data(), e->d_A + (size_t)replica * e->n_slots, e->n_slots * sizeof(double2), hipMemcpyDeviceToHost));
+    for (int k = 0; k < e->nk; ++k) { a[2 * k] = slots[e->kslot[k]].x; a[2 * k + 1] = slots[e->kslot[k]].y; }
     return MGPU_OK;
 }
 
@@ -804,7 +836,9 @@ int mgpu_set_structure_factor(mgpu_engine *e, int replica, const double *a) {
     if (!a) return set_error(MGPU_ERR_INVALID_ARG, "null buffer");
     if ((rc = use_device(e))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(e->d_A + (size_t)replica * e->nk, a, e->nk * sizeof(double2), hipMemcpyHostToDevice));
+    std::vector<double2> slots(e->n_slots, make_double2(0.0, 0.0));
+    for (int k = 0; k < e->nk; ++k) slots[e->kslot[k]] = make_double2(a[2 * k], a[2 * k + 1]);
+    HIP_TRY(hipMemcpy(e->d_A + (size_t)replica * e->n_slots, slots.data(), e->n_slots * sizeof(double2), hipMemcpyHostToDevice));
     return MGPU_OK;
 }
 

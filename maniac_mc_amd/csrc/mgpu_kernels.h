@@ -3,7 +3,10 @@
 // Data layout in HBM (per engine; R replicas):
 //   pos      [R][3][Ncap]   fp64   x / y / z planes of every replica's atom slots
 //   nmol     [R][n_res]     int32  live molecule count per residue type
-//   A        [R][Nk]        fp64x2 ewald%recip_amplitude of every replica
+//   A        [R][n_slots]   fp64x2 ewald%recip_amplitude of every replica, in TASK order: slot 2t holds
+//                                  A(kx, ky, +j) and slot 2t + 1 holds A(kx, ky, -j) of row-form task t (zero where
+//                                  the list has no such k), so a k sweep reads 32 contiguous bytes per task with no
+//                                  index load in front of them; kslot[k] maps the reference's k order to slots
 //   kpack    [Nk]           int32  kx | (ky+128)<<8 | (kz+128)<<16
 //   kw       [Nk]           fp64   form_factor(k) * W(k)
 //   pair_tab [nt][nt]       fp64x2 {4 epsilon, sigma^2} per atom-type pair
@@ -66,6 +69,7 @@ struct BoxDev {
     double volume;
     int kmax[3];
     int nk;
+    int n_slots;                  // complex entries of A(k) per replica (2 per row-form task; = nk without row form)
 };
 
 struct PairItem {
@@ -536,9 +540,9 @@ constexpr int kRecipChunk = 5;
 template <bool COMMIT, bool BOTH>
 __global__ __launch_bounds__(kBlock) void recip_kernel(
     Topo tp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
-    const int *__restrict__ kpack, const double *__restrict__ kw, double2 *__restrict__ A_base,
-    const RecipItem *__restrict__ items, const double *__restrict__ cand_sites, int site_stride,
-    double *__restrict__ u_new, double *__restrict__ u_old) {
+    const int *__restrict__ kpack, const int *__restrict__ kslot, const double *__restrict__ kw,
+    double2 *__restrict__ A_base, const RecipItem *__restrict__ items, const double *__restrict__ cand_sites,
+    int site_stride, double *__restrict__ u_new, double *__restrict__ u_old) {
     extern __shared__ double2 s_tab[];
     __shared__ double s_red[2 * kWavesPerBlock];
 
@@ -572,17 +576,18 @@ __global__ __launch_bounds__(kBlock) void recip_kernel(
     for (int a = threadIdx.x; a < n1; a += kBlock) s_q[a] = res_q[it.t * tp.max_atom + a];
     __syncthreads();
 
-    double2 *A = A_base + (size_t)it.replica * bx.nk;
+    double2 *A = A_base + (size_t)it.replica * bx.n_slots;
     double acc = 0.0, acc0 = 0.0;
     for (int k0 = threadIdx.x; k0 < bx.nk; k0 += kBlock * kRecipChunk) {
         double2 Ak[kRecipChunk];
         double w[kRecipChunk];
-        int kp[kRecipChunk];
+        int kp[kRecipChunk], ks[kRecipChunk];
 #pragma unroll
         for (int j = 0; j < kRecipChunk; ++j) {
             const int k = k0 + j * kBlock;
             const bool in = k < bx.nk;
-            Ak[j] = in ? A[k] : make_double2(0.0, 0.0);
+            ks[j] = in ? kslot[k] : 0;
+            Ak[j] = in ? A[ks[j]] : make_double2(0.0, 0.0);
             w[j] = (in && !COMMIT) ? kw[k] : 0.0;
             kp[j] = in ? kpack[k] : ((128 << 8) | (128 << 16));   // (0, 0, 0): harmless filler
         }
@@ -615,7 +620,7 @@ __global__ __launch_bounds__(kBlock) void recip_kernel(
             if (BOTH) acc0 += w[j] * fma(Ak[j].x, Ak[j].x, Ak[j].y * Ak[j].y);
             const double nx = Ak[j].x + dre, ny = Ak[j].y + dim;
             if (COMMIT) {
-                if (k0 + j * kBlock < bx.nk) A[k0 + j * kBlock] = make_double2(nx, ny);
+                if (k0 + j * kBlock < bx.nk) A[ks[j]] = make_double2(nx, ny);
             } else {
                 acc += w[j] * fma(nx, nx, ny * ny);                 // ewald_energy.f90:259-266
             }
@@ -669,10 +674,14 @@ __global__ __launch_bounds__(kBlock) void recip_kernel(
 // applies A <- A + delta and then the coordinate / count update.
 // Dynamic LDS: 2 n1 ktot (1-D tables) + n_rows 2 n1 (XY) complex entries + n1 charges + the row table.
 // ------------------------------------------------------------------------------------------
-struct RecipTask {
+struct RecipTask {                // host-side description of a task (the device reads the packed arrays below)
     int kp, km;                   // k index of (kx, ky, +j) and of (kx, ky, -j); -1: absent (j = 0 has no partner)
     int row, j;                   // (kx, ky) row and |kz|
 };
+// device form of a task: trj = row << 8 | j | kTaskHasP | kTaskHasM, tw = {ff W (+j), ff W (-j)} (0 where absent);
+// A of task t sits in slots 2t, 2t + 1 of the replica
+constexpr int kTaskHasP = 1 << 30;
+constexpr int kTaskHasM = 1 << 29;
 
 struct RecipRow {
     int kx, ky;
@@ -685,12 +694,15 @@ struct AcceptBits {
     unsigned w[kAcceptWords];
 };
 
+#ifndef MGPU_RECIP_MINWAVES
+#define MGPU_RECIP_MINWAVES 4   // <= 128 VGPRs: four 4-wave workgroups per CU, 1024 items resident at once
+#endif
 constexpr int kRecipTaskChunk = 5;
 template <bool COMMIT, bool BOTH>
-__global__ __launch_bounds__(kBlock) void recip_rows_kernel(
+__global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel(
     Topo tp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
-    const RecipTask *__restrict__ tasks, int n_tasks, const RecipRow *__restrict__ rows, int n_rows,
-    const double *__restrict__ kw, double2 *__restrict__ A_base, const RecipItem *__restrict__ items,
+    const int *__restrict__ trj, const double2 *__restrict__ tw, int n_tasks, const RecipRow *__restrict__ rows, int n_rows,
+    double2 *__restrict__ A_base, const RecipItem *__restrict__ items,
     const double *__restrict__ cand_sites, int site_stride, double *__restrict__ u_new, double *__restrict__ u_old,
     AcceptBits accept, int use_accept) {
     extern __shared__ double2 s_tab[];
@@ -716,7 +728,7 @@ __global__ __launch_bounds__(kBlock) void recip_rows_kernel(
     double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
     const bool use_new = (it.kind == 0 /*MOVE*/ || it.kind == 1 /*CREATION*/);
     const bool use_old = (it.kind == 0 /*MOVE*/ || it.kind == 2 /*DELETION*/);
-    double2 *A = A_base + (size_t)it.replica * bx.nk;
+    double2 *A = A_base + (size_t)it.replica * bx.n_slots;
 
     for (int r = threadIdx.x; r < n_rows; r += kBlock) s_rows[r] = rows[r];
 
@@ -761,28 +773,23 @@ __global__ __launch_bounds__(kBlock) void recip_rows_kernel(
 
     const double2 *zt = s_tab + kofs[2];
     double acc = 0.0, acc0 = 0.0;
-    // A(k) (16 B per k, the bulk of the kernel's memory traffic), ff*W and the task records of a whole
-    // chunk are requested before any of them is used
+    // A(k) (32 contiguous bytes per task, the bulk of the kernel's memory traffic), ff*W and the task words of a
+    // whole chunk are requested before any of them is used; none of the addresses depends on a load
     for (int t0 = threadIdx.x; t0 < n_tasks; t0 += kBlock * kRecipTaskChunk) {
-        int kp[kRecipTaskChunk], km[kRecipTaskChunk], rj[kRecipTaskChunk];
-        double2 Ap[kRecipTaskChunk], Am[kRecipTaskChunk];
-        double wp[kRecipTaskChunk], wm[kRecipTaskChunk];
+        int rj[kRecipTaskChunk];
+        double2 Ap[kRecipTaskChunk], Am[kRecipTaskChunk], w[kRecipTaskChunk];
 #pragma unroll
         for (int c = 0; c < kRecipTaskChunk; ++c) {
             const int t = t0 + c * kBlock;
-            const RecipTask tk = t < n_tasks ? tasks[t] : RecipTask{-1, -1, 0, 0};
-            kp[c] = tk.kp; km[c] = tk.km; rj[c] = (tk.row << 8) | tk.j;
+            const bool in = t < n_tasks;
+            rj[c] = in ? trj[t] : 0;                                   // filler: row 0, j 0, nothing present
+            Ap[c] = in ? A[2 * t] : make_double2(0.0, 0.0);
+            Am[c] = in ? A[2 * t + 1] : make_double2(0.0, 0.0);
+            w[c] = (in && !COMMIT) ? tw[t] : make_double2(0.0, 0.0);
         }
 #pragma unroll
         for (int c = 0; c < kRecipTaskChunk; ++c) {
-            Ap[c] = kp[c] >= 0 ? A[kp[c]] : make_double2(0.0, 0.0);
-            Am[c] = km[c] >= 0 ? A[km[c]] : make_double2(0.0, 0.0);
-            wp[c] = (kp[c] >= 0 && !COMMIT) ? kw[kp[c]] : 0.0;
-            wm[c] = (km[c] >= 0 && !COMMIT) ? kw[km[c]] : 0.0;
-        }
-#pragma unroll
-        for (int c = 0; c < kRecipTaskChunk; ++c) {
-            const double2 *xy = s_xy + (rj[c] >> 8) * nss;
+            const double2 *xy = s_xy + ((rj[c] >> 8) & 0xfffff) * nss;
             const double2 *z = zt + (rj[c] & 0xff);
             double sac = 0.0, sbd = 0.0, sad = 0.0, sbc = 0.0;
             for (int s = 0; s < nss; ++s) {
@@ -792,14 +799,18 @@ __global__ __launch_bounds__(kBlock) void recip_rows_kernel(
                 sad = fma(p.x, q.y, sad);
                 sbc = fma(p.y, q.x, sbc);
             }
-            if (BOTH) acc0 += wp[c] * fma(Ap[c].x, Ap[c].x, Ap[c].y * Ap[c].y) + wm[c] * fma(Am[c].x, Am[c].x, Am[c].y * Am[c].y);
+            const double wp = w[c].x, wm = w[c].y;
+            if (BOTH) acc0 += wp * fma(Ap[c].x, Ap[c].x, Ap[c].y * Ap[c].y) + wm * fma(Am[c].x, Am[c].x, Am[c].y * Am[c].y);
             const double npx = Ap[c].x + (sac - sbd), npy = Ap[c].y + (sad + sbc);
             const double nmx = Am[c].x + (sac + sbd), nmy = Am[c].y + (sbc - sad);
             if (COMMIT) {
-                if (kp[c] >= 0) A[kp[c]] = make_double2(npx, npy);
-                if (km[c] >= 0) A[km[c]] = make_double2(nmx, nmy);
+                const int t = t0 + c * kBlock;
+                if (t < n_tasks) {        // absent members stay zero
+                    A[2 * t] = (rj[c] & kTaskHasP) ? make_double2(npx, npy) : make_double2(0.0, 0.0);
+                    A[2 * t + 1] = (rj[c] & kTaskHasM) ? make_double2(nmx, nmy) : make_double2(0.0, 0.0);
+                }
             } else {
-                acc += wp[c] * fma(npx, npx, npy * npy) + wm[c] * fma(nmx, nmx, nmy * nmy);   // ewald_energy.f90:259-266
+                acc += wp * fma(npx, npx, npy * npy) + wm * fma(nmx, nmx, nmy * nmy);   // ewald_energy.f90:259-266
             }
         }
     }
@@ -860,8 +871,9 @@ __global__ __launch_bounds__(kBlock) void sfactor_kernel(Topo tp, BoxDev bx, con
                                                          const int *__restrict__ atom_res,
                                                          const int *__restrict__ atom_mol,
                                                          const double *__restrict__ atom_q,
-                                                         const int *__restrict__ kpack, int replica,
-                                                         const double2 *__restrict__ tab, double2 *__restrict__ S) {
+                                                         const int *__restrict__ kpack, const int *__restrict__ kslot,
+                                                         int replica, const double2 *__restrict__ tab,
+                                                         double2 *__restrict__ S) {
     __shared__ double s_red[2 * kWavesPerBlock];
     const int k = blockIdx.x;
     const int kp = kpack[k];
@@ -889,7 +901,7 @@ __global__ __launch_bounds__(kBlock) void sfactor_kernel(Topo tp, BoxDev bx, con
     if (threadIdx.x == 0) {
         double a = 0.0, b = 0.0;
         for (int w = 0; w < kWavesPerBlock; ++w) { a += s_red[2 * w]; b += s_red[2 * w + 1]; }
-        S[k] = make_double2(a, b);
+        S[kslot[k]] = make_double2(a, b);            // task-ordered slot of this k
     }
 }
 
