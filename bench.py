@@ -28,16 +28,25 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def pmc_traffic_per_evaluation():
-    """HBM bytes per Delta-E evaluation of the pair sweep from the committed rocprofv3 PMC passes
-    (FETCH_SIZE doubled per the gfx950 calibration, + WRITE_SIZE); None if the summary is absent.
-    PMC cannot be collected from inside this process, so the figure comes from profiles/."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 fp64 lanes x 2 flop x 2.4 GHz (spec)
+FP64_SUSTAINED_TFLOPS = 61.0    # tools/probe_fma.hip on MI355X: what back-to-back v_fma_f64 sustains (clock under load)
+PMC_SUMMARY = os.path.join("profiles", "r02", "pmc_latest.json")
+
+
+def pmc_summary(kernel_substr):
+    """Static figures from the committed rocprofv3 --pmc passes (tools/pmc_passes.sh; PMC cannot be collected
+    from inside this process): HBM-side bytes (FETCH_SIZE doubled per the gfx950 calibration + WRITE_SIZE),
+    VALU instructions and VALU-busy share per launch of tools/bench_kernels.py's batch (1024 trial moves =
+    2048 evaluations per pair-sweep launch, as in the default bench).  None if the summary is absent."""
     try:
-        with open(path) as f:
-            return float(json.load(f)["pair_sweep_kernel"]["hbm_bytes_per_evaluation"])
+        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
+            d = json.load(f)
+        for name, e in d["kernels"].items():
+            if kernel_substr in name:
+                return dict(e, build=d.get("build"), kernel=name)
     except Exception:
-        return None
+        pass
+    return None
 
 
 def cpu_baseline(system, translation_step, rotation_step, budget_s=15.0, seed=3):
@@ -136,6 +145,51 @@ def pin_host_threads(torch, device, local_rank, local_world, n_threads):
         return None
 
 
+
+ISOTHERM_POINTS = 8            # BASELINE.json configs[4]: isotherm sweep over 8 fugacities
+
+
+def isotherm_fugacities(volume):
+    """The 8 fugacity points of the CO2 isotherm (molecules per cubic Angstrom), log-spaced 20/V .. 160/V."""
+    return np.geomspace(20.0, 160.0, ISOTHERM_POINTS) / volume
+
+
+def isotherm_points_of_rank(rank, world):
+    """Fugacity points a rank holds: dealt round-robin, so 8 GPUs hold one point each (configs[4]) and
+    one GPU holds all eight; a rank beyond the eighth repeats point rank % 8 with its own seeds."""
+    pts = [p for p in range(ISOTHERM_POINTS) if p % world == rank]
+    return pts if pts else [rank % ISOTHERM_POINTS]
+
+
+def spawn_ranks(n_gpus, argv):
+    """`bench.py --gpus N` started without a launcher: start the N ranks (one process per GPU) as a child
+    `python -m torch.distributed.run`, BEFORE anything in this process has touched the GPU (a process that has
+    initialised HIP must never be replaced or forked into GPU work), pass its output through and return its
+    exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    return subprocess.call(cmd, env=env)
+
+
+def plan_host_threads(n_threads_req, local_world):
+    cores = len(os.sched_getaffinity(0))
+    try:                                             # a cgroup CPU quota (the GPU boxes: 16 CPUs per GPU) caps it too
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = min(cores, max(1, int(q) // int(per)))
+    except Exception:
+        pass
+    if n_threads_req > 0:
+        return n_threads_req
+    return max(1, min(8, cores // max(1, local_world)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,16 +211,48 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--settle-s", type=float, default=0.5,
                     help="untimed settle phase after the warm-up steps, seconds of the same step (0: none)")
+    ap.add_argument("--workload", choices=["spce", "co2_isotherm"], default="spce",
+                    help="spce: the 10 125-atom SPC/E box, translation / rotation (BASELINE metric, default); co2_isotherm: "
+                         "configs[4], GCMC of CO2 in a 50 A box, 8 fugacity points dealt over the ranks, per-block gather "
+                         "of the uptake (molecule-count) histogram")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: every rank reports its placement (device, host threads, fugacity points) and "
+                         "rank 0 prints the rank-ordered table gathered over the process group")
+    ap.add_argument("--dump-counts", default=None, help="directory: every rank writes its chains' final molecule counts (tests)")
     args = ap.parse_args()
 
-    if args.host_threads <= 0:
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-        args.host_threads = max(1, min(8, len(os.sched_getaffinity(0)) // max(1, local_world)))
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world != max(1, args.gpus):
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    args.host_threads = plan_host_threads(args.host_threads, local_world)
     device = local_rank if args.device is None else args.device
+
+    if args.dry_run:
+        # placement rehearsal (CPU only): same process group, same exchange call, no engine
+        from maniac_mc_amd import exchange
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo" if args.dist_backend != "gloo" else args.dist_backend)
+        pts = isotherm_points_of_rank(rank, world) if args.workload == "co2_isotherm" else []
+        row = [float(rank), float(local_rank), float(device), float(args.host_threads), float(args.replicas),
+               float(len(pts)), float(pts[0] if pts else -1)]
+        table, _ = exchange.gather_block_stats(row)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "workload": args.workload,
+                              "ranks": [dict(rank=int(r[0]), local_rank=int(r[1]), device=int(r[2]), host_threads=int(r[3]),
+                                             replicas=int(r[4]), fugacity_points=int(r[5]), first_point=int(r[6]))
+                                        for r in table]}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    import torch
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
@@ -178,21 +264,36 @@ def main():
 
     pinned = None
     if args.host == "fortran" and not args.no_pin:
-        local_world_size = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-        pinned = pin_host_threads(torch, device, local_rank, local_world_size, args.host_threads)
+        pinned = pin_host_threads(torch, device, local_rank, local_world, args.host_threads)
 
     from maniac_mc_amd import _lib, synth
-    system = synth.spce_box(args.n_side)
-    t_step, r_step = 0.3, 0.3
     if args.host == "fortran":
         from maniac_mc_amd.fortran_host import FortranFarm as Farm
     else:
         from maniac_mc_amd.farm import ReplicaFarm as Farm
     kw = dict(n_threads=args.host_threads, n_lanes=args.lanes) if args.host == "fortran" else {}
-    farm = Farm(system, args.replicas, device=device, seed=1000 + rank,
-                translation_step=t_step, rotation_step=r_step, p_translation=0.5, **kw)
+    R = args.replicas
+    iso_pts, fug_grid = None, None
+    if args.workload == "spce":
+        system = synth.spce_box(args.n_side)
+        t_step, r_step = 0.3, 0.3
+        farm = Farm(system, R, device=device, seed=1000 + rank,
+                    translation_step=t_step, rotation_step=r_step, p_translation=0.5, **kw)
+    else:
+        if args.host != "fortran":
+            sys.exit("bench.py: the isotherm workload runs on the Fortran farm")
+        # configs[2] / [4]: rigid 3-site CO2, empty-ish cubic 50 A box (Nk = 2975), 25 % translation, 25 % rotation,
+        # 50 % insertion / deletion; this rank's chains are split evenly over the fugacity points it holds
+        system = synth.co2_box(64, seed=13)
+        volume = float(np.prod(np.diag(system.box_matrix)))
+        fug_grid = isotherm_fugacities(volume)
+        iso_pts = isotherm_points_of_rank(rank, world)
+        point_of_chain = np.array([iso_pts[(i * len(iso_pts)) // R] for i in range(R)])
+        t_step, r_step = 1.0, 0.6
+        farm = Farm(system, R, device=device, seed=1000 + rank, translation_step=t_step, rotation_step=r_step,
+                    mol_capacity=[400], gcmc=dict(p_translation=0.25, p_rotation=0.25, fugacity=fug_grid[point_of_chain]), **kw)
     eng = farm.eng
-    N, Nk, R = system.n_atoms, eng.nk, args.replicas
+    N, Nk = system.n_atoms, eng.nk
 
     # profiling on BEFORE the warm-up: the first event-carrying dispatch of a stream costs ~7 ms once
     eng.profile_enable(True)
@@ -215,17 +316,28 @@ def main():
         torch.cuda.synchronize()
 
     fence()
+    trials0 = farm.trials if hasattr(farm, "trials") else 0
     t0 = time.perf_counter()
     accepted = farm.run(args.steps)
     # the path's one real exchange step: per-block all-gather of every rank's counters and
-    # molecule-count histogram (NVT here, so the histogram is a single bin; the message size is the same)
-    n_now = [int(system.n_mol[0])] * R
-    sums_by_rank, hist_by_rank = exchange.gather_block_stats(
-        [float(accepted), float(args.steps * R)], exchange.molecule_count_histogram(n_now, 5001))
+    # molecule-count histogram (NVT: a single bin per rank, the message size is the same; isotherm: one
+    # histogram of the chains' current N per fugacity point, ISOTHERM_POINTS x 5001 bins)
+    nbins = 5001
+    trials_now = float(farm.trials - trials0) if hasattr(farm, "trials") else float(args.steps * R)
+    if args.workload == "spce":
+        hist = exchange.molecule_count_histogram([int(system.n_mol[0])] * R, nbins)
+    else:
+        counts = farm.counts()[:, 0]
+        hist = np.concatenate([exchange.molecule_count_histogram(counts[point_of_chain == p], nbins)
+                               for p in range(ISOTHERM_POINTS)])
+    sums_by_rank, hist_by_rank = exchange.gather_block_stats([float(accepted), trials_now], hist)
     fence()
     elapsed = exchange.max_over_ranks(time.perf_counter() - t0)
     tot_acc, tot_trials = float(sums_by_rank[:, 0].sum()), float(sums_by_rank[:, 1].sum())
     assert int(hist_by_rank.sum()) == R * world
+    if args.dump_counts and args.workload == "co2_isotherm":
+        os.makedirs(args.dump_counts, exist_ok=True)
+        np.savez(os.path.join(args.dump_counts, f"rank{rank}.npz"), counts=counts, point_of_chain=point_of_chain)
 
     n_pair, ms_pair = eng.profile_get(_lib.KERNEL_PAIR)
     n_rec, ms_rec = eng.profile_get(_lib.KERNEL_RECIP)
@@ -235,7 +347,7 @@ def main():
     # flight the kernels of different lanes share the CUs, which raises throughput but stretches every
     # kernel's own duration; this gives the kernel's un-shared time for comparison.
     iso_us = None
-    if rank == 0 and args.host == "fortran":
+    if rank == 0 and args.host == "fortran" and args.workload == "spce":
         rng = np.random.default_rng(5)
         n_l = max(1, R // farm.n_lanes)
         m_iso = rng.integers(0, int(system.n_mol[0]), n_l).astype(np.int32)
@@ -256,9 +368,26 @@ def main():
         n_lanes = farm.n_lanes if args.host == "fortran" else 1
         evals_per_launch = (2 * R) / n_lanes
         avg_pair_s = ms_pair / max(1, n_pair) * 1e-3
-        achieved = bytes_pair_eval * evals_per_launch / avg_pair_s / 1e9 if n_pair else 0.0
+        alg_gbs = bytes_pair_eval * evals_per_launch / avg_pair_s / 1e9 if n_pair else 0.0
         evals_total = 2.0 * tot_trials
-        traffic_eval = pmc_traffic_per_evaluation()
+        # The pair sweep is bound by fp64 VALU issue, not by HBM (its measured memory-side traffic is a third of the
+        # algorithmic bytes and it sits at ~80 % VALU-busy), so the headline fraction is VALU work against the
+        # fp64 vector peak: every VALU instruction slot counted as one 64-lane FMA (2 flop), i.e. achieved =
+        # VALU wave-instructions x 128 / launch time.  The instruction count per launch is the PMC figure
+        # (SQ_INSTS_VALU of the same batch shape); the launch time is measured live by the dispatch events.
+        pmc = pmc_summary("pair_sweep_kernel<3, false, false, true>") or pmc_summary("pair_sweep_kernel")
+        pmc_evals = 2048.0
+        scale = evals_per_launch / pmc_evals
+        valu_instr = pmc["valu_instr_per_launch"] * scale if pmc and pmc.get("valu_instr_per_launch") else None
+        valu_tflops = valu_instr * 128.0 / avg_pair_s / 1e12 if (valu_instr and n_pair) else None
+        iso = None
+        if iso_us:
+            iso = {"avg_launch_us": iso_us,
+                   "achieved": valu_instr * 128.0 / (iso_us * 1e-6) / 1e12 if valu_instr else None,
+                   "frac": valu_instr * 128.0 / (iso_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if valu_instr else None,
+                   "algorithmic_hbm_GBs": bytes_pair_eval * evals_per_launch / (iso_us * 1e-6) / 1e9,
+                   "note": "same batch launched alone after the timed region; in the timed region the kernels of "
+                           "the lanes overlap on the device"}
         out = {
             "metric": "MC moves/sec", "value": tot_acc / elapsed, "unit": "accepted MC moves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -273,23 +402,57 @@ def main():
             "acceptance": tot_acc / max(1.0, tot_trials),
             "ns_per_dE_eval": elapsed / evals_total * 1e9 * world,
             "ns_per_dE_eval_note": "wall time per Delta-E evaluation per GPU (pair sweep + k sweep), host loop included",
-            "roofline": {"bound": "hbm", "kernel": "pair_sweep_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (traffic_eval * evals_per_launch) if traffic_eval else None,
-                         "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
-                         "algorithmic_bytes_per_launch": bytes_pair_eval * evals_per_launch,
-                         "avg_launch_us": avg_pair_s * 1e6, "launches": n_pair,
-                         "isolated": None if not iso_us else {
-                             "avg_launch_us": iso_us, "achieved": bytes_pair_eval * evals_per_launch / (iso_us * 1e-6) / 1e9,
-                             "frac": bytes_pair_eval * evals_per_launch / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                             "note": "same batch launched alone after the timed region; in the timed region the "
-                                     "kernels of the lanes overlap on the device"},
+            "roofline": {"bound": "valu", "bound_note": "fp64 vector issue (the contract's hbm / mfma do not apply: measured HBM-side "
+                                                         "traffic is 0.34 x the algorithmic bytes, no MFMA-shaped work; SURVEY 8(d))",
+                         "kernel": "pair_sweep_kernel<3,false,false,true> (old + new state of a trial move in one sweep)",
+                         "achieved": valu_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": valu_tflops / FP64_VECTOR_PEAK_TFLOPS if valu_tflops else None,
+                         "traffic": pmc["hbm_bytes_per_launch"] * scale if pmc and pmc.get("hbm_bytes_per_launch") else None,
+                         "traffic_source": f"static: {PMC_SUMMARY} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch, build "
+                                           f"{pmc.get('build') if pmc else None}; not a measurement of this run)",
+                         "avg_launch_us": avg_pair_s * 1e6, "launches": n_pair, "evaluations_per_launch": evals_per_launch,
+                         "valu": {"instr_per_launch": valu_instr, "valu_busy": pmc.get("valu_busy") if pmc else None,
+                                  "lds_busy": pmc.get("lds_busy") if pmc else None,
+                                  "frac_of_sustained_fma_rate": valu_tflops / FP64_SUSTAINED_TFLOPS if valu_tflops else None,
+                                  "sustained_peak": FP64_SUSTAINED_TFLOPS,
+                                  "source": f"static: {PMC_SUMMARY} (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x busy cycles)); "
+                                            "sustained peak from tools/probe_fma.hip"},
+                         "hbm": {"algorithmic_bytes_per_launch": bytes_pair_eval * evals_per_launch,
+                                 "algorithmic_equivalent_GBs": alg_gbs, "peak": HBM_PEAK_GBS,
+                                 "algorithmic_frac": alg_gbs / HBM_PEAK_GBS,
+                                 "note": "36 N bytes per evaluation (SURVEY 8(d)) / launch time: an algorithmic figure served mostly "
+                                         "from L2 / Infinity Cache, NOT an HBM utilisation"},
+                         "isolated": iso,
                          "job_frac": (evals_total / world / elapsed) * bytes_eval / 1e9 / HBM_PEAK_GBS,
                          "recip_avg_launch_us": ms_rec / max(1, n_rec) * 1e3, "commit_avg_launch_us": ms_com / max(1, n_com) * 1e3},
         }
+        if args.workload == "co2_isotherm":
+            # configs[4]: GCMC isotherm.  Trials are move SELECTIONS that reach the engine (no-op selections of the
+            # reference -- empty type, full type -- are skipped by the host); an insertion / deletion costs ONE
+            # evaluation, so the SPC/E roofline figures do not carry over: report the launch times only.
+            hist_pts = hist_by_rank.reshape(world, ISOTHERM_POINTS, nbins).sum(axis=0)
+            nn = np.arange(nbins)
+            out["config"] = {"workload": f"co2_isotherm_{ISOTHERM_POINTS}fugacities_50A_box_Nk{Nk}", "replicas_per_gpu": R,
+                             "host_driver": args.host, "host_threads": args.host_threads, "lanes": farm.n_lanes,
+                             "host_cores": pinned, "moves": "25% translation / 25% rotation / 50% insertion-deletion, 300 K",
+                             "parallelism": f"replicas x{world}; fugacity points dealt round-robin over the ranks"}
+            out["isotherm"] = [{"fugacity_molecules_per_A3": float(fug_grid[p]), "chains": int(hist_pts[p].sum()),
+                                "mean_N": float((hist_pts[p] * nn).sum() / max(1, hist_pts[p].sum())),
+                                "N_min": int(nn[hist_pts[p] > 0].min()) if hist_pts[p].sum() else None,
+                                "N_max": int(nn[hist_pts[p] > 0].max()) if hist_pts[p].sum() else None}
+                               for p in range(ISOTHERM_POINTS)]
+            out["exchange"] = {"collective": "all_gather", "backend": args.dist_backend if world > 1 else None,
+                               "bytes_per_rank": int(hist.nbytes + 16), "per": "block (= the timed region)"}
+            out["roofline"] = {"bound": "valu", "kernel": "pair_sweep_kernel (fused old + new for moves, single state for insertions / deletions)",
+                               "achieved": None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                               "avg_launch_us": avg_pair_s * 1e6, "launches": n_pair,
+                               "recip_avg_launch_us": ms_rec / max(1, n_rec) * 1e3, "commit_avg_launch_us": ms_com / max(1, n_com) * 1e3,
+                               "note": "not the BASELINE metric's workload: launch times only"}
+            for k in ("ns_per_dE_eval", "ns_per_dE_eval_note"):
+                out.pop(k, None)
         if hasattr(farm, "timers"):
             out["host_seconds"] = {k: v - timers0[k] for k, v in farm.timers().items()}   # timed region only
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "spce":
             out["cpu_baseline"] = cpu_baseline(system, t_step, r_step, budget_s=args.cpu_budget)
         print(json.dumps(out))
     farm.close()
