@@ -120,6 +120,15 @@ def make(name, s, moves, store_coords=True, n_amp_store=None):
 
 
 def main():
+    only = set(sys.argv[1:])
+
+    def make_if(name, *a, **k):
+        if not only or name in only:
+            make(name, *a, **k)
+    _main(make_if)
+
+
+def _main(make):
     make("spce216", synth.spce_box(6),
          [(0, 5, [0.11, -0.07, 0.13], 0, 0.0), (0, 40, [0, 0, 0], 1, 0.21), (0, 215, [-0.14, 0.02, 0.1], 2, -0.13)])
     make("mixture", synth.mixture_box(),
@@ -132,6 +141,10 @@ def main():
     make("spce1000_scalars", synth.spce_box(10), [(0, 17, [0.1, 0.05, -0.12], 1, 0.2), (0, 999, [-0.1, 0.1, 0.1], 2, -0.1)],
          store_coords=False, n_amp_store=64)
     make("spce3375_scalars", synth.spce_box(15), [(0, 100, [0.1, 0.05, -0.12], 1, 0.2), (0, 3374, [-0.1, 0.1, 0.1], 2, -0.1)],
+         store_coords=False, n_amp_store=64)
+    # BASELINE.json configs[3] at its stated size: the 2208-atom inactive framework + 40 four-site waters in a 34 A box
+    make("framework2208_scalars", synth.framework_water_box(),
+         [(1, 3, [0.2, -0.1, 0.1], 2, 0.2), (1, 39, [0.05, 0.1, -0.2], 0, -0.15), (1, 17, [-0.3, 0.25, 0.1], 1, 0.4)],
          store_coords=False, n_amp_store=64)
 
 

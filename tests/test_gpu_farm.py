@@ -167,3 +167,39 @@ def test_farm_at_benchmark_size_three_lanes():
         eng.init_structure_factor(r, True)
         assert np.max(np.abs(A - eng.structure_factor(r))) < 1e-9
     farm.close()
+
+
+def test_gcmc_farm_framework_water_at_stated_size():
+    """BASELINE.json configs[3] at its stated size: the 2208-atom inactive framework (site-major sweep, 35
+    chunks per molecule) + 4-site water as the adsorbate, full move set (translation / rotation / insertion /
+    deletion) on 12 chains at two fugacities.  Bookkeeping invariants: counts, running 5-component energies
+    and A(k) equal a from-scratch evaluation of every chain's final configuration; host mirrors equal the device."""
+    from maniac_mc_amd.fortran_host import FortranFarm
+    s = synth.framework_water_box()
+    assert s.topo.atoms_in_res[0] == 2208 and s.topo.atoms_in_res[1] == 4
+    R = 12
+    V = 34.0 ** 3
+    fug = np.repeat([30.0, 80.0], R // 2) / V
+    farm = FortranFarm(s, R, seed=23, translation_step=0.5, rotation_step=0.5, n_threads=4, mol_capacity=[1, 120],
+                       gcmc=dict(p_translation=0.25, p_rotation=0.25, fugacity=fug))
+    farm.run(400)
+    c = farm.counters()
+    assert c["trial_creations"] > 0 and c["trial_deletions"] > 0 and c["creations"] > 0 and c["deletions"] > 0
+    assert c["translations"] > 0 and c["rotations"] > 0
+    eng = farm.eng
+    counts = farm.counts()[:, 0]
+    assert counts.min() >= 0 and len(set(counts.tolist())) > 1
+    for r in range(R):
+        assert eng.num_molecules(r, 1) == counts[r] and eng.num_molecules(r, 0) == 1
+        e = eng.system_energy(r)
+        run = farm.energy(r)
+        ref = np.array([e[k] for k in ("non_coulomb", "coulomb", "recip_coulomb", "ewald_self", "intra_coulomb")])
+        assert np.max(np.abs(run - ref)) < 2e-5 * max(1.0, np.max(np.abs(ref)) * 1e-6), (r, run - ref)
+        A = eng.structure_factor(r)
+        eng.init_structure_factor(r, True)
+        assert np.max(np.abs(A - eng.structure_factor(r))) < 1e-9
+        dev = eng.get_molecules(r, 1)
+        for slot in range(counts[r]):
+            com, off = farm.molecule(r, 0, slot)
+            assert np.array_equal(dev[slot], com[None, :] + off[:4])
+    farm.close()

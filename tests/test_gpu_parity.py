@@ -31,7 +31,7 @@ def amp_close(a, b, what=""):
     assert err <= 1e-10, f"{what}: max |dA| = {err:.3e}"
 
 
-@pytest.mark.parametrize("name", GOLDEN_FULL + ["spce1000_scalars", "spce3375_scalars"])
+@pytest.mark.parametrize("name", GOLDEN_FULL + ["spce1000_scalars", "spce3375_scalars", "framework2208_scalars"])
 def test_engine_vs_golden(name):
     g, s = golden_system(name)
     eng = Engine.from_system(s, n_replicas=2)

@@ -30,7 +30,7 @@ def test_exports_match_header(hiplib):
     assert hiplib.mgpu_abi_version() == 1
 
 
-@pytest.mark.parametrize("name", GOLDEN_FULL + ["spce1000_scalars", "spce3375_scalars"])
+@pytest.mark.parametrize("name", GOLDEN_FULL + ["spce1000_scalars", "spce3375_scalars", "framework2208_scalars"])
 def test_host_setup_bitwise_vs_reference(name, hiplib):
     from maniac_mc_amd import engine
     g = load_golden(name)

@@ -34,7 +34,8 @@ def system_from_golden(g):
 
 # fixtures with stored coordinates, and the seeded generators for the scalar-only ones
 GOLDEN_FULL = ["spce216", "mixture", "argon256", "co2_20", "framework_small"]
-GOLDEN_SCALARS = {"spce1000_scalars": lambda: synth.spce_box(10), "spce3375_scalars": lambda: synth.spce_box(15)}
+GOLDEN_SCALARS = {"spce1000_scalars": lambda: synth.spce_box(10), "spce3375_scalars": lambda: synth.spce_box(15),
+                  "framework2208_scalars": lambda: synth.framework_water_box()}
 
 
 def golden_system(name):
