@@ -141,6 +141,29 @@ def five_site_water_box(n_mol=24, L=20.0, seed=13, rc=9.0, tol=1e-5, temperature
                   label=f"water5_{n_mol}mol")
 
 
+def rigid_adsorbate_box(n_mol=6, n_sites=24, L=26.0, seed=17, rc=10.0, tol=1e-5, temperature=300.0):
+    """A rigid adsorbate of ``n_sites`` (default 24) sites: two stacked 12-rings of alternating +-0.25 e sites of
+    two atom types (entirely synthetic).  With 24 sites the row-form reciprocal kernel's XY table exceeds its
+    LDS budget, so this molecule can only take the per-k kernel (and the generic-site-count pair sweep)."""
+    rng = np.random.default_rng(seed)
+    per_ring = n_sites // 2
+    ang = 2 * np.pi * np.arange(per_ring) / per_ring
+    ring = np.stack([2.4 * np.cos(ang), 2.4 * np.sin(ang), np.zeros(per_ring)], 1)
+    tmpl = np.vstack([ring + [0, 0, 0.9], ring[:n_sites - per_ring] @ np.array([[np.cos(0.26), -np.sin(0.26), 0],
+                                                                                [np.sin(0.26), np.cos(0.26), 0], [0, 0, 1]]).T - [0, 0, 0.9]])
+    tmpl = tmpl - tmpl.mean(0)
+    types = np.array([1 + (i % 2) for i in range(n_sites)], dtype=np.int32)
+    q = np.array([0.25 if i % 2 == 0 else -0.25 for i in range(n_sites)])
+    q -= q.mean()
+    eps, sig = lorentz_berthelot([0.09, 0.06], [3.3, 3.0])
+    topo = Topology(atoms_in_res=[n_sites], atom_types=[types], charges=[q], is_active=[1], epsilon=eps, sigma=sig,
+                    names=["CAGE"])
+    com = _spread_points(rng, n_mol, L, min_sep=8.5)
+    off = np.einsum("mij,aj->mai", _random_rotations(rng, n_mol), tmpl)
+    return System(topo, np.diag([L, L, L]), np.full(3, -L / 2), rc, tol, temperature, [com], [off],
+                  label=f"cage{n_sites}_{n_mol}mol")
+
+
 def _spread_points(rng, n, L, min_sep):
     """n points in [-L/2, L/2)^3 with pairwise minimum-image separation >= min_sep."""
     pts = np.empty((0, 3))

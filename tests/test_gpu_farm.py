@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("maker,R,steps", [(lambda: synth.spce_box(6, seed=3), 7, 40), (lambda: synth.co2_box(24, seed=5), 4, 60),
                                            (lambda: synth.mixture_box(seed=4), 5, 50),
-                                           (lambda: synth.mixture_box(seed=4, tilt=(1.5, -0.8, 0.6)), 4, 50)])
+                                           (lambda: synth.mixture_box(seed=4, tilt=(1.5, -0.8, 0.6)), 4, 50),
+                                           (lambda: synth.rigid_adsorbate_box(), 3, 30)])
 def test_fortran_farm_consistency(maker, R, steps):
     from maniac_mc_amd.fortran_host import FortranFarm
     s = maker()

@@ -111,7 +111,8 @@ def test_engine_vs_golden(name):
                                         (lambda: synth.co2_box(16, seed=2), 2),
                                         (lambda: synth.framework_water_box(n_water=10, n_frame=260, L=23.0, seed=9), 2),
                                         (lambda: synth.mixture_box(seed=6, tilt=(1.5, -0.8, 0.6)), 2),
-                                        (lambda: synth.five_site_water_box(), 2)])
+                                        (lambda: synth.five_site_water_box(), 2),
+                                        (lambda: synth.rigid_adsorbate_box(), 2)])
 def test_batched_candidates_vs_refcpu(maker, nrep, refcpu_mod):
     """Many candidates per launch, on replicas holding DIFFERENT configurations."""
     rng = np.random.default_rng(7)
@@ -394,4 +395,63 @@ def test_maximum_molecule_count(refcpu_mod):
         P.restore_fourier(0, m)
         close(old[0], exp_old, f"full box, molecule {m}, old")
         close(new[0], exp_new, f"full box, molecule {m}, new")
+    eng.close()
+
+
+def test_per_k_kernel_is_the_only_path_for_a_24_site_adsorbate(refcpu_mod):
+    """A 24-site rigid adsorbate: the row-form k sweep's LDS tables exceed its 40 KiB budget, so the per-k kernel is
+    what runs -- no environment switch.  Trial energies, a committed move (A(k) and coordinates), an insertion
+    and a deletion against the oracle."""
+    s = synth.rigid_adsorbate_box()
+    n1 = int(s.topo.atoms_in_res[0])
+    eng = Engine.from_system(s, n_replicas=2, mol_capacity=[10])
+    kv = eng.kvectors()
+    ktot = int(eng.kmax.sum()) + 3
+    n_rows = len(set(zip(kv["kx"].tolist(), kv["ky"].tolist())))
+    rows_lds = 2 * n1 * ktot * 16 + n1 * 8 + n_rows * (2 * n1 * 16 + 8)      # recip_rows_lds_bytes (mgpu_engine.hip)
+    assert rows_lds > 40 * 1024, "this molecule is meant to overflow the row form's LDS budget"
+    assert 2 * n1 * ktot * 16 + n1 * 8 <= 64 * 1024
+    for r in range(2):
+        eng.init_structure_factor(r, True)
+    P = refcpu_mod.RefCPU(s, mol_capacity=10)
+    e_sys = P.system_energy()
+    P.init_amplitude(True)
+    P.set_energy_recip(e_sys["recip_coulomb"])
+    amp_close(eng.structure_factor(0), P.amplitude(), "S(k)")
+    rng = np.random.default_rng(3)
+    n = int(s.n_mol[0])
+    # --- a trial move of every molecule, evaluated in one batch
+    sites = np.zeros((n, n1, 3)); exp_old = np.zeros((n, 3)); exp_new = np.zeros((n, 3))
+    for m in range(n):
+        com, off = P.get_molecule(0, m)
+        P.save_fourier(0, m)
+        exp_old[m] = P.old_energy(0, m, 0)[:3]
+        sites[m] = P.apply_pbc(com + rng.uniform(-0.3, 0.3, 3))[None, :] + off @ P.rotation_matrix(1 + m % 3, 0.2).T
+        P.set_molecule(0, m, sites[m, 0], sites[m] - sites[m, 0][None, :])
+        exp_new[m] = P.new_energy(0, m, 0)[:3]
+        if m != 2:
+            P.set_molecule(0, m, com, off)
+            P.restore_fourier(0, m)
+        else:
+            A_after = P.amplitude()                      # molecule 2 stays moved: the committed state
+            P.set_molecule(0, m, com, off)
+            P.restore_fourier(0, m)
+    old, new = eng.trial_energy_candidates(np.zeros(n, np.int32), np.zeros(n, np.int32), np.arange(n, dtype=np.int32), sites)
+    close(old, exp_old, "24-site old")
+    close(new, exp_new, "24-site new")
+    # --- commit the move of molecule 2 on replica 1 through a lane (resident rows; per-k commit kernel)
+    eng.commit_candidates([1], [0], [2], [MGPU_MOVE], sites[2:3], [1])
+    amp_close(eng.structure_factor(1), A_after, "A after the committed move")
+    assert np.array_equal(eng.get_molecules(1, 0)[2], sites[2])
+    # --- insertion / deletion energies on replica 0
+    csite = (s.bounds_lo + np.array([0.31, 0.77, 0.52]) * 26.0)[None, :] + s.offsets[0][0] @ P.rotation_matrix(2, 0.9).T
+    exp_o = P.old_energy(0, n, 1)[:5]
+    P.set_num_residues(0, n + 1)
+    P.save_fourier(0, n)
+    P.set_molecule(0, n, csite[0], csite - csite[0][None, :])
+    exp_n = P.new_energy(0, n, 1)[:5]
+    P.set_num_residues(0, n)
+    o5, n5 = eng.gcmc_trial([0], [0], [-1], [MGPU_CREATION], csite[None], lane=0)
+    close(o5[0], exp_o, "24-site creation old")
+    close(n5[0], exp_n, "24-site creation new")
     eng.close()
