@@ -43,6 +43,7 @@ extern "C" {
 #define MGPU_DELETION 2  /* A -= sum q phi_old                deletion               */
 #define MGPU_NONE 3      /* A unchanged: E = sum ff W |A|^2   (ComputeOldEnergy's recip call, where
                             the new tables equal the saved ones, monte_carlo_utils.f90:388)    */
+#define MGPU_FOURIER_ADD 4 /* mgpu_structure_factor_add only: A += sum q phi(sites), nothing else changes */
 
 /* which kernel mgpu_profile_get() reports */
 #define MGPU_KERNEL_PAIR 0
@@ -153,6 +154,13 @@ int mgpu_init_structure_factor(mgpu_engine *e, int replica, int mode);
 /* a[n_kvectors][2] = (re, im) of ewald%recip_amplitude */
 int mgpu_get_structure_factor(mgpu_engine *e, int replica, double *a);
 int mgpu_set_structure_factor(mgpu_engine *e, int replica, const double *a);
+/* A(k) <- A(k) + sum_a q_a exp(i k . sites_a) for ONE molecule of residue type t given by its site coordinates
+ * (the "creation" line of ComputeRecipEnergySingleMol, ewald_energy.f90:241-246) -- coordinates, molecule counts
+ * and everything else stay as they are.  A neutral building block: a host loop that wants the reference's
+ * deletion update exactly as written (monte_carlo_utils.f90:308 passes is_creation = deletion_flag, so A gains
+ * the swapped-in molecule's terms) composes it from mgpu_replica_replace_molecule, mgpu_replica_set_num_molecules
+ * and this call; no kernel knows about that mode.  sites: [atoms_in_res[t]][3]. */
+int mgpu_structure_factor_add(mgpu_engine *e, int replica, int t, const double *sites);
 
 /* ------------------------------------------------------------------------------------------
  * Batched per-move energies.  A candidate c is (replica[c], t[c], m[c], sites[c]):

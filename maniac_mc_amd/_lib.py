@@ -25,7 +25,7 @@ EXPORTS = [
     "mgpu_ewald_kvectors", "mgpu_coulomb_table_eval", "mgpu_engine_create", "mgpu_engine_destroy", "mgpu_engine_get_ewald",
     "mgpu_engine_get_kvectors", "mgpu_replica_set_molecules", "mgpu_replica_get_molecules",
     "mgpu_replica_num_molecules", "mgpu_replica_copy", "mgpu_system_energy", "mgpu_init_structure_factor",
-    "mgpu_get_structure_factor", "mgpu_set_structure_factor", "mgpu_pair_energy_candidates",
+    "mgpu_get_structure_factor", "mgpu_set_structure_factor", "mgpu_structure_factor_add", "mgpu_pair_energy_candidates",
     "mgpu_recip_energy_candidates", "mgpu_self_energy", "mgpu_intra_energy_candidates",
     "mgpu_trial_energy_candidates", "mgpu_commit_candidates", "mgpu_trial_submit", "mgpu_trial_wait",
     "mgpu_commit_submit", "mgpu_gcmc_trial_submit", "mgpu_gcmc_trial_wait", "mgpu_replica_replace_molecule",

@@ -842,6 +842,22 @@ int mgpu_set_structure_factor(mgpu_engine *e, int replica, const double *a) {
     return MGPU_OK;
 }
 
+int mgpu_structure_factor_add(mgpu_engine *e, int replica, int t, const double *sites) {
+    int rc = check_replica_t(e, replica, t);
+    if (rc) return rc;
+    if (!sites) return set_error(MGPU_ERR_INVALID_ARG, "structure_factor_add: null sites");
+    if ((rc = use_device(e))) return rc;
+    if ((rc = mgpu_synchronize(e))) return rc;
+    Lane &ln = e->lanes[0];
+    const int n1 = e->tp.n1[t];
+    RecipItem it{replica, t, -1, MGPU_FOURIER_ADD, 0, 0};
+    if ((rc = ln.d_items2.reserve(sizeof(RecipItem)))) return rc;
+    HIP_TRY(hipMemcpyAsync(ln.d_items2.p, &it, sizeof(RecipItem), hipMemcpyHostToDevice, ln.stream));
+    if ((rc = upload_sites(ln, sites, 1, n1))) return rc;
+    if ((rc = launch_recip(e, ln, (const RecipItem *)ln.d_items2.p, 1, n1, n1, true, e->d_A, nullptr))) return rc;
+    return sync_stream(e);
+}
+
 // ---- batched candidates ----------------------------------------------------------------------
 
 int mgpu_pair_energy_candidates(mgpu_engine *e, int n, const int *replica, const int *t, const int *m,

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kBlock) void recip_kernel(
     double *s_q = reinterpret_cast<double *>(s_tab + 2 * n1 * ktot);
     double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
     double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
-    const bool use_new = (it.kind == 0 /*MOVE*/ || it.kind == 1 /*CREATION*/);
+    const bool use_new = (it.kind == 0 /*MOVE*/ || it.kind == 1 /*CREATION*/ || it.kind == 4 /*FOURIER_ADD*/);
     const bool use_old = (it.kind == 0 /*MOVE*/ || it.kind == 2 /*DELETION*/);
 
     for (int e = threadIdx.x; e < 2 * n1 * ktot; e += kBlock) {
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(kBlock) void recip_kernel(
                 px[j] = px[jl]; py[j] = py[jl]; pz[j] = pz[jl];
             }
         }
-        if (threadIdx.x == 0 && it.kind != 0) nmol[it.replica * tp.n_res + it.t] = it.aux;
+        if (threadIdx.x == 0 && (it.kind == 1 || it.kind == 2)) nmol[it.replica * tp.n_res + it.t] = it.aux;
     }
 }
 
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
     RecipRow *s_rows = reinterpret_cast<RecipRow *>(s_q + n1);
     double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
     double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
-    const bool use_new = (it.kind == 0 /*MOVE*/ || it.kind == 1 /*CREATION*/);
+    const bool use_new = (it.kind == 0 /*MOVE*/ || it.kind == 1 /*CREATION*/ || it.kind == 4 /*FOURIER_ADD*/);
     const bool use_old = (it.kind == 0 /*MOVE*/ || it.kind == 2 /*DELETION*/);
     double2 *A = A_base + (size_t)it.replica * bx.n_slots;
 
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
                 px[j] = px[jl]; py[j] = py[jl]; pz[j] = pz[jl];
             }
         }
-        if (threadIdx.x == 0 && it.kind != 0) nmol[it.replica * tp.n_res + it.t] = it.aux;
+        if (threadIdx.x == 0 && (it.kind == 1 || it.kind == 2)) nmol[it.replica * tp.n_res + it.t] = it.aux;
     }
 }
 

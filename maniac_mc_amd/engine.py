@@ -153,6 +153,11 @@ class Engine:
     def replica_copy(self, dst, src):
         check(self.L.mgpu_replica_copy(self.h, C.c_int(dst), C.c_int(src)))
 
+    def structure_factor_add(self, replica, t, sites):
+        """A(k) += sum_a q_a exp(i k . sites_a) for one molecule of type t; nothing else changes."""
+        a = np.ascontiguousarray(sites, dtype=np.float64)[: int(self.topo.atoms_in_res[t])]
+        check(self.L.mgpu_structure_factor_add(self.h, C.c_int(replica), C.c_int(t), _d(np.ascontiguousarray(a))))
+
     def replace_molecule(self, replica, t, m_dst, m_src):
         check(self.L.mgpu_replica_replace_molecule(self.h, C.c_int(replica), C.c_int(t), C.c_int(m_dst),
                                                    C.c_int(m_src)))

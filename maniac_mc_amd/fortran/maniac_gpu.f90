@@ -87,6 +87,27 @@ module maniac_gpu
             real(c_double), intent(out) :: out(6)
             integer(c_int) :: rc
         end function
+        function mgpu_replica_replace_molecule(e, replica, t, m_dst, m_src) &
+                bind(C, name="mgpu_replica_replace_molecule") result(rc)
+            import :: c_ptr, c_int
+            type(c_ptr), value :: e
+            integer(c_int), value :: replica, t, m_dst, m_src
+            integer(c_int) :: rc
+        end function
+        function mgpu_replica_set_num_molecules(e, replica, t, n_mol) &
+                bind(C, name="mgpu_replica_set_num_molecules") result(rc)
+            import :: c_ptr, c_int
+            type(c_ptr), value :: e
+            integer(c_int), value :: replica, t, n_mol
+            integer(c_int) :: rc
+        end function
+        function mgpu_structure_factor_add(e, replica, t, sites) bind(C, name="mgpu_structure_factor_add") result(rc)
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: e
+            integer(c_int), value :: replica, t
+            real(c_double), intent(in) :: sites(*)
+            integer(c_int) :: rc
+        end function
         function mgpu_init_structure_factor(e, replica, mode) bind(C, name="mgpu_init_structure_factor") result(rc)
             import :: c_ptr, c_int
             type(c_ptr), value :: e

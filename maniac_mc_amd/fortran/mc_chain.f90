@@ -19,6 +19,13 @@
 !   ApplyPBC                          src/geometry_utils.f90:167-213
 ! Differences from the reference, both deliberate (SURVEY F2 / F3): A(k) is initialised to S(k) by
 ! ComputeSystemEnergy, and a deletion's new reciprocal energy removes the deleted molecule.
+! mchain_set_as_written(1) selects the reference's deletion exactly as written instead (F3): DeleteMolecule
+! compacts first (RemoveMolecule: slot m <- last slot, delete_molecule.f90:99-116) and ComputeNewEnergy then calls
+! ComputeRecipEnergySingleMol with is_creation = deletion_flag (monte_carlo_utils.f90:308), so A(k) GAINS the
+! terms of the molecule now sitting in slot m and keeps them when the move is accepted.  That mode lives in
+! this host loop only: it is composed from the engine's neutral primitives (a creation-kind reciprocal energy
+! of the swapped-in molecule's sites; on acceptance mgpu_replica_replace_molecule, mgpu_replica_set_num_molecules
+! and mgpu_structure_factor_add) -- no kernel knows about it.  Intended physics stays the default.
 ! Energies are evaluated against the engine's resident state; nothing is saved or restored on
 ! rejection (the reference's Save/RestoreSingleMolFourier have no counterpart).
 !===============================================================================
@@ -35,7 +42,7 @@ module mc_chain
     public :: mchain_reset, mchain_set_box, mchain_set_residue, mchain_set_bonded, mchain_set_tables, &
               mchain_set_moves, mchain_set_reservoir_box, mchain_set_reservoir_residue, mchain_run, &
               mchain_get_energy, mchain_get_counters, mchain_get_counts, mchain_get_molecule, mchain_get_steps, &
-              mchain_set_mode
+              mchain_set_mode, mchain_set_as_written
 
     real(real64), parameter :: PI = 3.14159265358979323846_real64, TWOPI = 2.0_real64 * PI
     real(real64), parameter :: zero = 0.0_real64, one = 1.0_real64, half = 0.5_real64, three = 3.0_real64
@@ -53,6 +60,8 @@ module mc_chain
     ! .true.: one batched engine call per move (mgpu_gcmc_trial_submit / wait with one candidate, resident-row
     ! commit) instead of one call per reference seam -- same energies, a third of the launches and waits
     logical, save :: fused = .true.
+    ! .true.: the reference's deletion update as written (SURVEY F3); see the header
+    logical, save :: as_written = .false.
 
 contains
 
@@ -338,6 +347,11 @@ contains
         fused = seams == 0
     end subroutine mchain_set_mode
 
+    subroutine mchain_set_as_written(on) bind(C, name="mchain_set_as_written")
+        integer(c_int), value :: on
+        as_written = on /= 0
+    end subroutine mchain_set_as_written
+
     !---------------------------------------------------------------------------
     ! Both energy states of a move from ONE engine call (fused mode): the candidate's sites are the
     ! molecule's current com + offsets in the host state; `old` / `new` are filled exactly as
@@ -537,7 +551,7 @@ contains
     subroutine delete_molecule(t, m)
         integer, intent(in) :: t, m
         real(real64) :: old(6), new(6), p, trial(3), com_old(3)
-        real(real64), allocatable :: off_old(:, :), off_last(:, :)
+        real(real64), allocatable :: off_old(:, :), off_last(:, :), sites_last(:, :)
         integer :: n1, last, stat
         if (S%res(t)%count == 0) return
         n1 = S%res(t)%n1
@@ -553,6 +567,15 @@ contains
         else
             call molecule_energy(t, m, new, .false., .true., .true.)
         end if
+        if (as_written) then
+            ! ComputeNewEnergy as written (monte_carlo_utils.f90:301-309): after RemoveMolecule slot m holds the
+            ! former last molecule, and the reciprocal update runs with is_creation = .true. on that slot
+            new = zero
+            call ComputeRecipEnergySingleMol(S%engine, t, last, S%res(t)%com(:, last), S%res(t)%off(:, 1:n1, last), n1, &
+                                             new(IE_RECIP), is_creation=.true., stat=stat)
+            call note(stat)
+            new(IE_TOTAL) = new(IE_NONC) + new(IE_COUL) + new(IE_RECIP) + new(IE_SELF) + new(IE_INTRA)
+        end if
         off_last = S%res(t)%off(:, :, last)
         S%res(t)%com(:, m) = S%res(t)%com(:, last)
         S%res(t)%off(:, :, m) = S%res(t)%off(:, :, last)
@@ -567,7 +590,18 @@ contains
             S%energy(IE_INTRA) = S%energy(IE_INTRA) + new(IE_INTRA) - old(IE_INTRA)
             S%energy(IE_TOTAL) = S%energy(IE_TOTAL) + new(IE_TOTAL) - old(IE_TOTAL)
             S%counter(C_D) = S%counter(C_D) + 1
-            if (fused) then
+            if (as_written) then
+                ! coordinates and count as RemoveMolecule leaves them; A(k) keeps the swapped-in molecule's terms
+                allocate(sites_last(3, n1))
+                call MoleculeSites(S%res(t)%com(:, m), S%res(t)%off(:, 1:n1, m), n1, sites_last)   ! slot m now = former last
+                stat = mgpu_replica_replace_molecule(S%engine, 0_c_int, int(t - 1, c_int), int(m - 1, c_int), int(last - 1, c_int))
+                call note(stat)
+                stat = mgpu_replica_set_num_molecules(S%engine, 0_c_int, int(t - 1, c_int), int(last - 1, c_int))
+                call note(stat)
+                stat = mgpu_structure_factor_add(S%engine, 0_c_int, int(t - 1, c_int), sites_last)
+                call note(stat)
+                deallocate(sites_last)
+            else if (fused) then
                 call fused_commit(t, m, MGPU_DELETION)
             else
                 call GpuAcceptMove(S%engine, t, m, MGPU_DELETION, com_old, off_old(:, 1:n1), n1, stat=stat)

@@ -50,7 +50,7 @@ def _mol_arrays(com, off, n1):
 
 
 def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoir_path=None, device=0,
-                   mol_capacity=None, nb_block=None, nb_step=None, seams=False):
+                   mol_capacity=None, nb_block=None, nb_step=None, seams=False, as_written=False):
     """Run the chain; returns a dict with the final energies (K), counters, molecule counts, step sizes.
 
     ``seed``: None -> the input file's ``seed`` if present, else the generator is left unseeded
@@ -58,6 +58,9 @@ def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoi
     ``mol_capacity``: molecule slots per residue type (default: NB_MAX_MOLECULE for active types).
     ``seams``: True -> one engine call per reference seam (ComputePairInteractionEnergy_singlemol, ...), the literal
     integration of INTEGRATION.md; False (default) -> one batched call per move, same energies, ~3x fewer waits.
+    ``as_written``: True -> the reference's deletion update exactly as written (A(k) gains the swapped-in
+    molecule's terms, monte_carlo_utils.f90:308), composed in the host loop from neutral engine primitives; for
+    charged grand-canonical runs this reproduces the reference's files but not the intended physics (default False).
     """
     system, inp, dat = io_maniac.load_system(maniac_path, data_path, inc_path, with_data=True)
     topo = system.topo
@@ -94,6 +97,7 @@ def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoi
         ntypes = np.array([dat["type_counts"][k] for k in ("bonds", "angles", "dihedrals", "impropers")], dtype=np.int32)
         H.mchain_set_tables(masses.ctypes.data_as(_dp), ntypes.ctypes.data_as(_ip))
         H.mchain_set_mode(C.c_int(1 if seams else 0))
+        H.mchain_set_as_written(C.c_int(1 if as_written else 0))
         H.mchain_set_moves(C.c_double(inp.translation_step), C.c_double(inp.rotation_step_angle),
                            C.c_double(inp.translation_proba), C.c_double(inp.rotation_proba),
                            C.c_int(1 if inp.recalibrate_moves else 0))
@@ -143,12 +147,15 @@ def main(argv=None):
     ap.add_argument("-o", dest="out", default="outputs/", help="output directory")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--as-written", action="store_true",
+                    help="the reference's deletion update exactly as written (SURVEY F3) instead of the intended physics")
     a = ap.parse_args(argv)
     for path, what in ((a.maniac, "Input"), (a.data, "Data"), (a.inc, "Parameter"), (a.reservoir, "Reservoir")):
         if path is not None and not os.path.isfile(path):
             print(f"{what} file not found: {path}", file=sys.stderr)
             return 1
-    res = run_simulation(a.maniac, a.data, a.inc, a.out, seed=a.seed, reservoir_path=a.reservoir, device=a.device)
+    res = run_simulation(a.maniac, a.data, a.inc, a.out, seed=a.seed, reservoir_path=a.reservoir, device=a.device,
+                         as_written=a.as_written)
     e = res["energy"]
     print(f"final energy (K): total {e['total']:.6f}  non_coulomb {e['non_coulomb']:.6f}  coulomb {e['coulomb']:.6f}  "
           f"recip {e['recip_coulomb']:.6f};  molecules {res['n_mol'].tolist()};  output in {os.path.join(a.out, '')}")

@@ -4,9 +4,13 @@ for them (its own MonteCarloLoop, writers and log), run through oracle/_ref with
 
     python tests/golden/make_run_fixtures.py
 
-Runs only where oracle/_ref exists (needs /root/reference + amdflang at build time).  Charged systems are
-run without insertion / deletion: the reference's deletion passes the wrong flag to its reciprocal
-update, so its charged GCMC trajectories are not the intended physics.
+    python tests/golden/make_run_fixtures.py [case ...]      (no arguments: every case)
+
+Runs only where oracle/_ref exists (needs /root/reference + amdflang at build time).  The reference's deletion
+passes the wrong flag to its reciprocal update, so its CHARGED grand-canonical trajectories are not the
+intended physics; the cases marked as_written (co2_gcmc = BASELINE.json configs[2], framework_water_gcmc =
+configs[3] in miniature) are the reference's files all the same, and the chain driver reproduces them in its
+as-written mode (mchain_set_as_written); every other case is identical in both modes.
 Layout: tests/golden/runs/<case>/inputs/{system.maniac,system.data,system.inc[,reservoir.data]},
         tests/golden/runs/<case>/expected/<the reference's output files>, log_mc.txt = log.maniac from the
         "Started Monte Carlo Loop" box on, with the output path blanked.
@@ -71,13 +75,32 @@ def cases():
                                           translation_proba=0.5, rotation_proba=0.5, recalibrate_moves=False,
                                           masses=[12.0] * 7 + [15.9994, 1.008, 1e-4], fugacity_atm=[1.0, 1.0]), None
     yield "dumbbell_gcmc_reservoir", d, kw, dumbbell_box(n_mol=40, L=30.0, seed=9)
+    # charged grand-canonical runs, the reference exactly as it is (F3 included)
+    co2 = synth.co2_box(8, seed=21)                      # configs[2]: 50 A box, rc 12 -> kmax 11, Nk = 2975
+    yield "co2_gcmc", co2, dict(nb_block=4, nb_step=250, translation_step=1.0, rotation_step_angle=0.5,
+                                translation_proba=0.2, rotation_proba=0.2, insertion_deletion_proba=0.6,
+                                fugacity_atm=[12.0], recalibrate_moves=False, masses=[12.011, 15.9994],
+                                atom_names=["C", "O"]), None
+    yield "framework_water_gcmc", fw, dict(nb_block=4, nb_step=200, translation_step=0.3, rotation_step_angle=0.3,
+                                           translation_proba=0.25, rotation_proba=0.25, insertion_deletion_proba=0.5,
+                                           recalibrate_moves=False, masses=[12.0] * 7 + [15.9994, 1.008, 1e-4],
+                                           fugacity_atm=[1.0, 40.0]), None
+
+
+AS_WRITTEN = {"co2_gcmc", "framework_water_gcmc"}
 
 
 def main():
-    if os.path.isdir(RUNS):
+    only = set(sys.argv[1:])
+    spath = os.path.join(RUNS, "summary.json")
+    summary = json.load(open(spath)) if (only and os.path.exists(spath)) else {}
+    if not only and os.path.isdir(RUNS):
         shutil.rmtree(RUNS)
-    summary = {}
     for name, system, kw, reservoir in cases():
+        if only and name not in only:
+            continue
+        if os.path.isdir(os.path.join(RUNS, name)):
+            shutil.rmtree(os.path.join(RUNS, name))
         inputs = os.path.join(RUNS, name, "inputs")
         expected = os.path.join(RUNS, name, "expected")
         files = io_maniac.write_input_files(system, inputs, **kw)
@@ -105,9 +128,9 @@ def main():
                     shutil.copy(os.path.join(out, f), os.path.join(expected, f))
         last = open(os.path.join(expected, "moves.dat")).read().strip().split("\n")[-1].split()
         summary[name] = dict(seed=SEED, files=sorted(os.listdir(expected)), last_moves_record=last,
-                             reservoir=bool(reservoir))
+                             reservoir=bool(reservoir), as_written=name in AS_WRITTEN)
         print(name, last)
-    json.dump(summary, open(os.path.join(RUNS, "summary.json"), "w"), indent=1)
+    json.dump(dict(sorted(summary.items())), open(spath, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -455,3 +455,27 @@ def test_per_k_kernel_is_the_only_path_for_a_24_site_adsorbate(refcpu_mod):
     close(o5[0], exp_o, "24-site creation old")
     close(n5[0], exp_n, "24-site creation new")
     eng.close()
+
+
+def test_structure_factor_add_primitive(refcpu_mod):
+    """mgpu_structure_factor_add: A(k) += sum q exp(i k . sites) and nothing else (coordinates, counts); two adds of
+    a molecule's own sites after its committed deletion restore 'A + S_mol' -- the composition the as-written host
+    mode uses."""
+    s = synth.co2_box(12, seed=3)
+    eng = Engine.from_system(s, n_replicas=1, mol_capacity=[20])
+    eng.init_structure_factor(0, True)
+    P = refcpu_mod.RefCPU(s, mol_capacity=20)
+    P.system_energy(); P.init_amplitude(True)
+    A0 = eng.structure_factor(0)
+    sites = s.all_sites(0)[5] + np.array([0.3, -0.2, 0.1])
+    eng.structure_factor_add(0, 0, sites)
+    # oracle: creation-kind update of A with those sites
+    n = int(s.n_mol[0])
+    P.set_num_residues(0, n + 1)
+    P.save_fourier(0, n)
+    P.set_molecule(0, n, sites[0], sites - sites[0][None, :])
+    P.new_energy(0, n, 1)
+    amp_close(eng.structure_factor(0), P.amplitude(), "A after structure_factor_add")
+    assert eng.num_molecules(0, 0) == n and np.array_equal(eng.get_molecules(0, 0), s.all_sites(0))
+    assert np.max(np.abs(eng.structure_factor(0) - A0)) > 1e-3
+    eng.close()
