@@ -19,6 +19,8 @@ import os
 import sys
 import time
 
+ORIG_AFFINITY = os.sched_getaffinity(0)      # before any OpenMP runtime binds this thread to its place
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -49,7 +51,7 @@ def pmc_summary(kernel_substr):
     return None
 
 
-def cpu_baseline(system, translation_step, rotation_step, budget_s=15.0, seed=3):
+def cpu_baseline(system, translation_step, rotation_step, budget_s=15.0, seed=3, all_cores_budget_s=6.0):
     """The reference itself (oracle/_ref, amdflang -O2, 1 thread) -- or, if that build is not on
     this box, the C restatement -- running the same Metropolis trial sequentially for a bounded
     number of moves.  Reported beside the GPU number; it is a baseline, not the target."""
@@ -83,11 +85,41 @@ def cpu_baseline(system, translation_step, rotation_step, budget_s=15.0, seed=3)
         el = time.perf_counter() - t0
         if el >= budget_s:
             break
-    return {"value": accepted / el, "unit": "accepted MC moves/s", "cores": 1, "kind": kind,
-            "sample": f"{trials} sequential translation/rotation trials ({2 * trials} Delta-E evaluations) of the same "
-                      f"{system.n_atoms}-atom box in {el:.1f} s",
-            "trial_moves_per_s": trials / el, "ns_per_dE_eval": el / (2 * trials) * 1e9,
-            "acceptance": accepted / max(1, trials)}
+    out = {"value": accepted / el, "unit": "accepted MC moves/s", "cores": 1, "kind": kind,
+           "sample": f"{trials} sequential translation/rotation trials ({2 * trials} Delta-E evaluations) of the same "
+                     f"{system.n_atoms}-atom box in {el:.1f} s",
+           "trial_moves_per_s": trials / el, "ns_per_dE_eval": el / (2 * trials) * 1e9,
+           "acceptance": accepted / max(1, trials)}
+    if all_cores_budget_s > 0:
+        # the Fortran driver's OpenMP runtime has bound this thread to one core and left OMP_PLACES in the
+        # environment: undo both before the oracle's own OpenMP runtime (libgomp) starts
+        os.sched_setaffinity(0, ORIG_AFFINITY)
+        os.environ.pop("OMP_PLACES", None)
+        os.environ.pop("OMP_PROC_BIND", None)
+        # SURVEY 8(d)(ii), labelled extra: the C restatement (oracle/refcpu.c, kind "port") running one independent
+        # chain per host core with OpenMP -- the same replica-level parallelism the GPU farm uses
+        cores = usable_cores()
+        try:
+            el2, tr, ac = refcpu.trial_farm(system, cores, cores, all_cores_budget_s, translation_step, rotation_step)
+            out["all_cores"] = {"value": float(ac.sum()) / el2, "unit": "accepted MC moves/s", "cores": cores, "kind": "port",
+                                "sample": f"{cores} independent chains (one per core, OpenMP) x the same sequential trial for "
+                                          f"{el2:.1f} s: {int(tr.sum())} trials ({2 * int(tr.sum())} Delta-E evaluations)",
+                                "trial_moves_per_s": float(tr.sum()) / el2,
+                                "ns_per_dE_eval_per_core": el2 / (2.0 * max(1.0, float(tr.mean()))) * 1e9}
+        except Exception as exc:                       # the extra leg must never take the bench line down
+            out["all_cores"] = {"error": str(exc)}
+    return out
+
+
+def usable_cores():
+    cores = len(ORIG_AFFINITY)
+    try:                                             # a cgroup CPU quota (the GPU boxes: 16 CPUs per GPU) caps it too
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = min(cores, max(1, int(q) // int(per)))
+    except Exception:
+        pass
+    return cores
 
 
 def _cpulist(text):
@@ -178,13 +210,7 @@ def spawn_ranks(n_gpus, argv):
 
 
 def plan_host_threads(n_threads_req, local_world):
-    cores = len(os.sched_getaffinity(0))
-    try:                                             # a cgroup CPU quota (the GPU boxes: 16 CPUs per GPU) caps it too
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            cores = min(cores, max(1, int(q) // int(per)))
-    except Exception:
-        pass
+    cores = usable_cores()
     if n_threads_req > 0:
         return n_threads_req
     return max(1, min(8, cores // max(1, local_world)))
@@ -208,7 +234,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of the 1-core reference leg")
+    ap.add_argument("--cpu-all-cores-budget", type=float, default=6.0,
+                    help="seconds of the labelled all-core OpenMP leg of the C restatement (0: skip)")
     ap.add_argument("--settle-s", type=float, default=0.5,
                     help="untimed settle phase after the warm-up steps, seconds of the same step (0: none)")
     ap.add_argument("--workload", choices=["spce", "co2_isotherm"], default="spce",
@@ -453,7 +481,8 @@ def main():
         if hasattr(farm, "timers"):
             out["host_seconds"] = {k: v - timers0[k] for k, v in farm.timers().items()}   # timed region only
         if world == 1 and not args.no_cpu_baseline and args.workload == "spce":
-            out["cpu_baseline"] = cpu_baseline(system, t_step, r_step, budget_s=args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(system, t_step, r_step, budget_s=args.cpu_budget,
+                                                all_cores_budget_s=args.cpu_all_cores_budget)
         print(json.dumps(out))
     farm.close()
     if dist is not None:

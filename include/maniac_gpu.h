@@ -37,6 +37,17 @@ extern "C" {
 #define MGPU_ERR_NO_DEVICE 4
 #define MGPU_ERR_STATE 5
 
+/* Environment switches, all read ONCE in mgpu_engine_create and all for tuning / tests only (defaults are the
+ * measured best; none changes results beyond the last bits of a sum order):
+ *   MGPU_PAIR_NSPLIT=<n>        waves per pair-sweep item (default: engine constant from the topology's capacity
+ *                               and the replica count, see engine_nsplit in mgpu_engine.hip)
+ *   MGPU_PAIR_BLOCKS_PER_CU=<n> resident pair-sweep workgroups per CU (default 2)
+ *   MGPU_PAIR_NO_FUSE=1         trial moves as two single-state sweeps instead of one fused old + new sweep
+ *   MGPU_RECIP_PER_K=1          per-k reciprocal kernel even where the row form's LDS tables fit
+ * Threading rule: one host thread drives an engine at a time; lanes must hold disjoint replicas while their
+ * trials / commits are in flight; every synchronous entry point that reads or rewrites replica state drains all
+ * lanes first. */
+
 /* candidate kinds for the reciprocal-space update, ewald_energy.f90:241-256 */
 #define MGPU_MOVE 0      /* A += sum q (phi_new - phi_old)   translation / rotation */
 #define MGPU_CREATION 1  /* A += sum q phi_new                insertion              */
@@ -95,6 +106,13 @@ int mgpu_ewald_kvectors(const double reciprocal[9], double alpha, const int kmax
  * box).  This evaluates the same table with the same arithmetic on the host, for accuracy checks:
  * out[i] = erfc(alpha sqrt(r2[i])) / sqrt(r2[i]) for r2[i] > 0; r2_max bounds the table range. */
 int mgpu_coulomb_table_eval(double alpha, double r2_max, int n, const double *r2, double *out);
+
+/* Seeds for a farm of independent chains: state[4 * n_streams] receives one xoshiro256+ state per chain, each
+ * filled from its own splitmix64 stream (Blackman & Vigna's recommended seeding; all-zero states cannot occur),
+ * started at mix(seed) + r * odd constant -- unsigned 64-bit arithmetic, which Fortran does not have.  The
+ * reference seeds ONE intrinsic generator with seed + 37 (i - 1) (random_utils.f90:33-56); a farm needs R
+ * statistically independent streams instead (host utility, no device involved). */
+int mgpu_rng_seed_streams(long long seed, int n_streams, long long *state);
 
 /* ------------------------------------------------------------------------------------------
  * Engine life cycle

@@ -135,6 +135,7 @@ struct mgpu_engine {
     int pair_blocks_per_cu = 2;      // resident pair-sweep workgroups per CU (VGPR / LDS bound)
     int pair_nsplit = 1;             // waves per pair-sweep item: an engine constant (see engine_nsplit)
     bool pair_fuse = true;           // trial moves sweep old + new together (MGPU_PAIR_NO_FUSE=1: tuning / A-B only)
+    bool recip_force_per_k = false;  // MGPU_RECIP_PER_K=1: per-k reciprocal kernel even where the row form fits (tests)
     double *d_res_q = nullptr;
     int *d_res_atype = nullptr;
     int *d_atom_res = nullptr, *d_atom_mol = nullptr;
@@ -197,6 +198,14 @@ int sync_lane(mgpu_engine *e, Lane &ln) {
     return prof_collect(e, ln);
 }
 int sync_stream(mgpu_engine *e) { return sync_lane(e, e->lanes[0]); }
+// The synchronous entry points that read or rewrite replica state (coordinates, counts, A(k)) on lane 0's stream or
+// the null stream first drain EVERY lane: the lanes' streams are non-blocking, so work still queued on lanes 1-3
+// would otherwise race with them.
+int sync_all_lanes(mgpu_engine *e) {
+    for (auto &ln : e->lanes)
+        if (int rc = sync_lane(e, ln)) return rc;
+    return MGPU_OK;
+}
 
 int check_candidate(const mgpu_engine *e, int c, int replica, int t, int m, bool need_resident) {
     if (replica < 0 || replica >= e->n_replicas)
@@ -329,8 +338,7 @@ size_t recip_rows_lds_bytes(const mgpu_engine *e, int n1_max) {
 // d_u_old != nullptr: also return the energy of the unchanged A(k) from the same pass (trial moves)
 // row form while its XY table fits the LDS budget (molecules of a few sites), else the per-k form
 bool recip_by_rows(const mgpu_engine *e, int n1_max) {
-    static const bool force_per_k = getenv("MGPU_RECIP_PER_K") != nullptr;
-    return !force_per_k && e->n_rtasks > 0 && recip_rows_lds_bytes(e, n1_max) <= 40 * 1024;
+    return !e->recip_force_per_k && e->n_rtasks > 0 && recip_rows_lds_bytes(e, n1_max) <= 40 * 1024;
 }
 
 // accept != nullptr (commit, row form only): d_items are the candidates of the lane's last trial and only
@@ -492,6 +500,7 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     tp.n_cap_atoms = off;
     e->pair_nsplit = engine_nsplit(e);
     e->pair_fuse = std::getenv("MGPU_PAIR_NO_FUSE") == nullptr;
+    e->recip_force_per_k = std::getenv("MGPU_RECIP_PER_K") != nullptr;
 
     BoxDev &bx = e->bx;
     for (int d = 0; d < 3; ++d) { bx.L[d] = box_matrix[d * 3 + d]; bx.invL[d] = 1.0 / bx.L[d]; bx.kmax[d] = e->kmax[d]; }
@@ -711,7 +720,7 @@ int mgpu_replica_set_molecules(mgpu_engine *e, int replica, int t, int n_mol, co
             const size_t j = tp.site_major[t] ? (size_t)m * n1 + a : (size_t)a * cap + m;
             for (int d = 0; d < 3; ++d) st[d * seg + j] = sites[((size_t)m * n1 + a) * 3 + d];
         }
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if ((rc = sync_all_lanes(e))) return rc;
     for (int d = 0; d < 3; ++d)
         HIP_TRY(hipMemcpy(e->d_pos + ((size_t)replica * 3 + d) * tp.n_cap_atoms + tp.seg_off[t], st + d * seg,
                           seg * sizeof(double), hipMemcpyHostToDevice));
@@ -732,7 +741,7 @@ int mgpu_replica_get_molecules(mgpu_engine *e, int replica, int t, int *n_mol, d
     rc = e->h_stage.reserve(3 * seg * sizeof(double));
     if (rc) return rc;
     double *st = (double *)e->h_stage.p;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if ((rc = sync_all_lanes(e))) return rc;
     for (int d = 0; d < 3; ++d)
         HIP_TRY(hipMemcpy(st + d * seg, e->d_pos + ((size_t)replica * 3 + d) * tp.n_cap_atoms + tp.seg_off[t],
                           seg * sizeof(double), hipMemcpyDeviceToHost));
@@ -757,7 +766,7 @@ int mgpu_replica_set_num_molecules(mgpu_engine *e, int replica, int t, int n_mol
     if (rc) return rc;
     if (n_mol < 0 || n_mol > e->tp.cap[t]) return set_error(MGPU_ERR_CAPACITY, "n_mol exceeds mol_capacity");
     if ((rc = use_device(e))) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if ((rc = sync_all_lanes(e))) return rc;
     e->h_nmol[replica * e->tp.n_res + t] = n_mol;
     HIP_TRY(hipMemcpy(e->d_nmol + replica * e->tp.n_res + t, &n_mol, sizeof(int), hipMemcpyHostToDevice));
     return MGPU_OK;
@@ -769,6 +778,7 @@ int mgpu_replica_copy(mgpu_engine *e, int dst, int src) {
     if ((rc = check_replica_t(e, src, 0))) return rc;
     if (dst == src) return MGPU_OK;
     if ((rc = use_device(e))) return rc;
+    if ((rc = sync_all_lanes(e))) return rc;
     const Topo &tp = e->tp;
     HIP_TRY(hipMemcpyAsync(e->d_pos + (size_t)dst * 3 * tp.n_cap_atoms, e->d_pos + (size_t)src * 3 * tp.n_cap_atoms,
                            (size_t)3 * tp.n_cap_atoms * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
@@ -788,6 +798,7 @@ int mgpu_replica_replace_molecule(mgpu_engine *e, int replica, int t, int m_dst,
         return set_error(MGPU_ERR_INVALID_ARG, "molecule slot out of range");
     if (m_dst == m_src) return MGPU_OK;
     if ((rc = use_device(e))) return rc;
+    if ((rc = sync_all_lanes(e))) return rc;
     const int n1 = tp.n1[t];
     for (int d = 0; d < 3; ++d) {
         double *base = e->d_pos + ((size_t)replica * 3 + d) * tp.n_cap_atoms + tp.seg_off[t];
@@ -808,6 +819,7 @@ int mgpu_init_structure_factor(mgpu_engine *e, int replica, int mode) {
     int rc = check_replica_t(e, replica, 0);
     if (rc) return rc;
     if ((rc = use_device(e))) return rc;
+    if ((rc = sync_all_lanes(e))) return rc;
     double2 *A = e->d_A + (size_t)replica * e->n_slots;
     if (mode == 0) {
         HIP_TRY(hipMemsetAsync(A, 0, e->n_slots * sizeof(double2), e->stream));
@@ -822,7 +834,7 @@ int mgpu_get_structure_factor(mgpu_engine *e, int replica, double *a) {
     if (rc) return rc;
     if (!a) return set_error(MGPU_ERR_INVALID_ARG, "null buffer");
     if ((rc = use_device(e))) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if ((rc = sync_all_lanes(e))) return rc;
     // the device keeps A(k) in task order; hand it out in the reference's k order
     std::vector<double2> slots(e->n_slots);
     HIP_TRY(hipMemcpy(slots.data(), e->d_A + (size_t)replica * e->n_slots, e->n_slots * sizeof(double2), hipMemcpyDeviceToHost));
@@ -835,7 +847,7 @@ int mgpu_set_structure_factor(mgpu_engine *e, int replica, const double *a) {
     if (rc) return rc;
     if (!a) return set_error(MGPU_ERR_INVALID_ARG, "null buffer");
     if ((rc = use_device(e))) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if ((rc = sync_all_lanes(e))) return rc;
     std::vector<double2> slots(e->n_slots, make_double2(0.0, 0.0));
     for (int k = 0; k < e->nk; ++k) slots[e->kslot[k]] = make_double2(a[2 * k], a[2 * k + 1]);
     HIP_TRY(hipMemcpy(e->d_A + (size_t)replica * e->n_slots, slots.data(), e->n_slots * sizeof(double2), hipMemcpyHostToDevice));
@@ -1302,6 +1314,7 @@ int mgpu_system_energy(mgpu_engine *e, int replica, double out[6]) {
     if (rc) return rc;
     if (!out) return set_error(MGPU_ERR_INVALID_ARG, "null out");
     if ((rc = use_device(e))) return rc;
+    if ((rc = sync_all_lanes(e))) return rc;
     const Topo &tp = e->tp;
     // ComputePairwiseEnergy (energy_utils.f90:83-115): one ordered item per molecule, results
     // accumulated on the host in the reference's (type, molecule) order.

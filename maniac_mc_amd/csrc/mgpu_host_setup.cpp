@@ -241,6 +241,27 @@ int mgpu_coulomb_table_eval(double alpha, double r2_max, int n, const double *r2
     return MGPU_OK;
 }
 
+int mgpu_rng_seed_streams(long long seed, int n_streams, long long *state) {
+    if (n_streams < 0 || (n_streams > 0 && !state)) return mgpu::set_error(MGPU_ERR_INVALID_ARG, "mgpu_rng_seed_streams: bad argument");
+    auto splitmix = [](unsigned long long &x) {
+        unsigned long long z = (x += 0x9e3779b97f4a7c15ULL);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+        return z ^ (z >> 31);
+    };
+    unsigned long long base = (unsigned long long)seed;
+    base = splitmix(base);                                   // decorrelate neighbouring user seeds
+    for (int r = 0; r < n_streams; ++r) {
+        unsigned long long x = base + 0xd1342543de82ef95ULL * (unsigned long long)(r + 1);
+        unsigned long long w[4];
+        do {
+            for (auto &v : w) v = splitmix(x);
+        } while ((w[0] | w[1] | w[2] | w[3]) == 0ULL);
+        for (int i = 0; i < 4; ++i) state[4 * (size_t)r + i] = (long long)w[i];
+    }
+    return MGPU_OK;
+}
+
 int mgpu_ewald_kvectors(const double reciprocal[9], double alpha, const int kmax[3], int n_kvectors, int *kx, int *ky,
                         int *kz, double *k2mag, double *form_factor, double *weights) {
     return mgpu::ewald_kvectors(reciprocal, alpha, kmax, n_kvectors, kx, ky, kz, k2mag, form_factor, weights);

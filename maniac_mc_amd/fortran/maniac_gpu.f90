@@ -87,6 +87,13 @@ module maniac_gpu
             real(c_double), intent(out) :: out(6)
             integer(c_int) :: rc
         end function
+        function mgpu_rng_seed_streams(seed, n_streams, state) bind(C, name="mgpu_rng_seed_streams") result(rc)
+            import :: c_int, c_long_long
+            integer(c_long_long), value :: seed
+            integer(c_int), value :: n_streams
+            integer(c_long_long), intent(out) :: state(*)
+            integer(c_int) :: rc
+        end function
         function mgpu_replica_replace_molecule(e, replica, t, m_dst, m_src) &
                 bind(C, name="mgpu_replica_replace_molecule") result(rc)
             import :: c_ptr, c_int

@@ -47,6 +47,7 @@ module mc_farm
     private
     public :: mfarm_create, mfarm_run, mfarm_destroy, mfarm_get_energy, mfarm_get_molecule, mfarm_recalibrate
     public :: mfarm_get_timers, mfarm_set_gcmc, mfarm_get_counts, mfarm_get_counters, mfarm_set_triclinic
+    public :: mfarm_rng_sample
 
     real(real64), parameter :: PI = 3.14159265358979323846_real64
     real(real64), parameter :: TWOPI = 2.0_real64 * PI
@@ -79,7 +80,8 @@ module mc_farm
         integer, allocatable :: cnt(:, :)                  ! (n_active, R)  primary%num_residues
         ! host mirror of primary%mol_com / primary%site_offset: one contiguous record per molecule,
         ! mol(1:3) = com, mol(3a+1:3a+3) = offset of site a -- one cache / TLB miss per random gather
-        real(real64), allocatable :: mol(:, :, :)          ! (3 + 3*max_n1, cap_total, R)
+        real(real64), pointer :: mol(:, :, :) => null()    ! (3 + 3*max_n1, cap_total, R); 2 MiB-aligned, MADV_HUGEPAGE
+        type(c_ptr) :: mol_raw = c_null_ptr                ! its allocation (posix_memalign)
         real(real64), allocatable :: energy(:, :)          ! (5, R) non_coulomb, coulomb, recip, self, intra
         real(real64), allocatable :: fugacity(:, :)        ! (n_active, R) molecules per cubic Angstrom
         real(real64) :: lo(3), len(3), volume, temperature, translation_step, rotation_step
@@ -99,55 +101,78 @@ module mc_farm
 
     type(farm_state), save, target :: F
 
+    interface
+        function c_posix_memalign(ptr, alignment, bytes) bind(C, name="posix_memalign") result(rc)
+            import :: c_ptr, c_size_t, c_int
+            type(c_ptr), intent(out) :: ptr
+            integer(c_size_t), value :: alignment, bytes
+            integer(c_int) :: rc
+        end function
+        function c_madvise(addr, bytes, advice) bind(C, name="madvise") result(rc)
+            import :: c_ptr, c_size_t, c_int
+            type(c_ptr), value :: addr
+            integer(c_size_t), value :: bytes
+            integer(c_int), value :: advice
+            integer(c_int) :: rc
+        end function
+        subroutine c_free(ptr) bind(C, name="free")
+            import :: c_ptr
+            type(c_ptr), value :: ptr
+        end subroutine
+    end interface
+
 contains
 
+    ! The host mirror is several hundred MB of 96-byte records gathered at random: with 4 KiB pages every gather
+    ! also misses the TLB and walks a page table that is itself out of cache.  Ask for transparent huge pages
+    ! (the GPU boxes run THP in madvise mode); a refusal changes nothing but speed.
+    subroutine alloc_mirror(n_rec, n_slots, n_rep)
+        integer, intent(in) :: n_rec, n_slots, n_rep
+        integer(c_size_t) :: bytes
+        integer(c_int) :: rc
+        integer(c_int), parameter :: MADV_HUGEPAGE = 14
+        integer(c_size_t), parameter :: HUGE = 2097152_c_size_t
+        bytes = int(n_rec, c_size_t) * int(n_slots, c_size_t) * int(n_rep, c_size_t) * 8_c_size_t
+        bytes = ((bytes + HUGE - 1) / HUGE) * HUGE
+        rc = c_posix_memalign(F%mol_raw, HUGE, bytes)
+        if (rc /= 0 .or. .not. c_associated(F%mol_raw)) error stop "mc_farm: cannot allocate the host mirror"
+        rc = c_madvise(F%mol_raw, bytes, MADV_HUGEPAGE)
+        call c_f_pointer(F%mol_raw, F%mol, [n_rec, n_slots, n_rep])
+    end subroutine alloc_mirror
+
+
     ! seed_rng (src/random_utils.f90:33-56): seed + 37*(i-1) for the intrinsic generator; every chain
-    ! additionally owns a xoshiro256+ generator (Blackman & Vigna) whose state is derived from the same
-    ! rule and the chain index, so a chain's random numbers do not depend on how many chains run beside it
+    ! additionally owns a xoshiro256+ generator (Blackman & Vigna) seeded from its own splitmix64 stream
+    ! (mgpu_rng_seed_streams: the authors' recommended seeding, in unsigned 64-bit arithmetic on the C side), so
+    ! the chains' streams are statistically independent and a chain's random numbers do not depend on how many
+    ! chains run beside it
     subroutine seed_farm_rng(seed, n_chains)
         integer, intent(in) :: seed, n_chains
-        integer :: n, i, r, k
+        integer :: n, i
+        integer(c_int) :: rc
         integer, allocatable :: s(:)
-        integer(int64) :: x, t, s1, s2, s3, s4
         call random_seed(size=n)
         allocate(s(n))
         s = seed + 37 * [(i - 1, i = 1, n)]
         call random_seed(put=s)
         if (allocated(F%cxs)) deallocate(F%cxs)
         allocate(F%cxs(4, n_chains))
-        do r = 1, n_chains
-            do i = 1, 4
-                x = int(seed + 37 * (i - 1), int64) + 88172645463325252_int64 * int(i, int64) + &
-                    1000003_int64 * int(r, int64)
-                do k = 1, 3                                ! xorshift64 rounds: spread the small differences
-                    x = ieor(x, ishft(x, 13))
-                    x = ieor(x, ishft(x, -7))
-                    x = ieor(x, ishft(x, 17))
-                end do
-                F%cxs(i, r) = x
-            end do
-            if (all(F%cxs(:, r) == 0_int64)) F%cxs(1, r) = 1_int64
-            ! run the generator in: its first outputs still mirror the seeding rule
-            s1 = F%cxs(1, r); s2 = F%cxs(2, r); s3 = F%cxs(3, r); s4 = F%cxs(4, r)
-            do k = 1, 16
-                t = ishft(s2, 17)
-                s3 = ieor(s3, s1); s4 = ieor(s4, s2); s2 = ieor(s2, s3); s1 = ieor(s1, s4)
-                s3 = ieor(s3, t)
-                s4 = ior(ishft(s4, 45), ishft(s4, -19))
-            end do
-            F%cxs(:, r) = [s1, s2, s3, s4]
-        end do
+        rc = mgpu_rng_seed_streams(int(seed, c_long_long), int(n_chains, c_int), F%cxs)
     end subroutine seed_farm_rng
 
-    ! NRAND uniform numbers in [0, 1) from chain r's generator: top 53 bits of s1 + s4
+    ! NRAND uniform numbers in [0, 1) from chain r's generator: top 53 bits of (s1 + s4) mod 2^64.  The sum is
+    ! formed without relying on signed overflow: q = floor((s1 + s4) / 4) from the operands' upper 62 bits plus the
+    ! carry of their two low bits (q < 2^63), of which bits 9..61 are bits 11..63 of the 64-bit sum.
     subroutine chain_random(r, u)
         integer, intent(in) :: r
         real(real64), intent(out) :: u(NRAND)
         integer :: i
-        integer(int64) :: t, s1, s2, s3, s4
+        integer(int64) :: t, s1, s2, s3, s4, q
+        integer(int64), parameter :: MASK62 = 4611686018427387903_int64          ! 2^62 - 1
         s1 = F%cxs(1, r); s2 = F%cxs(2, r); s3 = F%cxs(3, r); s4 = F%cxs(4, r)
         do i = 1, NRAND
-            u(i) = real(ishft(s1 + s4, -11), real64) * (1.0_real64 / 9007199254740992.0_real64)
+            q = ishft(s1, -2) + ishft(s4, -2) + ishft(iand(s1, 3_int64) + iand(s4, 3_int64), -2)
+            u(i) = real(ishft(iand(q, MASK62), -9), real64) * (1.0_real64 / 9007199254740992.0_real64)
             t = ishft(s2, 17)
             s3 = ieor(s3, s1); s4 = ieor(s4, s2); s2 = ieor(s2, s3); s1 = ieor(s1, s4)
             s3 = ieor(s3, t)
@@ -198,7 +223,8 @@ contains
             tot = tot + cap(ia)
         end do
         F%cap_total = tot
-        allocate(F%mol(3 + 3 * max_n1, tot, n_replicas), F%energy(5, n_replicas))
+        call alloc_mirror(3 + 3 * max_n1, tot, int(n_replicas))
+        allocate(F%energy(5, n_replicas))
         F%n_threads = max(1, int(n_threads))
         ! n_lanes groups of replicas, one per engine lane (<= 0: the default of two)
         F%n_lanes = n_lanes
@@ -307,7 +333,12 @@ contains
     subroutine mfarm_destroy() bind(C, name="mfarm_destroy")
         integer :: g
         if (allocated(F%res_type)) deallocate(F%res_type, F%n1, F%cap, F%first, F%cnt, F%fugacity)
-        if (allocated(F%mol)) deallocate(F%mol, F%energy)
+        if (c_associated(F%mol_raw)) then
+            call c_free(F%mol_raw)
+            F%mol_raw = c_null_ptr
+            nullify(F%mol)
+        end if
+        if (allocated(F%energy)) deallocate(F%energy)
         if (allocated(F%cxs)) deallocate(F%cxs)
         do g = 0, MGPU_LANES - 1
             if (allocated(F%lane(g)%rep)) then
@@ -319,6 +350,22 @@ contains
         end do
         F%ready = .false.
     end subroutine mfarm_destroy
+
+    ! mirror record <- (com, offsets): explicit element copies, no array temporaries
+    pure subroutine store_molecule(rec, com, off, n1)
+        real(real64), intent(inout) :: rec(:)
+        real(real64), intent(in) :: com(3), off(:, :)
+        integer, intent(in) :: n1
+        integer :: a, d
+        do d = 1, 3
+            rec(d) = com(d)
+        end do
+        do a = 1, n1
+            do d = 1, 3
+                rec(3 * a + d) = off(d, a)
+            end do
+        end do
+    end subroutine store_molecule
 
     ! rotation by theta about Cartesian axis `axis`: RotationMatrix (src/helper_utils.f90:39-77)
     ! written out -- it mixes the two other components: X -> (Y, Z), Y -> (Z, X), Z -> (X, Y)
@@ -346,14 +393,15 @@ contains
     function generate_and_submit(g) result(rc)
         integer, intent(in) :: g
         integer(c_int) :: rc
-        integer :: i, j, r, ia, slot, n1, axis, d, a, mv, n
-        integer(int64) :: c0, c1, c2, c3
+        integer :: i, j, k, r, ia, slot, n1, axis, d, a, mv, n
+        integer(int64) :: c0, c1, c2, c3, cp1, cp2
         real(real64) :: x, draw, v(3), frac(3)
         type(lane_buffers), pointer :: L
         L => F%lane(g)
         rc = MGPU_OK
         L%nc = 0
         if (L%n == 0) return
+        cp1 = 0; cp2 = 0
         call system_clock(c0)
         ! rng_kind 0: one serial draw from the intrinsic generator, the reference's stream
         if (F%rng_kind == 0) call random_number(L%u(:, 1:L%n))
@@ -366,7 +414,7 @@ contains
         !   phase 3  per candidate: gather com / offsets from the host mirror -- one contiguous record, the
         !            random access is DRAM / TLB-latency bound and the threads overlap the misses -- and
         !            build the move.
-        !$omp parallel num_threads(F%n_threads) private(i, j, n1, d, x, axis, a, r, ia, slot, v, frac, n, mv, draw)
+        !$omp parallel num_threads(F%n_threads) private(i, j, k, n1, d, x, axis, a, r, ia, slot, v, frac, n, mv, draw)
         !$omp do schedule(static)
         do i = 1, L%n
             r = L%first + i
@@ -400,6 +448,9 @@ contains
             L%sel_slot(i) = slot
         end do
         !$omp end do
+        !$omp master
+        call system_clock(cp1)
+        !$omp end master
         !$omp single
         j = 0
         do i = 1, L%n
@@ -423,6 +474,9 @@ contains
         L%nc = j
         F%skipped = F%skipped + (L%n - j)
         !$omp end single
+        !$omp master
+        call system_clock(cp2)
+        !$omp end master
         !$omp do schedule(static)
         do j = 1, L%nc
             i = L%cidx(j)
@@ -430,9 +484,17 @@ contains
             ia = L%ia(j)
             slot = L%m(j) + 1
             if (L%move(j) == MV_CREATION) slot = 1          ! geometry of molecule 1, create_molecule.f90:197-199
-            L%new_com(:, j) = F%mol(1:3, F%first(ia) + slot, r)
-            L%new_off(:, :, j) = reshape(F%mol(4:, F%first(ia) + slot, r), [3, F%max_n1])
             n1 = F%n1(ia)
+            ! explicit copies (an array-valued reshape costs a heap temporary per chain)
+            k = F%first(ia) + slot
+            do d = 1, 3
+                L%new_com(d, j) = F%mol(d, k, r)
+            end do
+            do a = 1, n1
+                do d = 1, 3
+                    L%new_off(d, a, j) = F%mol(3 * a + d, k, r)
+                end do
+            end do
             select case (L%move(j))
             case (MV_TRANSLATION)
                 ! translation.f90:104-110: rand_symmetric(3)*translation_step, then ApplyPBC
@@ -500,7 +562,8 @@ contains
         call system_clock(c2)
         F%ticks(1) = F%ticks(1) + (c1 - c0)
         F%ticks(2) = F%ticks(2) + (c2 - c1)
-        F%ticks(6) = F%ticks(6) + (c3 - c0)                 ! serial draw of the intrinsic generator (rng_kind 0)
+        F%ticks(6) = F%ticks(6) + (cp1 - c0)                ! draw + move selection (phase 1, incl. the region's fork)
+        F%ticks(7) = F%ticks(7) + (c1 - cp2)                ! mirror gather + move construction (phase 3, incl. the join)
     end function generate_and_submit
 
     !---------------------------------------------------------------------------
@@ -570,18 +633,18 @@ contains
                 slot = L%m(j) + 1
                 select case (L%move(j))
                 case (MV_CREATION)
-                    F%mol(1:3, base + slot, r) = L%new_com(:, j)
-                    F%mol(4:, base + slot, r) = reshape(L%new_off(:, :, j), [3 * F%max_n1])
+                    call store_molecule(F%mol(:, base + slot, r), L%new_com(:, j), L%new_off(:, :, j), n1)
                     F%cnt(ia, r) = F%cnt(ia, r) + 1
                     k_c = k_c + 1
                 case (MV_DELETION)
                     last = F%cnt(ia, r)                                    ! RemoveMolecule, delete_molecule.f90:107-114
-                    F%mol(:, base + slot, r) = F%mol(:, base + last, r)
+                    do k = 1, 3 + 3 * n1
+                        F%mol(k, base + slot, r) = F%mol(k, base + last, r)
+                    end do
                     F%cnt(ia, r) = last - 1
                     k_d = k_d + 1
                 case default
-                    F%mol(1:3, base + slot, r) = L%new_com(:, j)
-                    F%mol(4:, base + slot, r) = reshape(L%new_off(:, :, j), [3 * F%max_n1])
+                    call store_molecule(F%mol(:, base + slot, r), L%new_com(:, j), L%new_off(:, :, j), n1)
                     if (L%move(j) == MV_TRANSLATION) then
                         k_t = k_t + 1
                     else
@@ -696,6 +759,29 @@ contains
         steps(1) = F%translation_step
         steps(2) = F%rotation_step
     end subroutine mfarm_recalibrate
+
+    ! Test hook: seed n_chains generators as mfarm_create would and return the first n_per numbers of each stream,
+    ! u(n_per, n_chains) (does not touch a live farm's generators).
+    subroutine mfarm_rng_sample(seed, n_chains, n_per, u) bind(C, name="mfarm_rng_sample")
+        integer(c_int), value :: seed, n_chains, n_per
+        real(c_double), intent(out) :: u(n_per, n_chains)
+        integer(int64), allocatable :: keep(:, :)
+        real(real64) :: v(NRAND)
+        integer :: r, k, got
+        if (allocated(F%cxs)) call move_alloc(F%cxs, keep)
+        call seed_farm_rng(int(seed), int(n_chains))
+        do r = 1, n_chains
+            got = 0
+            do while (got < n_per)
+                call chain_random(r, v)
+                k = min(NRAND, n_per - got)
+                u(got + 1:got + k, r) = v(1:k)
+                got = got + k
+            end do
+        end do
+        deallocate(F%cxs)
+        if (allocated(keep)) call move_alloc(keep, F%cxs)
+    end subroutine mfarm_rng_sample
 
     ! host wall time spent in: trial generation, trial submit, waiting for the GPU, Metropolis
     ! resolution, commit submit, and inside generation: random numbers, mirror gathers (seconds)

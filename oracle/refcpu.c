@@ -677,3 +677,77 @@ double refcpu_convert_fugacity(double f_atm, double temp_K)
     double thermal_energy = KB_JK * temp_K;
     return f_atm * ATM_TO_PA * A3_TO_M3 / thermal_energy;
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * CPU baseline helper (bench.py cpu_baseline, "all cores" leg): n_chains independent copies of the SAME
+ * sequential Metropolis trial the reference runs (Translation / Rotation, translation.f90:36-112,
+ * rotation.f90:34-75: save, old energy, move, new energy, accept or restore), one chain per OpenMP thread
+ * at a time -- the replica-level parallelism the GPU farm uses, on the host's cores.  Runs until
+ * `budget_s` seconds have passed (checked after every trial); counts[2 * c] = trials, counts[2 * c + 1] =
+ * accepted moves of chain c.  Returns the elapsed wall time.  TEST INFRASTRUCTURE, like the rest of this file.
+ * ---------------------------------------------------------------------------------------------- */
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static inline unsigned long long splitmix64(unsigned long long *x)
+{
+    unsigned long long z = (*x += 0x9e3779b97f4a7c15ULL);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+static inline double u01(unsigned long long *x) { return (double)(splitmix64(x) >> 11) * (1.0 / 9007199254740992.0); }
+
+static double wall_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+double refcpu_trial_farm(refcpu **chains, int n_chains, int n_threads, double budget_s, unsigned long long seed,
+                         double translation_step, double rotation_step, double temperature, long long *counts)
+{
+    const double t0 = wall_now();
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads) schedule(static, 1)
+#endif
+    for (int c = 0; c < n_chains; ++c) {
+        refcpu *s = chains[c];
+        unsigned long long rng = seed + 0x1234567ULL * (unsigned long long)(c + 1);
+        const int t = 0, n = s->n_mol[0], n1 = s->atoms_in_res[0];
+        double com[3], off[3 * 64], ncom[3], noff[3 * 64], rot[9], eo[6], en[6];
+        long long trials = 0, accepted = 0;
+        while (wall_now() - t0 < budget_s) {
+            const int m = (int)(u01(&rng) * n) % n;
+            refcpu_get_molecule(s, t, m, com, off);
+            refcpu_save_fourier(s, t, m);
+            refcpu_old_energy(s, t, m, 0, eo);
+            if (u01(&rng) <= 0.5 || n1 == 1) {
+                for (int d = 0; d < 3; ++d) ncom[d] = com[d] + (u01(&rng) - 0.5) * translation_step;
+                refcpu_apply_pbc(s, ncom);
+                refcpu_set_molecule(s, t, m, ncom, off);
+            } else {
+                refcpu_rotation_matrix(1 + (int)(u01(&rng) * 3.0) % 3, (u01(&rng) - 0.5) * rotation_step, rot);
+                for (int a = 0; a < n1; ++a)
+                    for (int i = 0; i < 3; ++i)
+                        noff[3 * a + i] = rot[3 * i] * off[3 * a] + rot[3 * i + 1] * off[3 * a + 1] + rot[3 * i + 2] * off[3 * a + 2];
+                refcpu_set_molecule(s, t, m, com, noff);
+            }
+            refcpu_new_energy(s, t, m, 0, en);
+            ++trials;
+            if (u01(&rng) <= fmin(1.0, exp(-(en[5] - eo[5]) / temperature))) {
+                ++accepted;
+            } else {
+                refcpu_set_molecule(s, t, m, com, off);
+                refcpu_restore_fourier(s, t, m);
+            }
+        }
+        counts[2 * c] = trials;
+        counts[2 * c + 1] = accepted;
+    }
+    return wall_now() - t0;
+}

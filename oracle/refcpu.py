@@ -225,3 +225,25 @@ class RefCPU:
 
     def convert_fugacity(self, f_atm, temp_K):
         return self.L.refcpu_convert_fugacity(C.c_double(f_atm), C.c_double(temp_K))
+
+
+def trial_farm(system, n_chains, n_threads, budget_s, translation_step, rotation_step, seed=11):
+    """All-core CPU baseline: n_chains independent copies of the sequential translation / rotation trial (the
+    reference's loop, restated), spread over n_threads OpenMP threads for budget_s seconds.
+    Returns (elapsed_s, trials_per_chain, accepted_per_chain)."""
+    L = lib()
+    L.refcpu_trial_farm.restype = C.c_double
+    chains = []
+    for _ in range(n_chains):
+        P = RefCPU(system)
+        P.all_fourier_terms()
+        P.init_amplitude(True)
+        chains.append(P)
+    handles = (C.c_void_p * n_chains)(*[p.h for p in chains])
+    counts = np.zeros(2 * n_chains, dtype=np.int64)
+    el = L.refcpu_trial_farm(handles, C.c_int(n_chains), C.c_int(n_threads), C.c_double(budget_s),
+                             C.c_ulonglong(seed), C.c_double(translation_step), C.c_double(rotation_step),
+                             C.c_double(system.temperature), counts.ctypes.data_as(C.POINTER(C.c_longlong)))
+    for p in chains:
+        p.close()
+    return float(el), counts[0::2].copy(), counts[1::2].copy()
