@@ -44,6 +44,9 @@ extern "C" {
  *   MGPU_PAIR_BLOCKS_PER_CU=<n> resident pair-sweep workgroups per CU (default 2)
  *   MGPU_PAIR_NO_FUSE=1         trial moves as two single-state sweeps instead of one fused old + new sweep
  *   MGPU_RECIP_PER_K=1          per-k reciprocal kernel even where the row form's LDS tables fit
+ *   MGPU_DEFER_COMMIT=1         a commit from a lane's resident rows is not launched but folded into the lane's
+ *                               next trial (one kernel applies it and sweeps k for the new candidates); bitwise the
+ *                               same results, measured no faster than the two launches
  * Threading rule: one host thread drives an engine at a time; lanes must hold disjoint replicas while their
  * trials / commits are in flight; every synchronous entry point that reads or rewrites replica state drains all
  * lanes first. */

@@ -76,6 +76,9 @@ struct Lane {
     HostBuf h_in, h_commit, h_out;   // pinned staging: trial inputs, commit inputs, results
     struct Pending { int kernel; hipEvent_t a, b; };
     std::vector<Pending> pending;
+    // profiling state is per lane: lanes may be driven by different host threads (one thread per lane at a time)
+    std::vector<hipEvent_t> ev_pool;
+    ProfileSlot prof[MGPU_KERNEL_COUNT];
     int n_submitted = 0;          // candidates of the trial in flight (0 = none)
     int last_trial_n = 0, last_trial_stride = 0;   // shape of the site rows still resident in d_sites
     int n_pair_items = 0, n_split = 1;   // reduced pair-energy entries of the trial in flight (2 per fused item + 1 per single)
@@ -86,11 +89,24 @@ struct Lane {
     std::vector<int> pair_old, pair_new, intra_idx, kinds;   // per-candidate rows of the trial in flight
     std::vector<double> self_of;                              // per-candidate Ewald self term (host constant)
     std::vector<double> h_lj, h_cc;                           // pair energies of the trial being collected
+    // A commit of the lane's last trial that has been accepted by the host but not launched: the lane's next
+    // trial_submit folds it into its k sweep (trial_k_kernel); anything else that needs the engine's state flushes it
+    // with the stand-alone commit kernel first.  The previous trial's staging block lives on in d_prev meanwhile.
+    struct Deferred {
+        bool active = false;
+        int n = 0, stride = 0, n1_max = 1;
+        AcceptBits bits{};
+        const RecipItem *d_items = nullptr;
+        const double *d_sites = nullptr;
+        std::vector<int> replica;             // replica of every candidate of that trial
+    } deferred;
+    DevBuf d_prev;                            // the staging block the deferred commit still reads
+    std::vector<int> mark;                    // [n_replicas] scratch: replica -> deferred candidate index
     hipEvent_t commit_staged_ev = nullptr;                    // recorded behind the H2D copies that read h_commit
     bool commit_staged = false;
     void release() {
         if (commit_staged_ev) { (void)hipEventDestroy(commit_staged_ev); commit_staged_ev = nullptr; }
-        d_items.release(); d_items2.release(); d_sites.release(); d_partials.release(); d_out.release();
+        d_items.release(); d_items2.release(); d_sites.release(); d_partials.release(); d_out.release(); d_prev.release();
         h_in.release(); h_commit.release(); h_out.release();
     }
 };
@@ -136,6 +152,7 @@ struct mgpu_engine {
     int pair_nsplit = 1;             // waves per pair-sweep item: an engine constant (see engine_nsplit)
     bool pair_fuse = true;           // trial moves sweep old + new together (MGPU_PAIR_NO_FUSE=1: tuning / A-B only)
     bool recip_force_per_k = false;  // MGPU_RECIP_PER_K=1: per-k reciprocal kernel even where the row form fits (tests)
+    bool defer_commits = false;      // MGPU_DEFER_COMMIT=1: resident-row commits ride in the lane's next k sweep (trial_k_kernel)
     double *d_res_q = nullptr;
     int *d_res_atype = nullptr;
     int *d_atom_res = nullptr, *d_atom_mol = nullptr;
@@ -150,8 +167,6 @@ struct mgpu_engine {
     HostBuf h_stage;
     // profiling
     bool profiling = false;
-    ProfileSlot prof[MGPU_KERNEL_COUNT];
-    std::vector<hipEvent_t> ev_pool;
 };
 
 namespace {
@@ -164,11 +179,10 @@ int use_device(const mgpu_engine *e) {
 int prof_begin(mgpu_engine *e, Lane &ln, int kernel, hipEvent_t *a, hipEvent_t *b) {
     if (!e->profiling) return MGPU_OK;
     for (hipEvent_t *ev : {a, b}) {
-        if (!e->ev_pool.empty()) { *ev = e->ev_pool.back(); e->ev_pool.pop_back(); }
+        if (!ln.ev_pool.empty()) { *ev = ln.ev_pool.back(); ln.ev_pool.pop_back(); }
         else HIP_TRY(hipEventCreate(ev));
     }
     (void)kernel;
-    (void)ln;
     return MGPU_OK;
 }
 // The events are attached to the dispatch itself (hipExtLaunchKernelGGL start / stop events): they carry
@@ -184,10 +198,10 @@ int prof_collect(mgpu_engine *e, Lane &ln) {
     for (auto &p : ln.pending) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
-        e->prof[p.kernel].launches += 1;
-        e->prof[p.kernel].total_ms += ms;
-        e->ev_pool.push_back(p.a);
-        e->ev_pool.push_back(p.b);
+        ln.prof[p.kernel].launches += 1;
+        ln.prof[p.kernel].total_ms += ms;
+        ln.ev_pool.push_back(p.a);
+        ln.ev_pool.push_back(p.b);
     }
     ln.pending.clear();
     return MGPU_OK;
@@ -201,7 +215,9 @@ int sync_stream(mgpu_engine *e) { return sync_lane(e, e->lanes[0]); }
 // The synchronous entry points that read or rewrite replica state (coordinates, counts, A(k)) on lane 0's stream or
 // the null stream first drain EVERY lane: the lanes' streams are non-blocking, so work still queued on lanes 1-3
 // would otherwise race with them.
+int flush_all_deferred(mgpu_engine *e);
 int sync_all_lanes(mgpu_engine *e) {
+    if (int rc = flush_all_deferred(e)) return rc;
     for (auto &ln : e->lanes)
         if (int rc = sync_lane(e, ln)) return rc;
     return MGPU_OK;
@@ -226,10 +242,12 @@ int check_candidate(const mgpu_engine *e, int c, int replica, int t, int m, bool
 // ENGINE CONSTANT (a function of the topology's capacity only) -- never of how many candidates share a launch
 // or of another replica's state -- and a chain's trajectory does not depend on what runs beside it.  Waves are
 // persistent and stride over the n_items * nsplit work units, so a constant costs nothing when a launch has
-// more work units than resident waves.  Policy: never fewer than ~8 sweep units per wave; at most 4 splits for a
-// farm engine (>= 256 replicas: launches carry hundreds of items, and 4 splits x 1024 fused items = one work unit
-// per resident wave; measured at the 10 125-atom box: 4 -> 98.9 us, 8 -> 104.6 us, 16 -> 116 us per launch), at
-// most 16 for a small engine (single chains are latency-bound: a trial is swept by up to 16 waves).
+// more work units than resident waves.  Policy: never fewer than ~8 sweep units per wave.  A farm engine (>= 256
+// replicas) aims at one or two work units per resident wave for the launches a farm makes (a quarter to a half of
+// the replicas per launch): n_cu * 64 / n_replicas rounded down to a power of two, between 1 and 4 -- 4 at 2048
+// replicas, 2 at 8192 (measured at the 10 125-atom box, 1024 fused items per launch: 4 -> 98.9 us, 8 -> 104.6 us,
+// 16 -> 116 us; 2048 items per launch on four lanes: 2 -> 6.94 M, 4 -> 6.79 M, 8 -> 6.52 M accepted moves/s).
+// A small engine may use up to 16 (single chains are latency-bound: a trial is swept by up to 16 waves).
 // MGPU_PAIR_NSPLIT overrides it (tuning only; read once at engine creation).
 int engine_nsplit(const mgpu_engine *e) {
     int units = 0;
@@ -237,7 +255,13 @@ int engine_nsplit(const mgpu_engine *e) {
         const int cap = e->tp.cap[t], n1 = e->tp.n1[t];
         units += e->tp.site_major[t] ? cap * ((n1 + 63) / 64) : n1 * ((cap + 63) / 64);
     }
-    int ns = std::max(1, std::min(units / 8, e->n_replicas >= 256 ? 4 : 16));
+    int cap_split = 16;
+    if (e->n_replicas >= 256) {
+        const int want = std::max(1, e->n_cu * 64 / e->n_replicas);
+        cap_split = 1;
+        while (cap_split * 2 <= std::min(want, 4)) cap_split *= 2;
+    }
+    int ns = std::max(1, std::min(units / 8, cap_split));
     if (const char *ov = std::getenv("MGPU_PAIR_NSPLIT")) ns = std::max(1, std::min(std::atoi(ov), std::max(1, units)));
     return ns;
 }
@@ -344,8 +368,10 @@ bool recip_by_rows(const mgpu_engine *e, int n1_max) {
 // accept != nullptr (commit, row form only): d_items are the candidates of the lane's last trial and only
 // those whose bit is set are applied
 int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items, int n1_max, int site_stride,
-                 bool commit, double2 *A_base, double *d_u, double *d_u_old = nullptr, const AcceptBits *accept = nullptr) {
+                 bool commit, double2 *A_base, double *d_u, double *d_u_old = nullptr, const AcceptBits *accept = nullptr,
+                 const double *sites_override = nullptr) {
     const bool by_rows = recip_by_rows(e, n1_max);
+    const double *d_cand = sites_override ? sites_override : (const double *)ln.d_sites.p;
     static const AcceptBits no_bits{};
     const AcceptBits &bits = accept ? *accept : no_bits;
     const int use_accept = accept ? 1 : 0;
@@ -363,18 +389,52 @@ int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items
         if (by_rows)                                                                                                 \
             hipExtLaunchKernelGGL((recip_rows_kernel<COMMIT, BOTH>), dim3(n_items), dim3(kBlock), lds, ln.stream, a, b, \
                                   0, e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_trj, e->d_tw, e->n_rtasks, e->d_rrows, e->n_rrows, \
-                               A_base, d_items, (const double *)ln.d_sites.p, site_stride, d_u, d_u_old,      \
+                               A_base, d_items, d_cand, site_stride, d_u, d_u_old,      \
                                   bits, use_accept);                                                                \
         else                                                                                                         \
             hipExtLaunchKernelGGL((recip_kernel<COMMIT, BOTH>), dim3(n_items), dim3(kBlock), lds, ln.stream, a, b, 0,   \
                                   e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_kpack, e->d_kslot, e->d_kw, A_base, d_items,  \
-                               (const double *)ln.d_sites.p, site_stride, d_u, d_u_old);                               \
+                               d_cand, site_stride, d_u, d_u_old);                               \
     } while (0)
     if (commit) MGPU_LAUNCH_RECIP(true, false);
     else if (d_u_old) MGPU_LAUNCH_RECIP(false, true);
     else MGPU_LAUNCH_RECIP(false, false);
 #undef MGPU_LAUNCH_RECIP
     rc = prof_end(e, ln, slot, a, b);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return MGPU_OK;
+}
+
+// Launch a lane's deferred commit with the stand-alone kernel (only the candidates whose bit is set in `bits`).
+int launch_deferred(mgpu_engine *e, Lane &ln, const AcceptBits &bits) {
+    const Lane::Deferred &d = ln.deferred;
+    return launch_recip(e, ln, d.d_items, d.n, d.n1_max, d.stride, true, e->d_A, nullptr, nullptr, &bits, d.d_sites);
+}
+int flush_deferred(mgpu_engine *e, Lane &ln) {
+    if (!ln.deferred.active) return MGPU_OK;
+    ln.deferred.active = false;
+    return launch_deferred(e, ln, ln.deferred.bits);
+}
+int flush_all_deferred(mgpu_engine *e) {
+    for (auto &ln : e->lanes)
+        if (int rc = flush_deferred(e, ln)) return rc;
+    return MGPU_OK;
+}
+
+// Deferred commit + k sweep of the lane's new trial in one launch (trial_k_kernel)
+int launch_trial_k(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items, int n1_max, int site_stride,
+                   const int *d_pend_idx, double *d_u_new, double *d_u_old) {
+    const Lane::Deferred &d = ln.deferred;
+    const size_t lds = recip_rows_lds_bytes(e, n1_max) + (size_t)12 * n1_max * sizeof(double);
+    hipEvent_t a = nullptr, b = nullptr;
+    int rc = prof_begin(e, ln, MGPU_KERNEL_RECIP, &a, &b);
+    if (rc) return rc;
+    hipExtLaunchKernelGGL((trial_k_kernel<0>), dim3(n_items), dim3(kBlock), lds, ln.stream, a, b, 0, e->tp, e->bx, e->d_pos,
+                          e->d_nmol, e->d_res_q, e->d_trj, e->d_tw, e->n_rtasks, e->d_rrows, e->n_rrows, e->d_A, d_items,
+                          (const double *)ln.d_sites.p, site_stride, d.d_items, d.d_sites, d.stride, d_pend_idx, n1_max,
+                          d_u_new, d_u_old);
+    rc = prof_end(e, ln, MGPU_KERNEL_RECIP, a, b);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return MGPU_OK;
@@ -498,9 +558,9 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
         off += atoms_in_res[t] * mol_capacity[t];
     }
     tp.n_cap_atoms = off;
-    e->pair_nsplit = engine_nsplit(e);
     e->pair_fuse = std::getenv("MGPU_PAIR_NO_FUSE") == nullptr;
     e->recip_force_per_k = std::getenv("MGPU_RECIP_PER_K") != nullptr;
+    e->defer_commits = std::getenv("MGPU_DEFER_COMMIT") != nullptr;
 
     BoxDev &bx = e->bx;
     for (int d = 0; d < 3; ++d) { bx.L[d] = box_matrix[d * 3 + d]; bx.invL[d] = 1.0 / bx.L[d]; bx.kmax[d] = e->kmax[d]; }
@@ -617,6 +677,7 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
         HIP_TRY_E(hipGetDeviceProperties(&prop, device));
         e->n_cu = std::max(1, prop.multiProcessorCount);
         if (const char *ov = std::getenv("MGPU_PAIR_BLOCKS_PER_CU")) e->pair_blocks_per_cu = std::max(1, std::atoi(ov));   // tuning only
+        e->pair_nsplit = engine_nsplit(e);
     }
     HIP_TRY_E(hipMalloc(&e->d_res_q, e->charges.size() * sizeof(double)));
     HIP_TRY_E(hipMalloc(&e->d_res_atype, atype0.size() * sizeof(int)));
@@ -664,7 +725,8 @@ int mgpu_engine_destroy(mgpu_engine *e) {
         for (auto &p : ln.pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
     }
-    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    for (auto &ln : e->lanes)
+        for (auto ev : ln.ev_pool) (void)hipEventDestroy(ev);
     delete e;
     return MGPU_OK;
 }
@@ -880,6 +942,7 @@ int mgpu_pair_energy_candidates(mgpu_engine *e, int n, const int *replica, const
     if (n < 0 || !replica || !t || !m || !e_nc || !e_c) return set_error(MGPU_ERR_INVALID_ARG, "pair_energy_candidates: bad argument");
     int rc = use_device(e);
     if (rc) return rc;
+    if ((rc = flush_all_deferred(e))) return rc;
     std::vector<PairItem> items(n);
     bool any_sites = false;
     for (int c = 0; c < n; ++c) {
@@ -914,6 +977,7 @@ int mgpu_recip_energy_candidates(mgpu_engine *e, int n, const int *replica, cons
     if (n < 0 || !replica || !t || !m || !kind || !u) return set_error(MGPU_ERR_INVALID_ARG, "recip_energy_candidates: bad argument");
     int rc = use_device(e);
     if (rc) return rc;
+    if ((rc = flush_all_deferred(e))) return rc;
     std::vector<RecipItem> items(n);
     bool any_sites = false;
     int n1_max = 1;
@@ -957,6 +1021,7 @@ int mgpu_intra_energy_candidates(mgpu_engine *e, int n, const int *replica, cons
     if (n < 0 || !replica || !t || !m || !u) return set_error(MGPU_ERR_INVALID_ARG, "intra_energy_candidates: bad argument");
     int rc = use_device(e);
     if (rc) return rc;
+    if ((rc = flush_all_deferred(e))) return rc;
     std::vector<PairItem> items(n);
     bool any_sites = false;
     for (int c = 0; c < n; ++c) {
@@ -1003,7 +1068,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     ln.h_trial_items = nullptr;
     const size_t site_bytes = (size_t)n * site_stride * 3 * sizeof(double);
     const size_t pit_cap = 2 * (size_t)n * sizeof(PairItem), rit_bytes = (size_t)n * sizeof(RecipItem);
-    const size_t iit_cap = (size_t)n * sizeof(PairItem);
+    const size_t iit_cap = (size_t)n * sizeof(PairItem) + (size_t)n * sizeof(int);       // intra items | pend_idx
     if ((rc = ln.h_in.reserve(site_bytes + pit_cap + rit_bytes + iit_cap))) return rc;
     double *h_sites = (double *)ln.h_in.p;
     PairItem *pit = (PairItem *)((char *)ln.h_in.p + site_bytes);
@@ -1057,8 +1122,47 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     // records, reduced on the host in trial_wait) | u_old | u_new | intra]
     const int nsplit = e->pair_nsplit;
     const size_t out_doubles = 2 * (size_t)n_pair * nsplit + 3 * (size_t)n;
-    // one staging block [sites | pair items (2n slots) | recip items | intra items] -> one H2D copy
-    const size_t in_bytes = site_bytes + pit_cap + rit_bytes + iit_bytes;
+    // A deferred commit of this lane rides in this trial's k sweep when every new candidate sits on its own replica
+    // and the row-form kernel applies; otherwise it is launched on its own first.
+    bool fused_k = false;
+    int *pend_idx = (int *)((char *)iit + iit_bytes);
+    const size_t pend_bytes = (size_t)n * sizeof(int);
+    if (ln.deferred.active) {
+        Lane::Deferred &d = ln.deferred;
+        const int n1_both = std::max(n1_max, d.n1_max);
+        bool ok = recip_by_rows(e, n1_both) &&
+                  recip_rows_lds_bytes(e, n1_both) + (size_t)12 * n1_both * sizeof(double) <= 64 * 1024;
+        if ((int)ln.mark.size() != e->n_replicas) ln.mark.assign(e->n_replicas, -1);
+        if (ok) {
+            for (int i = 0; i < d.n; ++i)
+                if ((d.bits.w[i >> 5] >> (i & 31)) & 1u) ln.mark[d.replica[i]] = i;
+            for (int c = 0; c < n && ok; ++c) {
+                const int mk = ln.mark[replica[c]];
+                if (mk == -2) ok = false;                  // second candidate on a replica
+                pend_idx[c] = mk >= 0 ? mk : -1;
+                ln.mark[replica[c]] = -2;
+            }
+            // accepted candidates without a successor on their replica: committed by the stand-alone kernel
+            AcceptBits orphans{};
+            bool any_orphan = false;
+            for (int i = 0; i < d.n; ++i)
+                if (((d.bits.w[i >> 5] >> (i & 31)) & 1u) && ln.mark[d.replica[i]] == i) {
+                    orphans.w[i >> 5] |= 1u << (i & 31);
+                    any_orphan = true;
+                }
+            for (int i = 0; i < d.n; ++i) ln.mark[d.replica[i]] = -1;
+            for (int c = 0; c < n; ++c) ln.mark[replica[c]] = -1;
+            if (ok) {
+                // the previous trial's staging block stays alive in d_prev while this trial fills d_sites
+                std::swap(ln.d_sites, ln.d_prev);
+                if (any_orphan && (rc = launch_deferred(e, ln, orphans))) return rc;
+                fused_k = true;
+            }
+        }
+        if (!ok && (rc = flush_deferred(e, ln))) return rc;
+    }
+    // one staging block [sites | pair items (2n slots) | recip items | intra items | pend_idx] -> one H2D copy
+    const size_t in_bytes = site_bytes + pit_cap + rit_bytes + iit_bytes + (fused_k ? pend_bytes : 0);
     if ((rc = ln.d_sites.reserve(site_bytes + pit_cap + rit_bytes + iit_cap))) return rc;
     if ((rc = ln.d_out.reserve(out_doubles * sizeof(double)))) return rc;
     if ((rc = ln.h_out.reserve(out_doubles * sizeof(double)))) return rc;
@@ -1066,12 +1170,17 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     const PairItem *d_pit = (const PairItem *)((char *)ln.d_sites.p + site_bytes);
     const RecipItem *d_rit = (const RecipItem *)((char *)ln.d_sites.p + site_bytes + pit_cap);
     const PairItem *d_iit = (const PairItem *)((char *)ln.d_sites.p + site_bytes + pit_cap + rit_bytes);
+    const int *d_pend_idx = (const int *)((const char *)d_iit + iit_bytes);
     double2 *d_part = (double2 *)ln.d_out.p;
     double *d_uo = (double *)ln.d_out.p + 2 * (size_t)n_pair * nsplit, *d_un = d_uo + n, *d_in = d_un + n;
-    // Pair sweep first, k sweep second.  The persistent pair sweep owns every CU (16 waves x 128 VGPRs), so
-    // the memory-bound kernels never run beside it; what does overlap is this lane's k sweep with the other
-    // lane's commit, in the window between two pair sweeps.  (k sweep first was measured: 5.6 -> 5.0 M moves/s,
-    // the commit then queues behind two kernels instead of sharing that window.)
+    // Kernel order.  With a deferred commit: [commit + k sweep] first (the pair sweep and the intra kernel must see
+    // the committed coordinates), then the pair sweep.  Without: pair sweep first, k sweep second (the order the
+    // stand-alone commit of the other lane overlaps best with; k sweep first was measured 10 % slower there).
+    if (fused_k) {
+        if ((rc = launch_trial_k(e, ln, d_rit, n, std::max(n1_max, ln.deferred.n1_max), site_stride, d_pend_idx, d_un, d_uo)))
+            return rc;
+        ln.deferred.active = false;
+    }
     if (n_fused) {
         if ((rc = launch_pair(e, ln, d_pit, n_fused, common, site_stride, nsplit, nullptr, nullptr, false, d_part, true)))
             return rc;
@@ -1081,7 +1190,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
                               d_part + 2 * (size_t)n_fused * nsplit)))
             return rc;
     }
-    if ((rc = launch_recip(e, ln, d_rit, n, n1_max, site_stride, false, e->d_A, d_un, d_uo)))
+    if (!fused_k && (rc = launch_recip(e, ln, d_rit, n, n1_max, site_stride, false, e->d_A, d_un, d_uo)))
         return rc;
     if (n_intra) {
         hipLaunchKernelGGL(intra_kernel, dim3((n_intra + 63) / 64), dim3(64), 0, ln.stream, e->tp, e->bx, e->d_pos, e->d_res_q,
@@ -1153,6 +1262,7 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
     int rc;
     const size_t site_bytes = sites ? (size_t)n * site_stride * 3 * sizeof(double) : 0;
     if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "commit_submit: wait for the lane's trial first");
+    if ((rc = flush_deferred(e, ln))) return rc;
     // the pinned staging block may still feed the H2D copy of the lane's previous commit
     if (ln.commit_staged) {
         HIP_TRY(hipEventSynchronize(ln.commit_staged_ev));
@@ -1207,8 +1317,18 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
             bits.w[c >> 5] |= 1u << (c & 31);
         }
         if (!same) return set_error(MGPU_ERR_INVALID_ARG, "commit_submit: candidates differ from the lane's last trial");
-        if ((rc = launch_recip(e, ln, ln.d_trial_items, n, ln.trial_n1_max, site_stride, true, e->d_A, nullptr, nullptr, &bits)))
+        if (e->defer_commits) {
+            // not launched: the lane's next trial_submit applies it inside its k sweep (any other call flushes it)
+            Lane::Deferred &d = ln.deferred;
+            d.active = true;
+            d.n = n; d.stride = site_stride; d.n1_max = ln.trial_n1_max;
+            d.bits = bits;
+            d.d_items = ln.d_trial_items;
+            d.d_sites = (const double *)ln.d_sites.p;
+            d.replica.assign(replica, replica + n);
+        } else if ((rc = launch_recip(e, ln, ln.d_trial_items, n, ln.trial_n1_max, site_stride, true, e->d_A, nullptr, nullptr, &bits))) {
             return rc;
+        }
         // applied once: a second commit_submit(sites = NULL) must not find these rows "resident" again
         ln.last_trial_n = 0;
         ln.d_trial_items = nullptr;
@@ -1292,6 +1412,7 @@ int mgpu_trial_energy_candidates(mgpu_engine *e, int n, const int *replica, cons
         return set_error(MGPU_ERR_INVALID_ARG, "trial_energy_candidates: bad argument");
     int rc = use_device(e);
     if (rc) return rc;
+    if ((rc = flush_all_deferred(e))) return rc;
     if ((rc = trial_submit_impl(e, e->lanes[0], n, replica, t, m, nullptr, sites, site_stride))) return rc;
     return trial_wait_impl(e, e->lanes[0], old_energy, new_energy, 3);
 }
@@ -1303,6 +1424,7 @@ int mgpu_commit_candidates(mgpu_engine *e, int n, const int *replica, const int 
     if (n < 0 || !replica || !t || !m || !kind || !accept) return set_error(MGPU_ERR_INVALID_ARG, "commit_candidates: bad argument");
     int rc = use_device(e);
     if (rc) return rc;
+    if ((rc = flush_all_deferred(e))) return rc;
     if ((rc = commit_submit_impl(e, e->lanes[0], n, replica, t, m, kind, sites, site_stride, accept))) return rc;
     return sync_stream(e);
 }
@@ -1373,9 +1495,7 @@ int mgpu_synchronize(mgpu_engine *e) {
     if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
     int rc = use_device(e);
     if (rc) return rc;
-    for (auto &ln : e->lanes)
-        if ((rc = sync_lane(e, ln))) return rc;
-    return MGPU_OK;
+    return sync_all_lanes(e);            // launches any deferred commit first
 }
 
 int mgpu_profile_enable(mgpu_engine *e, int on) {
@@ -1387,21 +1507,21 @@ int mgpu_profile_enable(mgpu_engine *e, int on) {
     // Pay the one-time costs here, not inside the caller's timed region: the first dispatch that carries
     // start / stop events switches the stream's queue into profiling mode (measured: ~7 ms on the first
     // such launch), and the event pool is filled for every launch the lanes can have in flight.
-    while (e->ev_pool.size() < (size_t)kLanes * 16) {
-        hipEvent_t ev;
-        HIP_TRY(hipEventCreate(&ev));
-        e->ev_pool.push_back(ev);
-    }
     for (auto &ln : e->lanes) {
-        hipEvent_t a = e->ev_pool.back(); e->ev_pool.pop_back();
-        hipEvent_t b = e->ev_pool.back(); e->ev_pool.pop_back();
+        while (ln.ev_pool.size() < 16) {
+            hipEvent_t ev;
+            HIP_TRY(hipEventCreate(&ev));
+            ln.ev_pool.push_back(ev);
+        }
+        hipEvent_t a = ln.ev_pool.back(); ln.ev_pool.pop_back();
+        hipEvent_t b = ln.ev_pool.back(); ln.ev_pool.pop_back();
         hipExtLaunchKernelGGL(prime_kernel, dim3(1), dim3(64), 0, ln.stream, a, b, 0, (const int *)e->d_nmol);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(ln.stream));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, a, b));
-        e->ev_pool.push_back(a);
-        e->ev_pool.push_back(b);
+        ln.ev_pool.push_back(a);
+        ln.ev_pool.push_back(b);
     }
     return MGPU_OK;
 }
@@ -1410,7 +1530,8 @@ int mgpu_profile_reset(mgpu_engine *e) {
     if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
     int rc = mgpu_synchronize(e);
     if (rc) return rc;
-    for (auto &p : e->prof) p = ProfileSlot{};
+    for (auto &ln : e->lanes)
+        for (auto &p : ln.prof) p = ProfileSlot{};
     return MGPU_OK;
 }
 
@@ -1418,8 +1539,11 @@ int mgpu_profile_get(mgpu_engine *e, int kernel, long long *launches, double *to
     if (!e || kernel < 0 || kernel >= MGPU_KERNEL_COUNT) return set_error(MGPU_ERR_INVALID_ARG, "profile_get: bad argument");
     int rc = mgpu_synchronize(e);
     if (rc) return rc;
-    if (launches) *launches = e->prof[kernel].launches;
-    if (total_ms) *total_ms = e->prof[kernel].total_ms;
+    long long n = 0;
+    double ms = 0.0;
+    for (auto &ln : e->lanes) { n += ln.prof[kernel].launches; ms += ln.prof[kernel].total_ms; }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
     return MGPU_OK;
 }
 

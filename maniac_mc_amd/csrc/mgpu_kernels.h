@@ -846,6 +846,215 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
 }
 
 // ------------------------------------------------------------------------------------------
+// Deferred commit + k sweep of a lane's NEXT trial in one launch (row form), one workgroup per candidate of the
+// new trial.  The host accepted some candidates of the lane's previous trial but did not launch their commit:
+// the workgroup of the new candidate on the same replica applies it first --
+//   stage A (only if pend_idx[c] >= 0):  A <- A + delta(previous accepted move), coordinates / count of the replica
+//                                        updated exactly as recip_rows_kernel<true, false> does;
+//   stage B:                             u_old = sum ff W |A|^2, u_new = sum ff W |A + delta(candidate)|^2 on the updated A
+// -- so A(k) is read from HBM once for both (stage B re-reads what the same threads have just written) and the
+// commit costs no launch of its own.  The previous trial's items and site rows are still resident in the lane's
+// other staging buffer.  Every candidate of the new trial must sit on a different replica (the host checks it);
+// accepted previous candidates whose replica has no new candidate are committed by the stand-alone kernel.
+// The "old" sites of the new candidate are read BEFORE the coordinate update and patched where the previous move
+// touched the same slot (it moved / created that molecule, or its swap-with-last filled that slot).
+// ------------------------------------------------------------------------------------------
+template <int DUMMY = 0>
+__global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void trial_k_kernel(
+    Topo tp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
+    const int *__restrict__ trj, const double2 *__restrict__ tw, int n_tasks, const RecipRow *__restrict__ rows, int n_rows,
+    double2 *__restrict__ A_base, const RecipItem *__restrict__ items, const double *__restrict__ cand_sites, int site_stride,
+    const RecipItem *__restrict__ pend_items, const double *__restrict__ pend_sites, int pend_stride,
+    const int *__restrict__ pend_idx, int n1_max, double *__restrict__ u_new, double *__restrict__ u_old) {
+    extern __shared__ double2 s_tab[];
+    __shared__ double s_red[2 * kWavesPerBlock];
+
+    const RecipItem it = items[blockIdx.x];
+    const int pi = pend_idx[blockIdx.x];
+    const bool has_pend = pi >= 0;
+    RecipItem pit = has_pend ? pend_items[pi] : RecipItem{it.replica, it.t, -1, 3 /*NONE*/, -1, 0};
+    int pend_last = -1;                                      // deletion: the slot that moves into pit.m
+    if (has_pend && pit.kind != 0) {
+        const int nm = nmol[pit.replica * tp.n_res + pit.t];  // live count BEFORE the previous move is applied
+        if (pit.kind == 1) { pit.m = nm; pit.aux = nm + 1; }  // appended (monte_carlo.f90:63, create_molecule.f90:64)
+        else { pit.aux = nm - 1; pend_last = nm - 1; }        // swap-with-last target
+    }
+    const int n1c = tp.n1[it.t], n1p = tp.n1[pit.t];
+    const int kofs[3] = {0, bx.kmax[0] + 1, bx.kmax[0] + bx.kmax[1] + 2};
+    const int ktot = bx.kmax[0] + bx.kmax[1] + bx.kmax[2] + 3;
+    double2 *s_xy = s_tab + 2 * n1_max * ktot;
+    double *s_q = reinterpret_cast<double *>(s_xy + n_rows * 2 * n1_max);
+    double *s_site = s_q + n1_max;                           // [4 sets][n1_max][3]: cur new, cur old, pend new, pend old
+    RecipRow *s_rows = reinterpret_cast<RecipRow *>(s_site + 12 * n1_max);
+    double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
+    double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
+    double2 *A = A_base + (size_t)it.replica * bx.n_slots;
+    const bool c_new = (it.kind == 0 || it.kind == 1), c_old = (it.kind == 0 || it.kind == 2);
+    const bool p_new = has_pend && (pit.kind == 0 || pit.kind == 1), p_old = has_pend && (pit.kind == 0 || pit.kind == 2);
+    // where the candidate's "old" sites come from once the previous move is applied
+    int old_src = 0, old_slot = it.m;                        // 0: resident slot old_slot, 1: the previous move's new sites
+    if (has_pend && c_old && pit.t == it.t && it.m == pit.m) {
+        if (pit.kind == 2) old_slot = pend_last; else old_src = 1;
+    }
+
+    for (int r = threadIdx.x; r < n_rows; r += kBlock) s_rows[r] = rows[r];
+    // ---- stage 0: every site coordinate this workgroup needs, read before anything is written
+    for (int e = threadIdx.x; e < 4 * n1_max; e += kBlock) {
+        const int set = e / n1_max, a = e - set * n1_max;
+        double x = 0.0, y = 0.0, z = 0.0;
+        if (set == 0 && c_new && a < n1c) {
+            const double *c = cand_sites + ((size_t)it.src * site_stride + a) * 3;
+            x = c[0]; y = c[1]; z = c[2];
+        } else if (set == 1 && c_old && a < n1c) {
+            if (old_src == 1) {
+                const double *c = pend_sites + ((size_t)pit.src * pend_stride + a) * 3;
+                x = c[0]; y = c[1]; z = c[2];
+            } else {
+                const int j = atom_slot(tp, it.t, old_slot, a);
+                x = px[j]; y = py[j]; z = pz[j];
+            }
+        } else if (set == 2 && p_new && a < n1p) {
+            const double *c = pend_sites + ((size_t)pit.src * pend_stride + a) * 3;
+            x = c[0]; y = c[1]; z = c[2];
+        } else if (set == 3 && p_old && a < n1p) {
+            const int j = atom_slot(tp, pit.t, pit.m, a);
+            x = px[j]; y = py[j]; z = pz[j];
+        }
+        s_site[e * 3 + 0] = x; s_site[e * 3 + 1] = y; s_site[e * 3 + 2] = z;
+    }
+    __syncthreads();
+
+    const double2 *zt = s_tab + kofs[2];
+    // phase 1 + 2 for one (new set, old set) pair of site sets of a molecule of type t with n1 sites
+    auto build_tables = [&](int t, int n1, int set_new, bool use_new, int set_old, bool use_old) {
+        const int nss = 2 * n1;
+        for (int e = threadIdx.x; e < nss * ktot; e += kBlock) {
+            const int s = e / ktot, kk = e - s * ktot;
+            const int which = s >= n1 ? 1 : 0, a = s - which * n1;
+            const int axis = (kk >= kofs[2]) ? 2 : (kk >= kofs[1] ? 1 : 0);
+            if (which == 0 ? !use_new : !use_old) { s_tab[e] = make_double2(0.0, 0.0); continue; }
+            const double *c = s_site + ((which == 0 ? set_new : set_old) * n1_max + a) * 3;
+            s_tab[e] = phase_entry(atom_phase(bx, axis, c[0], c[1], c[2]), kk - kofs[axis]);
+        }
+        for (int a = threadIdx.x; a < n1; a += kBlock) s_q[a] = res_q[t * tp.max_atom + a];
+        __syncthreads();
+        for (int e = threadIdx.x; e < n_rows * nss; e += kBlock) {
+            const int row = e / nss, s = e - row * nss;
+            const int which = s >= n1 ? 1 : 0, a = s - which * n1;
+            double2 v = make_double2(0.0, 0.0);
+            if (which == 0 ? use_new : use_old) {
+                const RecipRow r = s_rows[row];
+                const double2 *tb = s_tab + s * ktot;
+                const int aky = r.ky < 0 ? -r.ky : r.ky;
+                double2 Y = tb[kofs[1] + aky];
+                if (r.ky < 0) Y.y = -Y.y;
+                v = cmul(tb[r.kx], Y);
+                const double q = which == 0 ? s_q[a] : -s_q[a];
+                v.x *= q; v.y *= q;
+            }
+            s_xy[e] = v;
+        }
+        __syncthreads();
+    };
+    // delta of one task from the tables in LDS: returns (sac, sbd, sad, sbc)
+    auto task_sums = [&](int rj, int nss, double &sac, double &sbd, double &sad, double &sbc) {
+        const double2 *xy = s_xy + ((rj >> 8) & 0xfffff) * nss;
+        const double2 *z = zt + (rj & 0xff);
+        sac = 0.0; sbd = 0.0; sad = 0.0; sbc = 0.0;
+        for (int s = 0; s < nss; ++s) {
+            const double2 p = xy[s], q = z[s * ktot];
+            sac = fma(p.x, q.x, sac);
+            sbd = fma(p.y, q.y, sbd);
+            sad = fma(p.x, q.y, sad);
+            sbc = fma(p.y, q.x, sbc);
+        }
+    };
+
+    // ---- stage A: the previous accepted move of this replica
+    if (has_pend) {
+        // coordinates / count, exactly as the stand-alone commit (all reads of old coordinates are behind us)
+        if (pit.kind == 0 || pit.kind == 1) {
+            if (threadIdx.x < n1p) {
+                const double *c = s_site + (2 * n1_max + threadIdx.x) * 3;
+                const int j = atom_slot(tp, pit.t, pit.m, threadIdx.x);
+                px[j] = c[0]; py[j] = c[1]; pz[j] = c[2];
+            }
+        } else if (pit.kind == 2) {
+            if (threadIdx.x < n1p && pend_last != pit.m) {     // swap-with-last, delete_molecule.f90:107-114
+                const int j = atom_slot(tp, pit.t, pit.m, threadIdx.x), jl = atom_slot(tp, pit.t, pend_last, threadIdx.x);
+                px[j] = px[jl]; py[j] = py[jl]; pz[j] = pz[jl];
+            }
+        }
+        if (threadIdx.x == 0 && (pit.kind == 1 || pit.kind == 2)) nmol[pit.replica * tp.n_res + pit.t] = pit.aux;
+        build_tables(pit.t, n1p, 2, p_new, 3, p_old);
+        const int nss = 2 * n1p;
+        for (int t0 = threadIdx.x; t0 < n_tasks; t0 += kBlock * kRecipTaskChunk) {
+            int rj[kRecipTaskChunk];
+            double2 Ap[kRecipTaskChunk], Am[kRecipTaskChunk];
+#pragma unroll
+            for (int c = 0; c < kRecipTaskChunk; ++c) {
+                const int t = t0 + c * kBlock;
+                const bool in = t < n_tasks;
+                rj[c] = in ? trj[t] : 0;
+                Ap[c] = in ? A[2 * t] : make_double2(0.0, 0.0);
+                Am[c] = in ? A[2 * t + 1] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int c = 0; c < kRecipTaskChunk; ++c) {
+                double sac, sbd, sad, sbc;
+                task_sums(rj[c], nss, sac, sbd, sad, sbc);
+                const int t = t0 + c * kBlock;
+                if (t < n_tasks) {        // absent members stay zero
+                    A[2 * t] = (rj[c] & kTaskHasP) ? make_double2(Ap[c].x + (sac - sbd), Ap[c].y + (sad + sbc)) : make_double2(0.0, 0.0);
+                    A[2 * t + 1] = (rj[c] & kTaskHasM) ? make_double2(Am[c].x + (sac + sbd), Am[c].y + (sbc - sad)) : make_double2(0.0, 0.0);
+                }
+            }
+        }
+        __syncthreads();                  // the tables are rebuilt for the new candidate
+    }
+
+    // ---- stage B: the new candidate against the (updated) A(k); every thread re-reads only slots it wrote itself
+    build_tables(it.t, n1c, 0, c_new, 1, c_old);
+    double acc = 0.0, acc0 = 0.0;
+    {
+        const int nss = 2 * n1c;
+        for (int t0 = threadIdx.x; t0 < n_tasks; t0 += kBlock * kRecipTaskChunk) {
+            int rj[kRecipTaskChunk];
+            double2 Ap[kRecipTaskChunk], Am[kRecipTaskChunk], w[kRecipTaskChunk];
+#pragma unroll
+            for (int c = 0; c < kRecipTaskChunk; ++c) {
+                const int t = t0 + c * kBlock;
+                const bool in = t < n_tasks;
+                rj[c] = in ? trj[t] : 0;
+                Ap[c] = in ? A[2 * t] : make_double2(0.0, 0.0);
+                Am[c] = in ? A[2 * t + 1] : make_double2(0.0, 0.0);
+                w[c] = in ? tw[t] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int c = 0; c < kRecipTaskChunk; ++c) {
+                double sac, sbd, sad, sbc;
+                task_sums(rj[c], nss, sac, sbd, sad, sbc);
+                const double wp = w[c].x, wm = w[c].y;
+                acc0 += wp * fma(Ap[c].x, Ap[c].x, Ap[c].y * Ap[c].y) + wm * fma(Am[c].x, Am[c].x, Am[c].y * Am[c].y);
+                const double npx = Ap[c].x + (sac - sbd), npy = Ap[c].y + (sad + sbc);
+                const double nmx = Am[c].x + (sac + sbd), nmy = Am[c].y + (sbc - sad);
+                acc += wp * fma(npx, npx, npy * npy) + wm * fma(nmx, nmx, nmy * nmy);   // ewald_energy.f90:259-266
+            }
+        }
+    }
+    acc = wave_sum(acc);
+    acc0 = wave_sum(acc0);
+    if ((threadIdx.x & 63) == 0) { s_red[2 * (threadIdx.x >> 6)] = acc; s_red[2 * (threadIdx.x >> 6) + 1] = acc0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double u = 0.0, u0 = 0.0;
+        for (int wv = 0; wv < kWavesPerBlock; ++wv) { u += s_red[2 * wv]; u0 += s_red[2 * wv + 1]; }
+        u_new[blockIdx.x] = u * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;   // ewald_energy.f90:272
+        u_old[blockIdx.x] = u0 * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Full structure factor S(k) (ComputeAllFourierTerms + ComputeRecipAmplitude,
 // ewald_phase.f90:340-360, ewald_energy.f90:40-77).
 // Step 1: per-atom 1-D phase tables, tab[axis][k][slot]; dead slots are skipped.

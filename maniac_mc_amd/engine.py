@@ -255,15 +255,17 @@ class Engine:
         check(self.L.mgpu_gcmc_trial_wait(self.h, C.c_int(lane), _d(old), _d(new)))
         return old, new
 
-    def commit_lane(self, lane, replica, t, m, kind, accept, sites=None):
-        """mgpu_commit_submit + synchronize; sites=None reuses the rows of the lane's last trial."""
+    def commit_lane(self, lane, replica, t, m, kind, accept, sites=None, sync=True):
+        """mgpu_commit_submit (+ synchronize unless sync=False); sites=None reuses the rows of the lane's last trial
+        (such a commit is deferred into the lane's next trial_submit; synchronize launches it at once)."""
         n, replica, t, m, sites = self._cand(replica, t, m, sites)
         kind = _ints(kind, n)
         accept = _ints(accept, n)
         stride = self._last_stride if sites is None else sites.shape[1]
         check(self.L.mgpu_commit_submit(self.h, C.c_int(lane), C.c_int(n), _i(replica), _i(t), _i(m), _i(kind),
                                         _d(sites), C.c_int(stride), _i(accept)))
-        self.synchronize()
+        if sync:
+            self.synchronize()
 
     def commit_candidates(self, replica, t, m, kind, sites, accept):
         n, replica, t, m, sites = self._cand(replica, t, m, sites)

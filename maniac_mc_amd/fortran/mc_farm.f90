@@ -71,6 +71,8 @@ module mc_farm
         real(real64), allocatable :: new_com(:, :), new_off(:, :, :)
         real(real64), allocatable :: old_e(:), new_e(:)    ! (ne * nc) rows packed by the engine
         real(real64), allocatable :: u(:, :)
+        ! per-lane accumulators (lanes may run on different host threads), folded into the farm's totals by mfarm_run
+        integer(int64) :: trials = 0, accepted = 0, skipped = 0, counters(8) = 0, ticks(7) = 0
     end type lane_buffers
 
     type :: farm_state
@@ -96,6 +98,8 @@ module mc_farm
         logical :: ready = .false.
         integer(int64) :: ticks(7) = 0                     ! generate, submit, wait, resolve, commit, rng, gather
         integer :: rng_kind = 1, n_threads = 1, n_lanes = 2
+        integer :: team = 1                                ! OpenMP threads of one lane's loops
+        logical :: lane_threads = .false.                  ! one host thread (plus its team) per lane
         integer(int64), allocatable :: cxs(:, :)           ! (4, R) xoshiro256+ state of every chain
     end type farm_state
 
@@ -414,7 +418,7 @@ contains
         !   phase 3  per candidate: gather com / offsets from the host mirror -- one contiguous record, the
         !            random access is DRAM / TLB-latency bound and the threads overlap the misses -- and
         !            build the move.
-        !$omp parallel num_threads(F%n_threads) private(i, j, k, n1, d, x, axis, a, r, ia, slot, v, frac, n, mv, draw)
+        !$omp parallel num_threads(F%team) private(i, j, k, n1, d, x, axis, a, r, ia, slot, v, frac, n, mv, draw)
         !$omp do schedule(static)
         do i = 1, L%n
             r = L%first + i
@@ -472,7 +476,7 @@ contains
             end select
         end do
         L%nc = j
-        F%skipped = F%skipped + (L%n - j)
+        L%skipped = L%skipped + (L%n - j)
         !$omp end single
         !$omp master
         call system_clock(cp2)
@@ -560,10 +564,10 @@ contains
             end if
         end if
         call system_clock(c2)
-        F%ticks(1) = F%ticks(1) + (c1 - c0)
-        F%ticks(2) = F%ticks(2) + (c2 - c1)
-        F%ticks(6) = F%ticks(6) + (cp1 - c0)                ! draw + move selection (phase 1, incl. the region's fork)
-        F%ticks(7) = F%ticks(7) + (c1 - cp2)                ! mirror gather + move construction (phase 3, incl. the join)
+        L%ticks(1) = L%ticks(1) + (c1 - c0)
+        L%ticks(2) = L%ticks(2) + (c2 - c1)
+        L%ticks(6) = L%ticks(6) + (cp1 - c0)                ! draw + move selection (phase 1, incl. the region's fork)
+        L%ticks(7) = L%ticks(7) + (c1 - cp2)                ! mirror gather + move construction (phase 3, incl. the join)
     end function generate_and_submit
 
     !---------------------------------------------------------------------------
@@ -593,7 +597,7 @@ contains
         if (rc /= MGPU_OK) return
         call system_clock(c1)
         k_tt = 0; k_t = 0; k_rt = 0; k_r = 0; k_ct = 0; k_c = 0; k_dt = 0; k_d = 0
-        !$omp parallel do num_threads(F%n_threads) schedule(static) &
+        !$omp parallel do num_threads(F%team) schedule(static) &
         !$omp& private(i, k, r, ia, slot, n1, delta_e, probability, nn, phi, last, base, o, e_old, e_new) &
         !$omp& reduction(+:k_tt, k_t, k_rt, k_r, k_ct, k_c, k_dt, k_d)
         do j = 1, L%nc
@@ -660,17 +664,17 @@ contains
             end if
         end do
         !$omp end parallel do
-        F%counters = F%counters + [k_tt, k_t, k_rt, k_r, k_ct, k_c, k_dt, k_d]
-        F%accepted = F%accepted + k_t + k_r + k_c + k_d
-        F%trials = F%trials + L%nc
+        L%counters = L%counters + [k_tt, k_t, k_rt, k_r, k_ct, k_c, k_dt, k_d]
+        L%accepted = L%accepted + k_t + k_r + k_c + k_d
+        L%trials = L%trials + L%nc
         call system_clock(c2)
         rc = mgpu_commit_submit(F%engine, int(g, c_int), int(L%nc, c_int), L%rep, L%t, L%m, L%kind, &
                                 c_null_ptr, int(F%max_n1, c_int), L%accept)
         call system_clock(c3)
         L%nc = 0
-        F%ticks(3) = F%ticks(3) + (c1 - c0)
-        F%ticks(4) = F%ticks(4) + (c2 - c1)
-        F%ticks(5) = F%ticks(5) + (c3 - c2)
+        L%ticks(3) = L%ticks(3) + (c1 - c0)
+        L%ticks(4) = L%ticks(4) + (c2 - c1)
+        L%ticks(5) = L%ticks(5) + (c3 - c2)
     end function resolve_and_commit
 
     !---------------------------------------------------------------------------
@@ -681,6 +685,9 @@ contains
         real(c_double), intent(out) :: out(3)
         integer(c_int) :: rc
         integer :: step, g, lu, ios, nlen
+        integer(c_int) :: rc_lane(0:MGPU_LANES - 1)
+        integer :: elen, eios
+        character(len=16) :: envval
         integer(int64), allocatable :: slog(:, :)
         integer(int64) :: rate
         character(len=512) :: logpath
@@ -693,12 +700,43 @@ contains
         ! diagnostic: MFARM_STEPLOG=<file> appends the host timers (microseconds) after every step
         call get_environment_variable("MFARM_STEPLOG", logpath, nlen, ios)
         if (ios == 0 .and. nlen > 0 .and. n_steps > 0) allocate(slog(7, 0:n_steps))
-        if (n_steps > 0) then
+        ! Two ways to drive the lanes.  (a) lock step on the calling thread (default): the lanes take turns, which also
+        ! staggers their kernels on the device -- the persistent pair sweeps of two lanes then run one after the other.
+        ! (b) MFARM_LANE_THREADS=1: one host thread per lane, each with its own OpenMP team, runs its lane's resolve ->
+        ! commit -> generate -> submit loop on its own (the engine's lanes are independent: own stream, scratch, staging,
+        ! profiling slots).  Measured on MI355X at the default bench size: the host stops being the limit (it waits
+        ! 60 % of the time) but the free-running lanes' pair sweeps share the device and stretch (100 -> 104-112 us),
+        ! 5.3 M against 5.9 M accepted moves/s in lock step -- kept as an option for hosts too slow to keep up.
+        F%lane_threads = .false.
+        call get_environment_variable("MFARM_LANE_THREADS", envval, elen, eios)
+        if (eios == 0 .and. elen > 0) then
+            if (envval(1:1) == "1") F%lane_threads = F%n_lanes > 1 .and. F%rng_kind /= 0 .and. .not. allocated(slog) &
+                                                     .and. F%n_threads >= 2 * F%n_lanes
+        end if
+        if (n_steps > 0 .and. F%lane_threads) then
+            F%team = max(1, F%n_threads / F%n_lanes)
+            call omp_set_max_active_levels(2)
+            rc_lane = MGPU_OK
+            !$omp parallel num_threads(F%n_lanes) private(g, step) proc_bind(spread)
+            g = omp_get_thread_num()
+            rc_lane(g) = generate_and_submit(g)
+            do step = 1, n_steps
+                if (rc_lane(g) /= MGPU_OK) exit
+                rc_lane(g) = resolve_and_commit(g)
+                if (rc_lane(g) == MGPU_OK .and. step < n_steps) rc_lane(g) = generate_and_submit(g)
+            end do
+            !$omp end parallel
+            do g = 0, F%n_lanes - 1
+                if (rc_lane(g) /= MGPU_OK) rc = rc_lane(g)
+            end do
+            if (rc == MGPU_OK) rc = mgpu_synchronize(F%engine)
+        else if (n_steps > 0) then
+            F%team = F%n_threads
             do g = 0, F%n_lanes - 1
                 rc = generate_and_submit(g)
                 if (rc /= MGPU_OK) return
             end do
-            if (allocated(slog)) slog(:, 0) = F%ticks
+            if (allocated(slog)) call lane_ticks(slog(:, 0))
             do step = 1, n_steps
                 do g = 0, F%n_lanes - 1
                     rc = resolve_and_commit(g)
@@ -708,10 +746,20 @@ contains
                         if (rc /= MGPU_OK) return
                     end if
                 end do
-                if (allocated(slog)) slog(:, step) = F%ticks
+                if (allocated(slog)) call lane_ticks(slog(:, step))
             end do
             rc = mgpu_synchronize(F%engine)
         end if
+        ! fold the lanes' accumulators into the farm's totals
+        do g = 0, F%n_lanes - 1
+            F%trials = F%trials + F%lane(g)%trials
+            F%accepted = F%accepted + F%lane(g)%accepted
+            F%skipped = F%skipped + F%lane(g)%skipped
+            F%counters = F%counters + F%lane(g)%counters
+            F%ticks = F%ticks + F%lane(g)%ticks
+            F%lane(g)%trials = 0; F%lane(g)%accepted = 0; F%lane(g)%skipped = 0
+            F%lane(g)%counters = 0; F%lane(g)%ticks = 0
+        end do
         if (allocated(slog)) then
             call system_clock(count_rate=rate)
             open(newunit=lu, file=logpath(1:nlen), position="append", action="write", iostat=ios)
@@ -727,6 +775,16 @@ contains
         out(2) = real(F%accepted, real64)
         out(3) = real(F%skipped, real64)
     end function mfarm_run
+
+    ! host timers so far: the farm's totals plus what the lanes have accumulated since the last fold
+    subroutine lane_ticks(t)
+        integer(int64), intent(out) :: t(7)
+        integer :: g
+        t = F%ticks
+        do g = 0, F%n_lanes - 1
+            t = t + F%lane(g)%ticks
+        end do
+    end subroutine lane_ticks
 
     ! trial / accepted counts: translations, rotations, creations, deletions (counter_type,
     ! src/simulation_state.f90:19-31)

@@ -45,6 +45,11 @@ _host = None
 def lib():
     global _host
     if _host is None:
+        # the farm drives each lane from its own host thread with a nested OpenMP team: allow two active levels and
+        # keep the inner teams alive between regions (must be in the environment before the OpenMP runtime starts)
+        os.environ.setdefault("OMP_MAX_ACTIVE_LEVELS", "2")
+        os.environ.setdefault("KMP_HOT_TEAMS_MAX_LEVEL", "2")
+        os.environ.setdefault("KMP_HOT_TEAMS_MODE", "1")
         _lib.lib()       # libmaniac_hip.so first, so the dependency resolves in-tree
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (needs amdflang)")

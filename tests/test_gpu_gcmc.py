@@ -69,3 +69,97 @@ def test_mixed_gcmc_batch_matches_oracle(refcpu_mod):
         eng.init_structure_factor(r, True)
         amp_close(A, eng.structure_factor(r), f"replica {r} A after mixed commit")
     eng.close()
+
+
+def _random_lane_run(eng, s, rng_seed, steps, lane):
+    """A scripted grand-canonical lane run: every step one candidate per replica (moves, insertions, deletions --
+    deliberately hitting the same molecule twice in a row, the slot a deletion has just refilled and the molecule an
+    insertion has just created), random acceptance, commit from the lane's resident rows WITHOUT synchronising."""
+    rng = np.random.default_rng(rng_seed)
+    R = eng.n_replicas
+    n = np.full(R, int(s.n_mol[0]))
+    tmpl = s.offsets[0][0]
+    L = float(s.box_matrix[0, 0])
+    log = []
+    last = [None] * R                       # (kind, slot) of the last ACCEPTED move per replica
+    for step in range(steps):
+        reps = [r for r in range(R) if not (step % 7 == 3 and r == 1)]      # replica 1 sits out sometimes: orphaned commits
+        kinds, ms, sites = [], [], []
+        for r in reps:
+            u = rng.random()
+            k = MGPU_MOVE if (u < 0.4 or n[r] < 3) else (MGPU_CREATION if u < 0.7 else MGPU_DELETION)
+            if k == MGPU_CREATION and n[r] >= eng.mol_capacity[0] - 1:
+                k = MGPU_MOVE
+            m = int(rng.integers(0, n[r]))
+            if last[r] is not None and rng.random() < 0.5:
+                lk, lm = last[r]
+                if lk in (MGPU_MOVE, MGPU_DELETION) and lm < n[r]:
+                    m = lm                                  # the molecule just moved / the slot just refilled
+                elif lk == MGPU_CREATION:
+                    m = n[r] - 1                            # the molecule just created
+            if k == MGPU_CREATION:
+                m = -1
+            kinds.append(k); ms.append(m)
+            sites.append((s.bounds_lo + rng.random(3) * L)[None, :] + tmpl @ np.linalg.qr(rng.normal(size=(3, 3)))[0].T)
+        rep = np.array(reps, dtype=np.int32); kinds = np.array(kinds, dtype=np.int32); ms = np.array(ms, dtype=np.int32)
+        sites = np.array(sites)
+        # moves displace the resident molecule a little instead of teleporting it
+        for c, r in enumerate(reps):
+            if kinds[c] == MGPU_MOVE:
+                sites[c] = eng_sites_cache[id(eng)][r][ms[c]] + rng.uniform(-0.3, 0.3, 3)[None, :]
+        old, new = eng.gcmc_trial(rep, np.zeros(len(reps), np.int32), ms, kinds, sites, lane=lane)
+        acc = (rng.random(len(reps)) < 0.6).astype(np.int32)
+        eng.commit_lane(lane, rep, np.zeros(len(reps), np.int32), ms, kinds, acc, sync=False)
+        for c, r in enumerate(reps):
+            if not acc[c]:
+                continue
+            cache = eng_sites_cache[id(eng)][r]
+            if kinds[c] == MGPU_MOVE:
+                cache[ms[c]] = sites[c]; last[r] = (MGPU_MOVE, int(ms[c]))
+            elif kinds[c] == MGPU_CREATION:
+                cache.append(sites[c].copy()); n[r] += 1; last[r] = (MGPU_CREATION, n[r] - 1)
+            else:
+                cache[ms[c]] = cache[-1]; cache.pop(); n[r] -= 1; last[r] = (MGPU_DELETION, int(ms[c]))
+        log.append((old.copy(), new.copy()))
+    return log, n
+
+
+eng_sites_cache = {}
+
+
+def test_deferred_commit_is_bitwise_the_immediate_commit():
+    """With MGPU_DEFER_COMMIT=1 a resident-row commit is not launched: the lane's next trial applies it inside its k
+    sweep (trial_k_kernel).  The same scripted lane run on an engine that defers and on a default one (immediate
+    commit launches) must give bitwise equal energies at every step and bitwise equal A(k), coordinates and counts
+    at the end."""
+    import os
+    s = synth.co2_box(14, seed=31)
+    R = 5
+    out = []
+    for defer in (True, False):
+        if defer:
+            os.environ["MGPU_DEFER_COMMIT"] = "1"
+        try:
+            eng = Engine.from_system(s, n_replicas=R, mol_capacity=[40])
+        finally:
+            os.environ.pop("MGPU_DEFER_COMMIT", None)
+        for r in range(R):
+            eng.init_structure_factor(r, True)
+        eng_sites_cache[id(eng)] = [[x.copy() for x in s.all_sites(0)] for _ in range(R)]
+        log, n = _random_lane_run(eng, s, 123, 60, lane=2)
+        state = dict(n=n, A=[eng.structure_factor(r) for r in range(R)], pos=[eng.get_molecules(r, 0) for r in range(R)],
+                     cache=eng_sites_cache.pop(id(eng)))
+        for r in range(R):
+            assert eng.num_molecules(r, 0) == n[r]
+            assert np.array_equal(state["pos"][r], np.array(state["cache"][r]))      # device == the scripted bookkeeping
+            fresh = eng.structure_factor(r)
+            eng.init_structure_factor(r, True)
+            assert np.max(np.abs(fresh - eng.structure_factor(r))) < 1e-9            # A(k) == S(k) of the final state
+        out.append((log, state))
+        eng.close()
+    (log_a, st_a), (log_b, st_b) = out
+    assert np.array_equal(st_a["n"], st_b["n"])
+    for (oa, na), (ob, nb) in zip(log_a, log_b):
+        assert np.array_equal(oa, ob) and np.array_equal(na, nb)
+    for r in range(R):
+        assert np.array_equal(st_a["A"][r], st_b["A"][r]) and np.array_equal(st_a["pos"][r], st_b["pos"][r])

@@ -17,6 +17,7 @@ from collections import defaultdict
 
 def main():
     d, tag = sys.argv[1], sys.argv[2]
+    repl = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
     vals = defaultdict(lambda: defaultdict(list))
     dur = defaultdict(list)
     for path in glob.glob(os.path.join(d, "*", "**", "*counter_collection.csv"), recursive=True):
@@ -35,9 +36,9 @@ def main():
             k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").strip()
             dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
     keep = [k for k in vals if "mgpu::" in k and ("pair_sweep" in k or "recip" in k or "trial_k" in k)]
-    lines = [f"# rocprofv3 --pmc passes (separate runs, --kernel-trace only) of `python3 tools/bench_kernels.py --reps 3`, build {tag}",
+    lines = [f"# rocprofv3 --pmc passes (separate runs, --kernel-trace only) of `python3 tools/bench_kernels.py --reps 3 --replicas {repl}`, build {tag}",
              "# per-dispatch means over the dispatches after each kernel's first; whole GPU", ""]
-    out = {"build": tag, "source": "tools/pmc_passes.sh (rocprofv3 --pmc, separate passes; FETCH_SIZE doubled per the gfx950 calibration)",
+    out = {"build": tag, "candidates_per_launch": repl, "evaluations_per_pair_launch": 2 * repl, "source": "tools/pmc_passes.sh (rocprofv3 --pmc, separate passes; FETCH_SIZE doubled per the gfx950 calibration)",
            "kernels": {}}
     for k in sorted(keep):
         c = {n: sum(v) / len(v) for n, v in vals[k].items()}
