@@ -42,7 +42,7 @@ module mc_chain
     public :: mchain_reset, mchain_set_box, mchain_set_residue, mchain_set_bonded, mchain_set_tables, &
               mchain_set_moves, mchain_set_reservoir_box, mchain_set_reservoir_residue, mchain_run, &
               mchain_get_energy, mchain_get_counters, mchain_get_counts, mchain_get_molecule, mchain_get_steps, &
-              mchain_set_mode, mchain_set_as_written
+              mchain_set_mode, mchain_set_as_written, mchain_set_log_header, mchain_write_log_header
 
     real(real64), parameter :: PI = 3.14159265358979323846_real64, TWOPI = 2.0_real64 * PI
     real(real64), parameter :: zero = 0.0_real64, one = 1.0_real64, half = 0.5_real64, three = 3.0_real64
@@ -62,6 +62,9 @@ module mc_chain
     logical, save :: fused = .true.
     ! .true.: the reference's deletion update as written (SURVEY F3); see the header
     logical, save :: as_written = .false.
+    ! the messages the reference logs before the Monte Carlo loop (banner, input echo, data-file summary,
+    ! Lorentz-Berthelot listing, Ewald parameters), one per line, prepared by the front end (io_maniac.log_header_lines)
+    character(len=:), allocatable, save :: log_header
 
 contains
 
@@ -346,6 +349,58 @@ contains
         integer(c_int), value :: seams
         fused = seams == 0
     end subroutine mchain_set_mode
+
+    ! text = the header messages separated by line feeds (n bytes; n = 0 clears it)
+    subroutine mchain_set_log_header(text, n) bind(C, name="mchain_set_log_header")
+        integer(c_int), value :: n
+        character(kind=c_char), intent(in) :: text(*)
+        integer :: i
+        if (allocated(log_header)) deallocate(log_header)
+        if (n <= 0) return
+        allocate(character(len=n) :: log_header)
+        do i = 1, n
+            log_header(i:i) = text(i)
+        end do
+    end subroutine mchain_set_log_header
+
+    ! every header message through the reference's list-directed write (LogMessage, output_utils.f90:30-36)
+    subroutine write_log_header(ch)
+        type(chain_block), intent(in) :: ch
+        integer :: a, b, n
+        if (.not. allocated(log_header)) return
+        n = len(log_header)
+        a = 1
+        do while (a <= n + 1)
+            b = index(log_header(min(a, n):n), achar(10))
+            if (a > n) then
+                call log_line(ch, '')
+                exit
+            end if
+            if (b == 0) then
+                call log_line(ch, log_header(a:n))
+                exit
+            end if
+            call log_line(ch, log_header(a:a + b - 2))
+            a = a + b
+        end do
+    end subroutine write_log_header
+
+    ! Test hook (no engine needed): write the header alone to `path`
+    subroutine mchain_write_log_header(path) bind(C, name="mchain_write_log_header")
+        character(kind=c_char), intent(in) :: path(*)
+        character(len=512) :: p
+        integer :: i
+        type(chain_block) :: tmp
+        p = ''
+        do i = 1, len(p)
+            if (path(i) == c_null_char) exit
+            p(i:i) = path(i)
+        end do
+        tmp%log_unit = 37
+        open(unit=tmp%log_unit, file=trim(p), status='replace')
+        call write_log_header(tmp)
+        close(tmp%log_unit)
+    end subroutine mchain_write_log_header
 
     subroutine mchain_set_as_written(on) bind(C, name="mchain_set_as_written")
         integer(c_int), value :: on
@@ -706,6 +761,7 @@ contains
         S%nb_step = nb_step
         S%counter = 0
         open(unit=S%log_unit, file=trim(S%outdir) // 'log.maniac', status='replace')
+        call write_log_header(S)
 
         call ComputeSystemEnergy(S%engine, e6, stat=stat)
         call note(stat)

@@ -73,6 +73,7 @@ class ManiacInput:
     rotation_proba: float = 0.0
     insertion_deletion_proba: float = 0.0
     swap_proba: float = 0.0
+    probabilities_rescaled: bool = False
     residues: List[Residue] = field(default_factory=list)
 
     def fugacity_per_A3(self):
@@ -237,6 +238,7 @@ def read_maniac_input(path) -> ManiacInput:
     inp.residues = [inp.residues[k] for k in order]
     # ValidateAndRescaleMoveProbabilities
     if abs(total - 1.0) > ERROR_TOL:
+        inp.probabilities_rescaled = True
         scale = 1.0 / total
         inp.translation_proba *= scale
         inp.rotation_proba *= scale
@@ -533,7 +535,7 @@ def read_lammps_data(path, inp: ManiacInput):
 
 # ---- .inc ---------------------------------------------------------------------------------------
 
-def read_parameters(path, n_atom_types, present_types):
+def read_parameters(path, n_atom_types, present_types, with_raw=False):
     """ReadParameters + ApplyLorentzBerthelot on an atom-type table (epsilon in K, sigma in A).
 
     ``present_types``: atom types that occur in some residue; the reference only ever stores
@@ -568,6 +570,8 @@ def read_parameters(path, n_atom_types, present_types):
                 if s > 1.0e-6 and e > 1.0e-6:
                     filled_s[i - 1, j - 1] = s
                     filled_e[i - 1, j - 1] = e
+    if with_raw:
+        return filled_e, filled_s, eps, sig
     return filled_e, filled_s
 
 
@@ -589,6 +593,136 @@ def load_system(maniac_path, data_path, inc_path, with_data=False):
     if with_data:
         return system, inp, dat
     return system, inp
+
+
+# ---- log.maniac header --------------------------------------------------------------------------
+
+MANIAC_VERSION = "v0.3.0-beta"      # what oracle/Makefile substitutes for @VERSION@ in version_module.f90.in
+
+
+def _box78(text):
+    return "| " + text.ljust(74)[:74] + " |"
+
+
+def _warn(msg):
+    """WarnUser, output_utils.f90:569-585."""
+    bar = "-" * 50
+    return [bar, "WARNING:", msg, "Execution will continue.", bar]
+
+
+def _f(value, w, d):
+    """Fortran Fw.d edit descriptor (asterisks on overflow)."""
+    t = f"{value:{w}.{d}f}"
+    return t if len(t) <= w else "*" * w
+
+
+def _data_block(name, dat, inp, is_primary, masses_n):
+    """PrepareSimulationBox + the section readers' INFO lines + LogData + LogConnectivity for one data file
+    (geometry_utils.f90:25-56, data_parser.f90:690-990, output_utils.f90:352-470)."""
+    from .engine import box_prepare
+    box_type, volume, _, _ = box_prepare(dat["matrix"])
+    out = ["====== Simulation preparation ======", "",
+           {1: "Box symmetry type: Cubic", 2: "Box symmetry type: Orthorhombic", 3: "Box symmetry type: Triclinic"}.get(
+               box_type, f"Box symmetry type determined: {box_type}"),
+           "Cell volume (Å^3): " + _f(volume, 20, 4)]
+    for key in ("bonds", "angles", "dihedrals", "impropers"):
+        if dat["bonded_counts"][key] == 0:
+            out.append(f"INFO: No {key} expected in data file: {name}")
+    out += ["", "====== Import data file ======", f"Reading file {name}", "",
+            f"Number of atoms: {dat['n_atoms']}", f"Number of type of residues: {len(inp.residues)}",
+            f"Number of type of atoms: {dat['n_atom_types']}"]
+    last = None
+    for i, r in enumerate(inp.residues):
+        n = int(dat["n_mol"][i])
+        if n != 0 and r.is_active == 1:
+            last = f"Active residue {r.name} found in the data file: {n}"
+        elif n != 0 and r.is_active == 0:
+            last = f"Inactive residue {r.name} found in the data file: {n}"
+        # a residue absent from the file repeats the previous message (LogData logs formatted_msg unconditionally)
+        out.append(last if last is not None else "")
+    m = np.asarray(dat["matrix"])
+    out += ["", "Simulation box (rows):"] + ["".join(_f(m[i, j], 12, 6) for j in range(3)) for i in range(3)]
+    out += ["", "Atoms masses (g/mol):"] + [f"{k + 1:5d}  " + _f(dat["masses"][k], 12, 6) for k in range(masses_n)]
+    if dat["bonded_counts"]["bonds"] > 0 or dat["bonded_counts"]["angles"] > 0:
+        out += ["", "===== Connectivity summary =====", ""]
+        for kind, word, ncol in (("bonds", "bond", 3), ("angles", "angle", 4)):
+            for i, r in enumerate(inp.residues):
+                if int(dat["n_mol"][i]) > 0:
+                    rows = dat["bonded_per_residue"][kind][i]
+                    out.append(f"Residue {r.name}: {len(rows)} {kind}")
+                    for row in rows[:6]:
+                        out.append(f"   {word} type {row[0]}: atoms [" + ",".join(str(v) for v in row[1:ncol]) + "]")
+                    if len(rows) > 6:
+                        out.append(f"   ... {len(rows) - 6} more {kind} not shown")
+            if kind == "bonds":
+                out.append("")
+    return out
+
+
+def log_header_lines(inp: ManiacInput, dat, maniac_name, data_name, inc_name, eps_raw, sig_raw, ewald,
+                     reservoir=None):
+    """The messages the reference logs before "Started Monte Carlo Loop", in its order: banner (WriteHeader,
+    initoutput_utils.f90:68-82), input echo (PrintInputSummary, output_utils.f90:655-735), the data-file blocks (primary,
+    then the reservoir), the Lorentz-Berthelot listing (parameters_parser.f90:116-182), LogParameters and
+    LogEwaldParameters (prepare_utils.f90:75-97).  One string per LogMessage call; the Fortran side writes each with
+    the reference's list-directed write, so line wrapping is the runtime's own.
+
+    ``eps_raw`` / ``sig_raw``: the pair table as read (K, Angstrom), before the Lorentz-Berthelot fill;
+    ``ewald``: dict(rc, tol, screening, alpha, fourier_precision, kmax, nk); ``reservoir``: (file name, parsed dict)."""
+    rule = "+" + "-" * 76 + "+"
+    out = ["", rule, _box78("MANIAC-MC - Version " + MANIAC_VERSION),
+           _box78("Code written and maintained by Simon Gravelle, LIPhy, CNRS"), rule, ""]
+    if inp.probabilities_rescaled:
+        out += _warn("Move probabilities rescaled to sum to 1.0")
+    out += ["====== Import input file ======", "", f"Reading file {maniac_name}", "", "=== Generic parameters",
+            f"Number of blocks: {inp.nb_block}", f"Number of steps: {inp.nb_step}",
+            "Temperature (K): " + _f(inp.temperature, 10, 2), "", "=== Electrostatic interactions",
+            "Ewald tolerance: " + _f(inp.ewald_tolerance, 15, 8), "Cutoff (Å): " + _f(inp.real_space_cutoff, 10, 2), "",
+            "=== Monte carlo move", "Translation step (Å): " + _f(inp.translation_step, 10, 2),
+            "Rotation step angle (radian): " + _f(inp.rotation_step_angle, 10, 2),
+            "Translation proba: " + _f(inp.translation_proba, 10, 2), "Rotation proba: " + _f(inp.rotation_proba, 10, 2),
+            "Insertion deletion proba: " + _f(inp.insertion_deletion_proba, 10, 2), "Swap proba: " + _f(inp.swap_proba, 10, 2),
+            "", "=== Residue information", "", f"Number of type of residue found: {len(inp.residues)}", ""]
+    for r in inp.residues:
+        out += [f"  Residue {r.name}", "  Is active: " + ("yes" if r.is_active == 1 else "no")]
+        if r.is_active == 1:
+            out.append("  Fugacity (atm): " + _f(r.fugacity_atm, 10, 2))
+        out += [f"  Number of atoms in residue: {r.nb_atoms}", f"  Number of atom types in residue: {len(r.types)}",
+                "  Types:" + "".join(f" {t}" for t in r.types), "  Names:" + "".join(f" {n}" for n in r.names), ""]
+    out += _data_block(data_name, dat, inp, True, dat["n_atom_types"])
+    if reservoir is not None:
+        out += _data_block(reservoir[0], reservoir[1], inp, False, dat["n_atom_types"])
+    # ApplyLorentzBerthelot: pairs in the order the 4-deep loop (residue, atom, residue, atom) first meets them
+    warned = set()
+    types = dat["atom_types"]
+    lb = []
+    for i, ri in enumerate(inp.residues):
+        for k in range(ri.nb_atoms):
+            for j, rj in enumerate(inp.residues):
+                for l in range(rj.nb_atoms):
+                    ti, tj = int(types[i, k]), int(types[j, l])
+                    if ti <= 0 or tj <= 0:
+                        continue
+                    if abs(eps_raw[ti - 1, tj - 1]) < 1.0e-6 and abs(sig_raw[ti - 1, tj - 1]) < 1.0e-6:
+                        sg = (sig_raw[ti - 1, ti - 1] + sig_raw[tj - 1, tj - 1]) / 2
+                        ep = math.sqrt(eps_raw[ti - 1, ti - 1] * eps_raw[tj - 1, tj - 1])
+                        if sg > 1.0e-6 and ep > 1.0e-6 and (ti, tj) not in warned:
+                            if not warned:
+                                lb += ["INFO: Enforcing the Lorentz-Berthelot rule", "typei typej epsilon sigma"]
+                            a, b = (ti, tj) if ti < tj else (tj, ti)
+                            lb.append(f"{a:3d} -{b:3d} : " + _f(sg, 8, 4) + " Å " + _f(ep * KB_KCALMOL, 8, 4) + " kcal/mol")
+                            warned.add((ti, tj)); warned.add((tj, ti))
+    out += lb
+    km = ewald["kmax"]
+    out += ["", "====== Import parameter file ======", "", f"Reading file {inc_name}",
+            "Real-space cutoff (Å): " + _f(ewald["rc"], 10, 4),
+            "Ewald accuracy tolerance: " + "%12s" % ("%.5E" % ewald["tol"]),
+            "Screening factor (dimensionless): " + _f(ewald["screening"], 10, 4),
+            "Ewald damping parameter alpha (1/Å): " + _f(ewald["alpha"], 10, 4),
+            "Fourier-space precision parameter: " + _f(ewald["fourier_precision"], 10, 4),
+            f"Max Fourier index (kmax(1), kmax(2), kmax(3)): {int(km[0]):5d}, {int(km[1]):5d}, {int(km[2]):5d}",
+            f"Total reciprocal lattice vectors: {int(ewald['nk']):10d}"]
+    return out
 
 
 # ---- writing input files ------------------------------------------------------------------------

@@ -49,6 +49,23 @@ def _mol_arrays(com, off, n1):
     return com, off
 
 
+def header_text(inp, dat, maniac_path, data_path, inc_path, eng_or_ewald, reservoir_path=None, rdat=None):
+    """The messages above "Started Monte Carlo Loop" as one byte string (one message per line) for mchain_set_log_header.
+    File names are echoed as given, like the reference does.  ``eng_or_ewald``: an Engine, or the dict ewald_setup returns."""
+    present = sorted({int(t) for i, r in enumerate(inp.residues) for t in dat["atom_types"][i, : r.nb_atoms] if t > 0})
+    _, _, eps_raw, sig_raw = io_maniac.read_parameters(inc_path, dat["n_atom_types"], present, with_raw=True)
+    if isinstance(eng_or_ewald, dict):
+        ew = eng_or_ewald
+    else:
+        from .engine import ewald_setup
+        _, _, _, metrics = box_prepare(dat["matrix"])
+        ew = ewald_setup(metrics, inp.real_space_cutoff, inp.ewald_tolerance)
+        assert ew["nk"] == eng_or_ewald.nk and ew["alpha"] == eng_or_ewald.alpha      # what the engine itself set up
+    lines = io_maniac.log_header_lines(inp, dat, maniac_path, data_path, inc_path, eps_raw, sig_raw, ew,
+                                       reservoir=(reservoir_path, rdat) if reservoir_path else None)
+    return "\n".join(lines).encode("utf-8")
+
+
 def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoir_path=None, device=0,
                    mol_capacity=None, nb_block=None, nb_step=None, seams=False, as_written=False):
     """Run the chain; returns a dict with the final energies (K), counters, molecule counts, step sizes.
@@ -63,6 +80,7 @@ def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoi
     charged grand-canonical runs this reproduces the reference's files but not the intended physics (default False).
     """
     system, inp, dat = io_maniac.load_system(maniac_path, data_path, inc_path, with_data=True)
+    rdat = io_maniac.read_lammps_data(reservoir_path, inp) if reservoir_path else None
     topo = system.topo
     n_res = topo.n_res
     if mol_capacity is None:
@@ -98,11 +116,12 @@ def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoi
         H.mchain_set_tables(masses.ctypes.data_as(_dp), ntypes.ctypes.data_as(_ip))
         H.mchain_set_mode(C.c_int(1 if seams else 0))
         H.mchain_set_as_written(C.c_int(1 if as_written else 0))
+        header = header_text(inp, dat, maniac_path, data_path, inc_path, eng, reservoir_path, rdat)
+        H.mchain_set_log_header(header, C.c_int(len(header)))
         H.mchain_set_moves(C.c_double(inp.translation_step), C.c_double(inp.rotation_step_angle),
                            C.c_double(inp.translation_proba), C.c_double(inp.rotation_proba),
                            C.c_int(1 if inp.recalibrate_moves else 0))
         if reservoir_path:
-            rdat = io_maniac.read_lammps_data(reservoir_path, inp)
             rkeep, rargs = _box_args(rdat)
             any_bonded = np.array([1 if rdat["bonded_counts"][k] > 0 else 0
                                    for k in ("bonds", "angles", "dihedrals", "impropers")], dtype=np.int32)

@@ -12,8 +12,8 @@ intended physics; the cases marked as_written (co2_gcmc = BASELINE.json configs[
 configs[3] in miniature) are the reference's files all the same, and the chain driver reproduces them in its
 as-written mode (mchain_set_as_written); every other case is identical in both modes.
 Layout: tests/golden/runs/<case>/inputs/{system.maniac,system.data,system.inc[,reservoir.data]},
-        tests/golden/runs/<case>/expected/<the reference's output files>, log_mc.txt = log.maniac from the
-        "Started Monte Carlo Loop" box on, with the output path blanked.
+        tests/golden/runs/<case>/expected/<the reference's output files>; log.maniac is the whole log (banner, input
+        echo, data-file summary, Lorentz-Berthelot listing, Ewald parameters, Monte Carlo part) with the output path blanked.
 """
 import json
 import os
@@ -112,18 +112,21 @@ def main():
                 os.remove(os.path.join(inputs, junk))
         with tempfile.TemporaryDirectory() as tmp:
             out = os.path.join(tmp, "out", "")
-            cmd = [sys.executable, os.path.join(ROOT, "oracle", "run_ref_mc.py"), *args, out, str(SEED)]
+            # run from the inputs directory with relative file names: the log echoes the names as given, and a
+            # path-free header is the same wherever the test-suite later runs
+            rel = [os.path.basename(a) for a in args]
+            cmd = [sys.executable, os.path.join(ROOT, "oracle", "run_ref_mc.py"), *rel, out, str(SEED)]
             if res_path:
-                cmd.append(res_path)
-            p = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp)
+                cmd.append(os.path.basename(res_path))
+            p = subprocess.run(cmd, capture_output=True, text=True, cwd=inputs)
             assert "RUN_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
             os.makedirs(expected, exist_ok=True)
             for f in sorted(os.listdir(out)):
                 if f == "log.maniac":
+                    # the whole log; only the output directory (a temporary path, printed in the closing box) is blanked
                     lines = open(os.path.join(out, f)).read().split("\n")
-                    start = next(i for i, ln in enumerate(lines) if "Started Monte Carlo Loop" in ln) - 2
-                    tail = ["<output path>" if out.rstrip("/") in ln else ln for ln in lines[start:]]
-                    open(os.path.join(expected, "log_mc.txt"), "w").write("\n".join(tail))
+                    lines = ["<output path>" if out.rstrip("/") in ln else ln for ln in lines]
+                    open(os.path.join(expected, "log.maniac"), "w").write("\n".join(lines))
                 else:
                     shutil.copy(os.path.join(out, f), os.path.join(expected, f))
         last = open(os.path.join(expected, "moves.dat")).read().strip().split("\n")[-1].split()

@@ -1,8 +1,9 @@
 """Whole-run parity: the Fortran chain driver on the engine (B = 1 seams of
 maniac_gpu.f90) against the reference's own MonteCarloLoop on the same input files and seed.  The chain
 draws its random numbers in the reference's order, so it must visit the same states: the output files --
-energy.dat, moves.dat, number_<res>.dat, trajectory.lammpstrj, topology.data, reservoir.lammpstrj and the
-Monte Carlo part of log.maniac -- are compared with the files the reference wrote
+energy.dat, moves.dat, number_<res>.dat, trajectory.lammpstrj, topology.data, reservoir.lammpstrj and the WHOLE
+log.maniac (banner, input echo, data-file summary, Lorentz-Berthelot listing, Ewald parameters, status table, final
+report; only the output directory printed in the closing box is blanked) -- are compared with the files the reference wrote
 (tests/golden/runs/*/expected, made by tests/golden/make_run_fixtures.py), character for character.
 The charged grand-canonical cases (summary "as_written": co2_gcmc = BASELINE.json configs[2] with Nk = 2975,
 framework_water_gcmc = configs[3] in miniature) are the reference's files WITH its deletion defect;
@@ -30,11 +31,15 @@ def test_run_writes_the_reference_files(case, seams, tmp_path):
     inputs = os.path.join(RUNS, case, "inputs")
     expected = os.path.join(RUNS, case, "expected")
     out = str(tmp_path / "out") + "/"
-    reservoir = os.path.join(inputs, "reservoir.data") if SUMMARY[case]["reservoir"] else None
+    reservoir = "reservoir.data" if SUMMARY[case]["reservoir"] else None
     as_written = bool(SUMMARY[case].get("as_written"))
-    res = run.run_simulation(os.path.join(inputs, "system.maniac"), os.path.join(inputs, "system.data"),
-                             os.path.join(inputs, "system.inc"), out, seed=SUMMARY[case]["seed"],
-                             reservoir_path=reservoir, seams=seams, as_written=as_written)
+    cwd = os.getcwd()
+    os.chdir(inputs)                    # the log echoes the file names as given: the fixtures used relative ones
+    try:
+        res = run.run_simulation("system.maniac", "system.data", "system.inc", out, seed=SUMMARY[case]["seed"],
+                                 reservoir_path=reservoir, seams=seams, as_written=as_written)
+    finally:
+        os.chdir(cwd)
     # running energies of the chain == a full recomputation of the final configuration (as written, A(k) carries
     # the terms of deleted molecules, so the reciprocal energy and the total are exempt there)
     for k, v in res["energy"].items():
@@ -42,14 +47,12 @@ def test_run_writes_the_reference_files(case, seams, tmp_path):
             continue
         assert abs(v - res["recomputed_energy"][k]) <= 1e-9 * max(1.0, abs(v)) + 50 * TOL_K, k
     produced = sorted(os.listdir(out))
-    assert produced == sorted(f if f != "log_mc.txt" else "log.maniac" for f in SUMMARY[case]["files"])
+    assert produced == sorted(SUMMARY[case]["files"]) and "log.maniac" in produced
     for f in SUMMARY[case]["files"]:
         want = open(os.path.join(expected, f)).read().split("\n")
-        if f == "log_mc.txt":
-            got = open(os.path.join(out, "log.maniac")).read().split("\n")
+        got = open(os.path.join(out, f)).read().split("\n")
+        if f == "log.maniac":
             got = ["<output path>" if out.rstrip("/") in ln else ln for ln in got]
-        else:
-            got = open(os.path.join(out, f)).read().split("\n")
         assert len(got) == len(want), f
         bad = [i for i, (a, b) in enumerate(zip(got, want)) if a != b]
         assert not bad, f"{f}: first differing line {bad[0] + 1}: {got[bad[0]]!r} vs {want[bad[0]]!r} ({len(bad)} lines differ)"

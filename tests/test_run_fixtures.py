@@ -50,3 +50,38 @@ def test_written_input_files_round_trip(tmp_path):
     for t in range(system.topo.n_res):
         assert np.max(np.abs(again.all_sites(t) - system.all_sites(t))) < 1e-13
     assert np.allclose(again.topo.epsilon, system.topo.epsilon, rtol=1e-15, atol=0)
+
+
+@pytest.mark.parametrize("case", sorted(SUMMARY))
+def test_log_header_is_the_references(case, tmp_path):
+    """Everything the reference logs before "Started Monte Carlo Loop" -- banner, input echo, box and data-file
+    summary (primary and reservoir), Lorentz-Berthelot listing, LogEwaldParameters block -- rebuilt by the front end
+    (io_maniac.log_header_lines) and written through the Fortran driver's list-directed write (so long lines wrap as
+    the runtime wraps them): character for character the head of the log the reference wrote for the fixture."""
+    import ctypes as C
+    from maniac_mc_amd import fortran_host, run
+    from maniac_mc_amd.engine import box_prepare, ewald_setup
+    if not os.path.exists(fortran_host.LIB_PATH):
+        pytest.skip("Fortran host library not built")
+    d = os.path.join(RUNS, case, "inputs")
+    cwd = os.getcwd()
+    os.chdir(d)                                   # the fixtures were generated with relative file names
+    try:
+        system, inp, dat = io_maniac.load_system("system.maniac", "system.data", "system.inc", with_data=True)
+        res = "reservoir.data" if SUMMARY[case]["reservoir"] else None
+        rdat = io_maniac.read_lammps_data(res, inp) if res else None
+        _, _, _, metrics = box_prepare(dat["matrix"])
+        ew = ewald_setup(metrics, inp.real_space_cutoff, inp.ewald_tolerance)
+        text = run.header_text(inp, dat, "system.maniac", "system.data", "system.inc", ew, res, rdat)
+    finally:
+        os.chdir(cwd)
+    H = fortran_host.lib()
+    H.mchain_set_log_header(text, C.c_int(len(text)))
+    out = tmp_path / "header.txt"
+    H.mchain_write_log_header(str(out).encode())
+    H.mchain_set_log_header(b"", C.c_int(0))
+    got = open(out).read().split("\n")
+    want = open(os.path.join(RUNS, case, "expected", "log.maniac")).read().split("\n")
+    stop = next(i for i, ln in enumerate(want) if "Started Monte Carlo Loop" in ln) - 2
+    assert got[-1] == "" and got[:-1] == want[:stop], next(
+        (i, a, b) for i, (a, b) in enumerate(zip(got + [None] * 400, want[:stop] + [None])) if a != b)
