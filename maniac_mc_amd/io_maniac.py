@@ -597,7 +597,7 @@ def load_system(maniac_path, data_path, inc_path, with_data=False):
 
 # ---- log.maniac header --------------------------------------------------------------------------
 
-MANIAC_VERSION = "v0.3.0-beta"      # what oracle/Makefile substitutes for @VERSION@ in version_module.f90.in
+MANIAC_VERSION = "v0.3.0-beta"      # the reference version this front end mirrors (its version_module string)
 
 
 def _box78(text):
