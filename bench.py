@@ -221,17 +221,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--replicas", type=int, default=8192, help="independent chains per GPU")
+    ap.add_argument("--replicas", type=int, default=None,
+                    help="independent chains per GPU (default: 8192 for the SPC/E workload, 2048 for the isotherm, whose small "
+                         "boxes are host-bound)")
     ap.add_argument("--n-side", type=int, default=15, help="SPC/E lattice side (15 -> 10 125 atoms)")
     ap.add_argument("--host", choices=["fortran", "python"], default="fortran",
                     help="Metropolis driver: the Fortran farm (mc_farm.f90, two overlapped lanes) or the numpy one")
     ap.add_argument("--host-threads", type=int, default=0,
                     help="OpenMP threads of the Fortran driver per GPU (0: min(8, cores available / ranks on the node))")
     ap.add_argument("--no-pin", action="store_true", help="do not bind the host threads to the GPU's NUMA node")
-    ap.add_argument("--lanes", type=int, default=4,
+    ap.add_argument("--lanes", type=int, default=None,
                     help="submission lanes (chain groups in flight) of the Fortran driver: the host prepares / resolves one "
                          "group while the GPU evaluates the others (measured: 2048 chains x 2 lanes 5.6 M, 8192 x 4 lanes 6.9 M "
-                         "accepted moves/s; kernels of different lanes overlap, which stretches their individual durations)")
+                         "accepted moves/s; kernels of different lanes overlap, which stretches their individual durations); "
+                         "default 4 (SPC/E) or 2 (isotherm)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -250,6 +253,10 @@ def main():
     ap.add_argument("--dump-counts", default=None, help="directory: every rank writes its chains' final molecule counts (tests)")
     args = ap.parse_args()
 
+    if args.replicas is None:
+        args.replicas = 8192 if args.workload == "spce" else 2048
+    if args.lanes is None:
+        args.lanes = 4 if args.workload == "spce" else 2
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not launched:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
