@@ -184,11 +184,13 @@ int build_coulomb_table(double alpha, double s_max, std::vector<CoulRow> &rows, 
                     const long double sign = ((j - i) & 1) ? -1.0L : 1.0L;
                     tc[i] += mono[j] * binom[j][i] * ldexpl(1.0L, i) * sign;
                 }
-            // the device evaluates in t' = t / 64 = mantissa remainder (m - 1): scale c_i by 64^i
+            // the device evaluates in ds = s - a (a = the row's first s: s with its low mantissa bits cleared; the
+            // subtraction is exact), and t = ds * 64 / 2^e on a row of octave e: scale c_i by (64 / 2^e)^i, a power of two
             CoulRow &row = rows[(size_t)o * per_oct + q];
-            for (int i = 0; i < 5; ++i) row.c[i] = (double)ldexpl(tc[i], kCoulM * i);
-            row.c5 = (float)ldexpl(tc[5], kCoulM * 5);
-            row.c6 = (float)ldexpl(tc[6], kCoulM * 6);
+            const int sh = kCoulM - (kCoulEmin + o);
+            for (int i = 0; i < 5; ++i) row.c[i] = (double)ldexpl(tc[i], sh * i);
+            row.c5 = (float)ldexpl(tc[5], sh * 5);
+            row.c6 = (float)ldexpl(tc[6], sh * 6);
         }
     return MGPU_OK;
 }
@@ -204,10 +206,10 @@ double coulomb_table_eval_host(const std::vector<CoulRow> &rows, int idx_base, d
     }
     const int last = (int)rows.size() - 1;
     if (row > last) row = last;
-    const unsigned long long mb = (bits & ((1ull << (52 - kCoulM)) - 1)) | (0x3ffull << 52);
-    double m;
-    std::memcpy(&m, &mb, 8);
-    const double t = m - 1.0;
+    const unsigned long long ab = bits & ~((1ull << (52 - kCoulM)) - 1);      // the row's first s
+    double a;
+    std::memcpy(&a, &ab, 8);
+    const double t = s - a;
     const CoulRow &r = rows[row];
     double p = (double)r.c6;
     p = std::fma(p, t, (double)r.c5);

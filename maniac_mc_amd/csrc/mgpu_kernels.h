@@ -143,7 +143,7 @@ __device__ __forceinline__ double fast_rcp(double x) {
 
 // G(s) = erfc(alpha sqrt(s)) / sqrt(s), s = r^2, from the LDS-resident Coulomb table
 // (build_coulomb_table, mgpu_host_setup.cpp): the row is selected by the binary exponent and the top
-// 6 mantissa bits of s, the local coordinate t in [0, 2^-6) is the remaining mantissa, the value a
+// 6 mantissa bits of s, the local coordinate t = s - (s with the remaining mantissa bits cleared), the value a
 // degree-6 polynomial (5 fp64 + 2 fp32 coefficients = 48 bytes = three ds_read_b128).  No sqrt, rsqrt,
 // erfc, exp or division.  `below` is set for s < 2^-2 (r < 0.5 A), where the caller takes the slow path.
 __device__ __forceinline__ double coul_lds(double s, const char *__restrict__ tab, int idx_base, int last_row,
@@ -155,9 +155,8 @@ __device__ __forceinline__ double coul_lds(double s, const char *__restrict__ ta
     // above it, on the all-zero last row (the caller replaces `below` lanes by the slow path)
     const unsigned row = min((unsigned)srow, (unsigned)last_row);
     constexpr int kMant = (1 << (20 - kCoulM)) - 1;
-    const int hi_m = (kMant & hi) | (~kMant & 0x3ff00000);                 // v_bfi_b32
-    const double m = __hiloint2double(hi_m, __double2loint(s));          // in [1, 1 + 2^-6)
-    const double t = m - 1.0;                                            // exact; rows are expanded in it
+    const double s0 = __hiloint2double(hi & ~kMant, 0);                  // the row's first s: low mantissa bits cleared
+    const double t = s - s0;                                             // exact; rows are expanded in it
     const double2 *r = reinterpret_cast<const double2 *>(tab + __umul24(row, 48));
     const double2 c01 = r[0], c23 = r[1], c4f = r[2];
     const double c5 = (double)__int_as_float(__double2loint(c4f.y));
