@@ -116,6 +116,9 @@ int mgpu_coulomb_table_eval(double alpha, double r2_max, int n, const double *r2
  * reference seeds ONE intrinsic generator with seed + 37 (i - 1) (random_utils.f90:33-56); a farm needs R
  * statistically independent streams instead (host utility, no device involved). */
 int mgpu_rng_seed_streams(long long seed, int n_streams, long long *state);
+/* Software prefetch of `bytes` bytes at p into the calling core's caches (host utility for Fortran callers, which
+ * have no prefetch intrinsic: the farm driver announces the mirror records it is about to gather). */
+void mgpu_host_prefetch(const void *p, int bytes);
 
 /* ------------------------------------------------------------------------------------------
  * Engine life cycle

@@ -243,6 +243,10 @@ int mgpu_coulomb_table_eval(double alpha, double r2_max, int n, const double *r2
     return MGPU_OK;
 }
 
+void mgpu_host_prefetch(const void *p, int bytes) {
+    for (int o = 0; o < bytes; o += 64) __builtin_prefetch((const char *)p + o, 0, 3);
+}
+
 int mgpu_rng_seed_streams(long long seed, int n_streams, long long *state) {
     if (n_streams < 0 || (n_streams > 0 && !state)) return mgpu::set_error(MGPU_ERR_INVALID_ARG, "mgpu_rng_seed_streams: bad argument");
     auto splitmix = [](unsigned long long &x) {

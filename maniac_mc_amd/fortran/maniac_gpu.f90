@@ -87,6 +87,11 @@ module maniac_gpu
             real(c_double), intent(out) :: out(6)
             integer(c_int) :: rc
         end function
+        subroutine mgpu_host_prefetch(p, bytes) bind(C, name="mgpu_host_prefetch")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: p
+            integer(c_int), value :: bytes
+        end subroutine
         function mgpu_rng_seed_streams(seed, n_streams, state) bind(C, name="mgpu_rng_seed_streams") result(rc)
             import :: c_int, c_long_long
             integer(c_long_long), value :: seed

@@ -450,6 +450,12 @@ contains
             L%sel_ia(i) = ia
             L%sel_mv(i) = mv
             L%sel_slot(i) = slot
+            ! announce the mirror record phase 3 will gather: a prefetch does not stall this loop, so a thread has
+            ! the DRAM misses of all its chains in flight instead of taking them one by one in phase 3
+            if (slot > 0) then
+                k = F%first(ia) + merge(1, slot, mv == MV_CREATION)
+                call mgpu_host_prefetch(c_loc(F%mol(1, k, r)), int(8 * (3 + 3 * F%n1(ia)), c_int))
+            end if
         end do
         !$omp end do
         !$omp master
