@@ -422,18 +422,30 @@ int flush_all_deferred(mgpu_engine *e) {
     return MGPU_OK;
 }
 
+// LDS of trial_k_kernel: phase tables of four site sets, one XY table, charges, site coordinates, row table
+size_t trial_k_lds_bytes(const mgpu_engine *e, int n1_max) {
+    const int ktot = e->kmax[0] + e->kmax[1] + e->kmax[2] + 3;
+    return (size_t)4 * n1_max * ktot * sizeof(double2) + (size_t)e->n_rrows * (2 * n1_max * sizeof(double2) + sizeof(RecipRow)) +
+           (size_t)(2 + 12) * n1_max * sizeof(double);
+}
+constexpr int kTrialKMaxTasks = kBlock * 8;     // tasks per launch the fused kernel's registers hold (8 per thread)
+
 // Deferred commit + k sweep of the lane's new trial in one launch (trial_k_kernel)
 int launch_trial_k(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items, int n1_max, int site_stride,
                    const int *d_pend_idx, double *d_u_new, double *d_u_old) {
     const Lane::Deferred &d = ln.deferred;
-    const size_t lds = recip_rows_lds_bytes(e, n1_max) + (size_t)12 * n1_max * sizeof(double);
+    const size_t lds = trial_k_lds_bytes(e, n1_max);
     hipEvent_t a = nullptr, b = nullptr;
     int rc = prof_begin(e, ln, MGPU_KERNEL_RECIP, &a, &b);
     if (rc) return rc;
-    hipExtLaunchKernelGGL((trial_k_kernel<0>), dim3(n_items), dim3(kBlock), lds, ln.stream, a, b, 0, e->tp, e->bx, e->d_pos,
-                          e->d_nmol, e->d_res_q, e->d_trj, e->d_tw, e->n_rtasks, e->d_rrows, e->n_rrows, e->d_A, d_items,
-                          (const double *)ln.d_sites.p, site_stride, d.d_items, d.d_sites, d.stride, d_pend_idx, n1_max,
-                          d_u_new, d_u_old);
+#define MGPU_LAUNCH_TRIAL_K(NT)                                                                                         \
+    hipExtLaunchKernelGGL((trial_k_kernel<NT>), dim3(n_items), dim3(kBlock), lds, ln.stream, a, b, 0, e->tp, e->bx, e->d_pos, \
+                          e->d_nmol, e->d_res_q, e->d_trj, e->d_tw, e->n_rtasks, e->d_rrows, e->n_rrows, e->d_A, d_items,  \
+                          (const double *)ln.d_sites.p, site_stride, d.d_items, d.d_sites, d.stride, d_pend_idx, n1_max,  \
+                          d_u_new, d_u_old)
+    if (e->n_rtasks <= kBlock * 5) MGPU_LAUNCH_TRIAL_K(5);
+    else MGPU_LAUNCH_TRIAL_K(8);
+#undef MGPU_LAUNCH_TRIAL_K
     rc = prof_end(e, ln, MGPU_KERNEL_RECIP, a, b);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
@@ -1130,8 +1142,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     if (ln.deferred.active) {
         Lane::Deferred &d = ln.deferred;
         const int n1_both = std::max(n1_max, d.n1_max);
-        bool ok = recip_by_rows(e, n1_both) &&
-                  recip_rows_lds_bytes(e, n1_both) + (size_t)12 * n1_both * sizeof(double) <= 64 * 1024;
+        bool ok = recip_by_rows(e, n1_both) && e->n_rtasks <= kTrialKMaxTasks && trial_k_lds_bytes(e, n1_both) <= 64 * 1024;
         if ((int)ln.mark.size() != e->n_replicas) ln.mark.assign(e->n_replicas, -1);
         if (ok) {
             for (int i = 0; i < d.n; ++i)

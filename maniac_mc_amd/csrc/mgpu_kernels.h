@@ -847,19 +847,22 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
 // ------------------------------------------------------------------------------------------
 // Deferred commit + k sweep of a lane's NEXT trial in one launch (row form), one workgroup per candidate of the
 // new trial.  The host accepted some candidates of the lane's previous trial but did not launch their commit:
-// the workgroup of the new candidate on the same replica applies it first --
-//   stage A (only if pend_idx[c] >= 0):  A <- A + delta(previous accepted move), coordinates / count of the replica
-//                                        updated exactly as recip_rows_kernel<true, false> does;
-//   stage B:                             u_old = sum ff W |A|^2, u_new = sum ff W |A + delta(candidate)|^2 on the updated A
-// -- so A(k) is read from HBM once for both (stage B re-reads what the same threads have just written) and the
-// commit costs no launch of its own.  The previous trial's items and site rows are still resident in the lane's
-// other staging buffer.  Every candidate of the new trial must sit on a different replica (the host checks it);
-// accepted previous candidates whose replica has no new candidate are committed by the stand-alone kernel.
-// The "old" sites of the new candidate are read BEFORE the coordinate update and patched where the previous move
-// touched the same slot (it moved / created that molecule, or its swap-with-last filled that slot).
+// the workgroup of the new candidate on the same replica applies it --
+//   delta_prev(k) of the previous accepted move and delta_cur(k) of the new candidate are both formed from phase
+//   tables built in ONE pass (four site sets: candidate new / old, previous new / old); then ONE pass over A(k):
+//   A <- A + delta_prev (stored, coordinates / count of the replica updated exactly as the stand-alone commit does),
+//   u_old = sum ff W |A|^2 and u_new = sum ff W |A + delta_cur|^2 on the updated A
+// -- so A(k) crosses HBM once per trial (read) plus once per accepted move (write) and the commit costs neither a
+// launch nor a second latency chain.  The arithmetic per k is the stand-alone kernels' (A + delta_prev formed the same
+// way, energies from the stored value), so results are bitwise those of commit launch + k sweep.  The previous
+// trial's items and site rows are still resident in the lane's other staging buffer.  Every candidate of the new
+// trial must sit on a different replica (the host checks it); accepted previous candidates whose replica has no new
+// candidate are committed by the stand-alone kernel.  The "old" sites of the new candidate are read BEFORE the
+// coordinate update and patched where the previous move touched the same slot (it moved / created that molecule,
+// or its swap-with-last filled that slot).  NT = tasks per thread the registers hold (n_tasks <= 256 NT).
 // ------------------------------------------------------------------------------------------
-template <int DUMMY = 0>
-__global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void trial_k_kernel(
+template <int NT>
+__global__ __launch_bounds__(kBlock, 2) void trial_k_kernel(
     Topo tp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
     const int *__restrict__ trj, const double2 *__restrict__ tw, int n_tasks, const RecipRow *__restrict__ rows, int n_rows,
     double2 *__restrict__ A_base, const RecipItem *__restrict__ items, const double *__restrict__ cand_sites, int site_stride,
@@ -881,9 +884,10 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void trial_k_kernel(
     const int n1c = tp.n1[it.t], n1p = tp.n1[pit.t];
     const int kofs[3] = {0, bx.kmax[0] + 1, bx.kmax[0] + bx.kmax[1] + 2};
     const int ktot = bx.kmax[0] + bx.kmax[1] + bx.kmax[2] + 3;
-    double2 *s_xy = s_tab + 2 * n1_max * ktot;
-    double *s_q = reinterpret_cast<double *>(s_xy + n_rows * 2 * n1_max);
-    double *s_site = s_q + n1_max;                           // [4 sets][n1_max][3]: cur new, cur old, pend new, pend old
+    // LDS: phase tables of the four site sets [set][site][ktot] | XY [row][2 n1] | charges (cur, prev) | sites | rows
+    double2 *s_xy = s_tab + 4 * n1_max * ktot;
+    double *s_q = reinterpret_cast<double *>(s_xy + n_rows * 2 * n1_max);       // [2][n1_max]
+    double *s_site = s_q + 2 * n1_max;                       // [4 sets][n1_max][3]: cur new, cur old, pend new, pend old
     RecipRow *s_rows = reinterpret_cast<RecipRow *>(s_site + 12 * n1_max);
     double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
     double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
@@ -896,8 +900,21 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void trial_k_kernel(
         if (pit.kind == 2) old_slot = pend_last; else old_src = 1;
     }
 
+    // A(k), weights and task words of this thread's tasks: requested first, used last (nothing below depends on them)
+    int rj[NT];
+    double2 Ap[NT], Am[NT], w[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const int t = threadIdx.x + c * kBlock;
+        const bool in = t < n_tasks;
+        rj[c] = in ? trj[t] : 0;
+        Ap[c] = in ? A[2 * t] : make_double2(0.0, 0.0);
+        Am[c] = in ? A[2 * t + 1] : make_double2(0.0, 0.0);
+        w[c] = in ? tw[t] : make_double2(0.0, 0.0);
+    }
+
     for (int r = threadIdx.x; r < n_rows; r += kBlock) s_rows[r] = rows[r];
-    // ---- stage 0: every site coordinate this workgroup needs, read before anything is written
+    // ---- every site coordinate this workgroup needs, read before anything is written
     for (int e = threadIdx.x; e < 4 * n1_max; e += kBlock) {
         const int set = e / n1_max, a = e - set * n1_max;
         double x = 0.0, y = 0.0, z = 0.0;
@@ -921,57 +938,16 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void trial_k_kernel(
         }
         s_site[e * 3 + 0] = x; s_site[e * 3 + 1] = y; s_site[e * 3 + 2] = z;
     }
+    for (int a = threadIdx.x; a < 2 * n1_max; a += kBlock) {
+        const int which = a / n1_max, aa = a - which * n1_max;
+        const int t = which == 0 ? it.t : pit.t;
+        s_q[a] = aa < tp.n1[t] ? res_q[t * tp.max_atom + aa] : 0.0;
+    }
     __syncthreads();
 
-    const double2 *zt = s_tab + kofs[2];
-    // phase 1 + 2 for one (new set, old set) pair of site sets of a molecule of type t with n1 sites
-    auto build_tables = [&](int t, int n1, int set_new, bool use_new, int set_old, bool use_old) {
-        const int nss = 2 * n1;
-        for (int e = threadIdx.x; e < nss * ktot; e += kBlock) {
-            const int s = e / ktot, kk = e - s * ktot;
-            const int which = s >= n1 ? 1 : 0, a = s - which * n1;
-            const int axis = (kk >= kofs[2]) ? 2 : (kk >= kofs[1] ? 1 : 0);
-            if (which == 0 ? !use_new : !use_old) { s_tab[e] = make_double2(0.0, 0.0); continue; }
-            const double *c = s_site + ((which == 0 ? set_new : set_old) * n1_max + a) * 3;
-            s_tab[e] = phase_entry(atom_phase(bx, axis, c[0], c[1], c[2]), kk - kofs[axis]);
-        }
-        for (int a = threadIdx.x; a < n1; a += kBlock) s_q[a] = res_q[t * tp.max_atom + a];
-        __syncthreads();
-        for (int e = threadIdx.x; e < n_rows * nss; e += kBlock) {
-            const int row = e / nss, s = e - row * nss;
-            const int which = s >= n1 ? 1 : 0, a = s - which * n1;
-            double2 v = make_double2(0.0, 0.0);
-            if (which == 0 ? use_new : use_old) {
-                const RecipRow r = s_rows[row];
-                const double2 *tb = s_tab + s * ktot;
-                const int aky = r.ky < 0 ? -r.ky : r.ky;
-                double2 Y = tb[kofs[1] + aky];
-                if (r.ky < 0) Y.y = -Y.y;
-                v = cmul(tb[r.kx], Y);
-                const double q = which == 0 ? s_q[a] : -s_q[a];
-                v.x *= q; v.y *= q;
-            }
-            s_xy[e] = v;
-        }
-        __syncthreads();
-    };
-    // delta of one task from the tables in LDS: returns (sac, sbd, sad, sbc)
-    auto task_sums = [&](int rj, int nss, double &sac, double &sbd, double &sad, double &sbc) {
-        const double2 *xy = s_xy + ((rj >> 8) & 0xfffff) * nss;
-        const double2 *z = zt + (rj & 0xff);
-        sac = 0.0; sbd = 0.0; sad = 0.0; sbc = 0.0;
-        for (int s = 0; s < nss; ++s) {
-            const double2 p = xy[s], q = z[s * ktot];
-            sac = fma(p.x, q.x, sac);
-            sbd = fma(p.y, q.y, sbd);
-            sad = fma(p.x, q.y, sad);
-            sbc = fma(p.y, q.x, sbc);
-        }
-    };
-
-    // ---- stage A: the previous accepted move of this replica
+    // coordinates / count of the previous move, exactly as the stand-alone commit (all reads of old coordinates are
+    // behind the barrier)
     if (has_pend) {
-        // coordinates / count, exactly as the stand-alone commit (all reads of old coordinates are behind us)
         if (pit.kind == 0 || pit.kind == 1) {
             if (threadIdx.x < n1p) {
                 const double *c = s_site + (2 * n1_max + threadIdx.x) * 3;
@@ -985,61 +961,89 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void trial_k_kernel(
             }
         }
         if (threadIdx.x == 0 && (pit.kind == 1 || pit.kind == 2)) nmol[pit.replica * tp.n_res + pit.t] = pit.aux;
-        build_tables(pit.t, n1p, 2, p_new, 3, p_old);
-        const int nss = 2 * n1p;
-        for (int t0 = threadIdx.x; t0 < n_tasks; t0 += kBlock * kRecipTaskChunk) {
-            int rj[kRecipTaskChunk];
-            double2 Ap[kRecipTaskChunk], Am[kRecipTaskChunk];
-#pragma unroll
-            for (int c = 0; c < kRecipTaskChunk; ++c) {
-                const int t = t0 + c * kBlock;
-                const bool in = t < n_tasks;
-                rj[c] = in ? trj[t] : 0;
-                Ap[c] = in ? A[2 * t] : make_double2(0.0, 0.0);
-                Am[c] = in ? A[2 * t + 1] : make_double2(0.0, 0.0);
-            }
-#pragma unroll
-            for (int c = 0; c < kRecipTaskChunk; ++c) {
-                double sac, sbd, sad, sbc;
-                task_sums(rj[c], nss, sac, sbd, sad, sbc);
-                const int t = t0 + c * kBlock;
-                if (t < n_tasks) {        // absent members stay zero
-                    A[2 * t] = (rj[c] & kTaskHasP) ? make_double2(Ap[c].x + (sac - sbd), Ap[c].y + (sad + sbc)) : make_double2(0.0, 0.0);
-                    A[2 * t + 1] = (rj[c] & kTaskHasM) ? make_double2(Am[c].x + (sac + sbd), Am[c].y + (sbc - sad)) : make_double2(0.0, 0.0);
-                }
-            }
-        }
-        __syncthreads();                  // the tables are rebuilt for the new candidate
     }
 
-    // ---- stage B: the new candidate against the (updated) A(k); every thread re-reads only slots it wrote itself
-    build_tables(it.t, n1c, 0, c_new, 1, c_old);
-    double acc = 0.0, acc0 = 0.0;
-    {
-        const int nss = 2 * n1c;
-        for (int t0 = threadIdx.x; t0 < n_tasks; t0 += kBlock * kRecipTaskChunk) {
-            int rj[kRecipTaskChunk];
-            double2 Ap[kRecipTaskChunk], Am[kRecipTaskChunk], w[kRecipTaskChunk];
-#pragma unroll
-            for (int c = 0; c < kRecipTaskChunk; ++c) {
-                const int t = t0 + c * kBlock;
-                const bool in = t < n_tasks;
-                rj[c] = in ? trj[t] : 0;
-                Ap[c] = in ? A[2 * t] : make_double2(0.0, 0.0);
-                Am[c] = in ? A[2 * t + 1] : make_double2(0.0, 0.0);
-                w[c] = in ? tw[t] : make_double2(0.0, 0.0);
+    // phase 1, all four sets at once: entry (set, a, axis, k >= 0) at s_tab[(set * n1_max + a) * ktot + kofs[axis] + k]
+    for (int e = threadIdx.x; e < 4 * n1_max * ktot; e += kBlock) {
+        const int sa = e / ktot, kk = e - sa * ktot;
+        const int set = sa / n1_max, a = sa - set * n1_max;
+        const int axis = (kk >= kofs[2]) ? 2 : (kk >= kofs[1] ? 1 : 0);
+        const bool used = (set == 0 ? c_new : set == 1 ? c_old : set == 2 ? p_new : p_old) && a < (set < 2 ? n1c : n1p);
+        if (!used) { s_tab[e] = make_double2(0.0, 0.0); continue; }
+        const double *c = s_site + sa * 3;
+        s_tab[e] = phase_entry(atom_phase(bx, axis, c[0], c[1], c[2]), kk - kofs[axis]);
+    }
+    __syncthreads();
+
+    // phase 2 for the (new, old) pair of sets starting at set0: XY[row][which * n1 + a]
+    auto build_xy = [&](int set0, int n1, bool use_new, bool use_old, const double *q) {
+        const int nss = 2 * n1;
+        for (int e = threadIdx.x; e < n_rows * nss; e += kBlock) {
+            const int row = e / nss, s = e - row * nss;
+            const int which = s >= n1 ? 1 : 0, a = s - which * n1;
+            double2 v = make_double2(0.0, 0.0);
+            if (which == 0 ? use_new : use_old) {
+                const RecipRow r = s_rows[row];
+                const double2 *tb = s_tab + ((set0 + which) * n1_max + a) * ktot;
+                const int aky = r.ky < 0 ? -r.ky : r.ky;
+                double2 Y = tb[kofs[1] + aky];
+                if (r.ky < 0) Y.y = -Y.y;
+                v = cmul(tb[r.kx], Y);
+                const double qa = which == 0 ? q[a] : -q[a];
+                v.x *= qa; v.y *= qa;
             }
-#pragma unroll
-            for (int c = 0; c < kRecipTaskChunk; ++c) {
-                double sac, sbd, sad, sbc;
-                task_sums(rj[c], nss, sac, sbd, sad, sbc);
-                const double wp = w[c].x, wm = w[c].y;
-                acc0 += wp * fma(Ap[c].x, Ap[c].x, Ap[c].y * Ap[c].y) + wm * fma(Am[c].x, Am[c].x, Am[c].y * Am[c].y);
-                const double npx = Ap[c].x + (sac - sbd), npy = Ap[c].y + (sad + sbc);
-                const double nmx = Am[c].x + (sac + sbd), nmy = Am[c].y + (sbc - sad);
-                acc += wp * fma(npx, npx, npy * npy) + wm * fma(nmx, nmx, nmy * nmy);   // ewald_energy.f90:259-266
-            }
+            s_xy[e] = v;
         }
+        __syncthreads();
+    };
+    // the four sums of one task over the site-states of a set pair, in the stand-alone kernels' order
+    auto task_sums = [&](int rjc, int set0, int n1, double &sac, double &sbd, double &sad, double &sbc) {
+        const double2 *xy = s_xy + ((rjc >> 8) & 0xfffff) * 2 * n1;
+        const double2 *z = s_tab + set0 * n1_max * ktot + kofs[2] + (rjc & 0xff);
+        sac = 0.0; sbd = 0.0; sad = 0.0; sbc = 0.0;
+        for (int which = 0; which < 2; ++which)
+            for (int a = 0; a < n1; ++a) {
+                const double2 p = xy[which * n1 + a], q = z[(which * n1_max + a) * ktot];
+                sac = fma(p.x, q.x, sac);
+                sbd = fma(p.y, q.y, sbd);
+                sad = fma(p.x, q.y, sad);
+                sbc = fma(p.y, q.x, sbc);
+            }
+    };
+
+    // delta of the previous accepted move, per task, in registers: (+j member, -j member)
+    double2 dp[NT], dm[NT];
+    if (has_pend) {
+        build_xy(2, n1p, p_new, p_old, s_q + n1_max);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            double sac, sbd, sad, sbc;
+            task_sums(rj[c], 2, n1p, sac, sbd, sad, sbc);
+            dp[c] = make_double2(sac - sbd, sad + sbc);
+            dm[c] = make_double2(sac + sbd, sbc - sad);
+        }
+        __syncthreads();                  // XY is rebuilt for the new candidate
+    }
+    build_xy(0, n1c, c_new, c_old, s_q);
+
+    // ---- the one pass over A(k)
+    double acc = 0.0, acc0 = 0.0;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const int t = threadIdx.x + c * kBlock;
+        if (has_pend) {
+            // A <- A + delta_prev, absent members stay zero (as recip_rows_kernel<true, false> stores them)
+            Ap[c] = (rj[c] & kTaskHasP) ? make_double2(Ap[c].x + dp[c].x, Ap[c].y + dp[c].y) : make_double2(0.0, 0.0);
+            Am[c] = (rj[c] & kTaskHasM) ? make_double2(Am[c].x + dm[c].x, Am[c].y + dm[c].y) : make_double2(0.0, 0.0);
+            if (t < n_tasks) { A[2 * t] = Ap[c]; A[2 * t + 1] = Am[c]; }
+        }
+        double sac, sbd, sad, sbc;
+        task_sums(rj[c], 0, n1c, sac, sbd, sad, sbc);
+        const double wp = w[c].x, wm = w[c].y;
+        acc0 += wp * fma(Ap[c].x, Ap[c].x, Ap[c].y * Ap[c].y) + wm * fma(Am[c].x, Am[c].x, Am[c].y * Am[c].y);
+        const double npx = Ap[c].x + (sac - sbd), npy = Ap[c].y + (sad + sbc);
+        const double nmx = Am[c].x + (sac + sbd), nmy = Am[c].y + (sbc - sad);
+        acc += wp * fma(npx, npx, npy * npy) + wm * fma(nmx, nmx, nmy * nmy);   // ewald_energy.f90:259-266
     }
     acc = wave_sum(acc);
     acc0 = wave_sum(acc0);
