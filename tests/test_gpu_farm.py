@@ -204,3 +204,22 @@ def test_gcmc_farm_framework_water_at_stated_size():
             com, off = farm.molecule(r, 0, slot)
             assert np.array_equal(dev[slot], com[None, :] + off[:4])
     farm.close()
+
+
+@pytest.mark.parametrize("env", [{"MFARM_LANE_THREADS": "1"}, {"MGPU_DEFER_COMMIT": "1"},
+                                 {"MFARM_LANE_THREADS": "1", "MGPU_DEFER_COMMIT": "1"}],
+                         ids=["lane_threads", "deferred_commit", "both"])
+def test_farm_options_keep_the_invariants(env):
+    """The opt-in modes -- one host thread per lane (MFARM_LANE_THREADS=1) and commits folded into the next trial's k
+    sweep (MGPU_DEFER_COMMIT=1) -- are selected by environment variables read when the libraries start: re-run the
+    NVT / GCMC consistency tests (running energies, A(k), host mirrors vs a from-scratch evaluation) in a child
+    process with them set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_farm.py", "-q", "-x", "-m", "gpu", "-k",
+                        "test_fortran_farm_consistency or test_gcmc_farm_consistency_and_ideal_gas_limit or "
+                        "test_farm_at_benchmark_size_three_lanes"],
+                       capture_output=True, text=True, env=dict(os.environ, **env), cwd=root, timeout=900)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
