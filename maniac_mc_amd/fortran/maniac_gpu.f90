@@ -348,6 +348,18 @@ contains
         call GpuCheck(rc, 'ComputeRecipEnergySingleMol', stat)
     end subroutine ComputeRecipEnergySingleMol
 
+    ! mc_acceptance_probability_swap (monte_carlo_utils.f90:228-268): acceptance of turning a molecule of a type with
+    ! n_old molecules (fugacity phi_old) into one of a type with n_new molecules (phi_new); energies in K.  The
+    ! reference has this rule and a `swap_proba` keyword but no swap move (monte_carlo.f90:50-75 has no branch for it).
+    pure function mc_acceptance_probability_swap(old_total, new_total, n_old, n_new, phi_old, phi_new, temperature) &
+            result(probability)
+        real(real64), intent(in) :: old_total, new_total, phi_old, phi_new, temperature
+        integer, intent(in) :: n_old, n_new
+        real(real64) :: probability, combinatorial
+        combinatorial = real(n_old, real64) / (real(n_new, real64) + 1.0_real64)
+        probability = min(1.0_real64, (phi_new / phi_old) * combinatorial * exp(-(new_total - old_total) / temperature))
+    end function mc_acceptance_probability_swap
+
     ! ComputeEwaldSelfInteractionSingleMol (ewald_energy.f90:308-336)
     subroutine ComputeEwaldSelfInteractionSingleMol(engine, residue_type, self_energy, stat)
         type(c_ptr), intent(in) :: engine

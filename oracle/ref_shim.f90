@@ -500,6 +500,45 @@ contains
         p = mc_acceptance_probability(eo, en, res_type, move_type)
     end function ref_acceptance
 
+    ! mc_acceptance_probability_swap (monte_carlo_utils.f90:228-268): the only piece of a swap move the reference has
+    function ref_acceptance_swap(old_total, new_total, type_old, type_new, fug_old, fug_new) &
+            bind(C, name="ref_acceptance_swap") result(p)
+        real(c_double), value :: old_total, new_total, fug_old, fug_new
+        integer(c_int), value :: type_old, type_new
+        real(c_double) :: p
+        type(energy_state) :: eo, en
+        eo%total = old_total
+        en%total = new_total
+        input%fugacity(type_old) = fug_old
+        input%fugacity(type_new) = fug_new
+        p = mc_acceptance_probability_swap(eo, en, type_old, type_new)
+    end function ref_acceptance_swap
+
+    ! PrecomputeTable + LookupTabulated (tabulated_utils.f90:10-113): the reference's tabulated potentials.  They are
+    ! dead code in the reference (use_table is a compile-time .false., parameters.f90:42); the routines themselves
+    ! are callable.  which: 1 erfc(alpha r)/r, 2 r**6, 3 r**12.  (Re)builds the tables on first use after a setup.
+    function ref_table_lookup(which, r) bind(C, name="ref_table_lookup") result(f)
+        integer(c_int), value :: which
+        real(c_double), value :: r
+        real(c_double) :: f
+        f = 0.0_c_double
+        if (.not. is_setup) return
+        if (allocated(erfc_r_table%x)) then
+            if (erfc_r_table%dx /= input%real_space_cutoff / real(TABULATED_POINTS, real64)) then
+                deallocate(erfc_r_table%x, erfc_r_table%f, r6_table%x, r6_table%f, r12_table%x, r12_table%f)
+            end if
+        end if
+        if (.not. allocated(erfc_r_table%x)) call PrecomputeTable()
+        select case (which)
+        case (1)
+            f = LookupTabulated(erfc_r_table, r)
+        case (2)
+            f = LookupTabulated(r6_table, r)
+        case default
+            f = LookupTabulated(r12_table, r)
+        end select
+    end function ref_table_lookup
+
     ! RotationMatrix (helper_utils.f90:39-77), column-major 3x3 out
     subroutine ref_rotation_matrix(axis, theta, r) bind(C, name="ref_rotation_matrix")
         integer(c_int), value :: axis

@@ -660,6 +660,53 @@ double refcpu_acceptance(double old_total, double new_total, double N, double V,
     return fmin(1.0, exp(-de / T));
 }
 
+/* monte_carlo_utils.f90:228-268 mc_acceptance_probability_swap: a molecule of type `old` (N_old of them) becomes one of
+ * type `new` (N_new of them); the reference has this rule but no swap move (monte_carlo.f90:50-75 has no branch).
+ * The reference forms N_old / (N_new + 1) with `one` a real64: real(N_new + one) is N_new + 1.0 */
+double refcpu_acceptance_swap(double old_total, double new_total, int n_old, int n_new, double phi_old, double phi_new, double T)
+{
+    double de = new_total - old_total;
+    double combinatorial = (double)n_old / ((double)n_new + 1.0);
+    return fmin(1.0, (phi_new / phi_old) * combinatorial * exp(-de / T));
+}
+
+/* tabulated_utils.f90:10-113: the reference's tabulated potentials -- InitializeTabulatedErfcR / InitializeTabulatedRPower
+ * fill TABULATED_POINTS + 1 = 5001 points on [0, rc] (parameters.f90:41), LookupTabulated interpolates linearly and returns
+ * 0 from rc on.  Dead code in the reference (use_table is a compile-time .false., parameters.f90:42): restated and pinned
+ * for completeness; neither the reference nor the engine ever evaluates an energy with them.
+ * which: 1 erfc(alpha r)/r, 2 r**6, 3 r**12. */
+#define REFCPU_TABULATED_POINTS 5000
+static double int_power(double r, int p)
+{
+    /* flang lowers r**6 / r**12 with an integer exponent to repeated squaring: r2 = r*r; r4 = r2*r2; ... */
+    double acc = 1.0, b = r;
+    int e = p;
+    while (e > 0) {
+        if (e & 1) acc *= b;
+        e >>= 1;
+        if (e) b *= b;
+    }
+    return acc;
+}
+static double table_point(const refcpu *s, int which, int i)
+{
+    const double dx = s->rc / (double)REFCPU_TABULATED_POINTS;
+    const double r = i * dx;
+    if (which == 1) return (r < ERR) ? 2.0 * s->alpha / sqrt(PI) : erfc(s->alpha * r) / r;
+    if (r < ERR) return 0.0;
+    return int_power(r, which == 2 ? 6 : 12);
+}
+double refcpu_table_lookup(const refcpu *s, int which, double r)
+{
+    const double dx = s->rc / (double)REFCPU_TABULATED_POINTS;
+    if (r <= 0.0) return table_point(s, which, 0);
+    if (r >= REFCPU_TABULATED_POINTS * dx) return 0.0;
+    const int i = (int)(r / dx);
+    const double f1 = table_point(s, which, i), f2 = table_point(s, which, i + 1);
+    const double t = (r - i * dx) / dx;
+    return (1.0 - t) * f1 + t * f2;
+}
+
 /* helper_utils.f90:39-77 RotationMatrix; r[i*3+j] = rotation_matrix(i+1, j+1) */
 void refcpu_rotation_matrix(int axis, double theta, double *r)
 {

@@ -72,6 +72,9 @@ void refcpu_old_energy(refcpu *s, int t, int m, int kind, double *out6);
 void refcpu_new_energy(refcpu *s, int t, int m, int kind, double *out6);
 double refcpu_acceptance(double old_total, double new_total, double n_mol, double volume,
                          double fugacity, double temperature, int move_type);
+double refcpu_table_lookup(const refcpu *s, int which, double r);
+double refcpu_acceptance_swap(double old_total, double new_total, int n_old, int n_new, double phi_old, double phi_new,
+                              double T);
 void refcpu_rotation_matrix(int axis, double theta, double *r9_rowmajor);
 double refcpu_convert_fugacity(double f_atm, double temp_K);
 

@@ -46,7 +46,7 @@ def lib():
         L.refcpu_create.restype = C.c_void_p
         for name in ("refcpu_distance", "refcpu_lj", "refcpu_coulomb", "refcpu_recip_singlemol",
                      "refcpu_recip_total", "refcpu_self_singlemol", "refcpu_intra_singlemol",
-                     "refcpu_acceptance", "refcpu_convert_fugacity"):
+                     "refcpu_acceptance", "refcpu_acceptance_swap", "refcpu_convert_fugacity", "refcpu_table_lookup"):
             getattr(L, name).restype = C.c_double
         L.refcpu_get_num_residues.restype = C.c_int
         _lib = L
@@ -217,6 +217,15 @@ class RefCPU:
         return self.L.refcpu_acceptance(C.c_double(old_total), C.c_double(new_total), C.c_double(n),
                                         C.c_double(vol), C.c_double(fugacity),
                                         C.c_double(self.sys.temperature), C.c_int(move_type))
+
+    def table_lookup(self, which, r):
+        """The reference's tabulated potentials (dead code there): 1 erfc(alpha r)/r, 2 r**6, 3 r**12."""
+        return self.L.refcpu_table_lookup(self.h, C.c_int(which), C.c_double(r))
+
+    def acceptance_swap(self, old_total, new_total, t_old, t_new, fug_old, fug_new):
+        return self.L.refcpu_acceptance_swap(C.c_double(old_total), C.c_double(new_total), C.c_int(self.num_residues(t_old)),
+                                             C.c_int(self.num_residues(t_new)), C.c_double(fug_old), C.c_double(fug_new),
+                                             C.c_double(self.sys.temperature))
 
     def rotation_matrix(self, axis, theta):
         r = np.zeros(9)

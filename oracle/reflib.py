@@ -48,6 +48,8 @@ def lib():
         _lib.ref_lj.restype = C.c_double
         _lib.ref_coulomb.restype = C.c_double
         _lib.ref_acceptance.restype = C.c_double
+        _lib.ref_acceptance_swap.restype = C.c_double
+        _lib.ref_table_lookup.restype = C.c_double
         _lib.ref_convert_fugacity.restype = C.c_double
         _lib.ref_setup.restype = C.c_int
         _lib.ref_get_num_residues.restype = C.c_int
@@ -228,6 +230,13 @@ class Reference:
     def acceptance(self, old_total, new_total, t, move_type, fugacity=1.0):
         return self.L.ref_acceptance(C.c_double(old_total), C.c_double(new_total), C.c_int(t + 1),
                                      C.c_int(move_type), C.c_double(fugacity))
+
+    def table_lookup(self, which, r):
+        return self.L.ref_table_lookup(C.c_int(which), C.c_double(r))
+
+    def acceptance_swap(self, old_total, new_total, t_old, t_new, fug_old, fug_new):
+        return self.L.ref_acceptance_swap(C.c_double(old_total), C.c_double(new_total), C.c_int(t_old + 1), C.c_int(t_new + 1),
+                                          C.c_double(fug_old), C.c_double(fug_new))
 
     def rotation_matrix(self, axis, theta):
         r = np.zeros(9)

@@ -120,6 +120,15 @@ def test_small_functions_bitwise(refcpu_mod, reflib_mod):
         for de in (-50.0, 0.0, 37.5, 900.0):
             assert R.acceptance(100.0, 100.0 + de, 0, mt, 1e-4) == P.acceptance(100.0, 100.0 + de, 0, mt, 1e-4)
     assert R.convert_fugacity(0.7, 310.0) == P.convert_fugacity(0.7, 310.0)
+    # the reference's tabulated potentials (dead code there, parameters.f90:42): table build + linear lookup
+    for which in (1, 2, 3):
+        for r in list(rng.uniform(0.0, 1.05 * s.real_space_cutoff, 40)) + [0.0, -1.0, s.real_space_cutoff, 1e-12]:
+            assert R.table_lookup(which, float(r)) == P.table_lookup(which, float(r)), (which, r)
+    # the swap acceptance rule (all the reference has of a swap move, monte_carlo_utils.f90:228-268)
+    if s.topo.n_res >= 2:
+        for de in (-50.0, 0.0, 37.5, 900.0):
+            for (a, b) in ((0, 1), (1, 0)):
+                assert R.acceptance_swap(100.0, 100.0 + de, a, b, 2e-4, 5e-5) == P.acceptance_swap(100.0, 100.0 + de, a, b, 2e-4, 5e-5)
 
 
 def test_survey_logged_values():
