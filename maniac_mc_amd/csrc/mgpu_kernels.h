@@ -696,6 +696,9 @@ struct AcceptBits {
 #ifndef MGPU_RECIP_MINWAVES
 #define MGPU_RECIP_MINWAVES 4   // <= 128 VGPRs: four 4-wave workgroups per CU, 1024 items resident at once
 #endif
+#ifndef MGPU_RECIP_EARLY_LOAD
+#define MGPU_RECIP_EARLY_LOAD 0   // 1: request the first chunk of A(k) before the phase tables (measured slower, see below)
+#endif
 constexpr int kRecipTaskChunk = 5;
 template <bool COMMIT, bool BOTH>
 __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel(
@@ -730,6 +733,29 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
     double2 *A = A_base + (size_t)it.replica * bx.n_slots;
 
     for (int r = threadIdx.x; r < n_rows; r += kBlock) s_rows[r] = rows[r];
+
+    // A(k) (32 contiguous bytes per task, the bulk of the kernel's memory traffic), ff*W and the task words of a
+    // whole chunk are requested before any of them is used; none of the addresses depends on a load.
+    // (MGPU_RECIP_EARLY_LOAD = 1 requests the first chunk -- all of a thread's tasks at the bench size -- HERE, before
+    // the phase tables are built, so that the memory round trip would run under the sincos / XY phases.  Measured on
+    // MI355X, 2048 items: k sweep 27.3 -> 35.0 us, commit 25.2 -> 27.5 us: holding 65 VGPRs of loaded data across the
+    // sincos phase spills 37 dwords under the 128-VGPR cap that keeps every item's workgroup resident.)
+    int rj[kRecipTaskChunk];
+    double2 Ap[kRecipTaskChunk], Am[kRecipTaskChunk], w[kRecipTaskChunk];
+    auto load_chunk = [&](int t0) {
+#pragma unroll
+        for (int c = 0; c < kRecipTaskChunk; ++c) {
+            const int t = t0 + c * kBlock;
+            const bool in = t < n_tasks;
+            rj[c] = in ? trj[t] : 0;                                   // filler: row 0, j 0, nothing present
+            Ap[c] = in ? A[2 * t] : make_double2(0.0, 0.0);
+            Am[c] = in ? A[2 * t + 1] : make_double2(0.0, 0.0);
+            w[c] = (in && !COMMIT) ? tw[t] : make_double2(0.0, 0.0);
+        }
+    };
+#if MGPU_RECIP_EARLY_LOAD
+    load_chunk(threadIdx.x);
+#endif
 
     // phase 1: entry (s = set * n1 + a, axis, k >= 0) at s_tab[s * ktot + kofs[axis] + k]
     for (int e = threadIdx.x; e < nss * ktot; e += kBlock) {
@@ -772,20 +798,8 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
 
     const double2 *zt = s_tab + kofs[2];
     double acc = 0.0, acc0 = 0.0;
-    // A(k) (32 contiguous bytes per task, the bulk of the kernel's memory traffic), ff*W and the task words of a
-    // whole chunk are requested before any of them is used; none of the addresses depends on a load
     for (int t0 = threadIdx.x; t0 < n_tasks; t0 += kBlock * kRecipTaskChunk) {
-        int rj[kRecipTaskChunk];
-        double2 Ap[kRecipTaskChunk], Am[kRecipTaskChunk], w[kRecipTaskChunk];
-#pragma unroll
-        for (int c = 0; c < kRecipTaskChunk; ++c) {
-            const int t = t0 + c * kBlock;
-            const bool in = t < n_tasks;
-            rj[c] = in ? trj[t] : 0;                                   // filler: row 0, j 0, nothing present
-            Ap[c] = in ? A[2 * t] : make_double2(0.0, 0.0);
-            Am[c] = in ? A[2 * t + 1] : make_double2(0.0, 0.0);
-            w[c] = (in && !COMMIT) ? tw[t] : make_double2(0.0, 0.0);
-        }
+        if (!MGPU_RECIP_EARLY_LOAD || t0 != (int)threadIdx.x) load_chunk(t0);
 #pragma unroll
         for (int c = 0; c < kRecipTaskChunk; ++c) {
             const double2 *xy = s_xy + ((rj[c] >> 8) & 0xfffff) * nss;
