@@ -150,6 +150,7 @@ struct mgpu_engine {
     int n_cu = 256;                  // compute units of the device
     int pair_blocks_per_cu = 2;      // resident pair-sweep workgroups per CU (VGPR / LDS bound)
     int pair_nsplit = 1;             // waves per pair-sweep item: an engine constant (see engine_nsplit)
+    std::vector<double> self_of_type; // ComputeEwaldSelfInteractionSingleMol per residue type (host constant)
     bool pair_fuse = true;           // trial moves sweep old + new together (MGPU_PAIR_NO_FUSE=1: tuning / A-B only)
     bool recip_force_per_k = false;  // MGPU_RECIP_PER_K=1: per-k reciprocal kernel even where the row form fits (tests)
     bool defer_commits = false;      // MGPU_DEFER_COMMIT=1: resident-row commits ride in the lane's next k sweep (trial_k_kernel)
@@ -718,6 +719,8 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     HIP_TRY_E(hipMemcpy(e->d_atom_mol, a_mol.data(), ncap * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY_E(hipMemcpy(e->d_atom_q, a_q.data(), ncap * sizeof(double), hipMemcpyHostToDevice));
 #undef HIP_TRY_E
+    e->self_of_type.resize(n_res);
+    for (int t = 0; t < n_res; ++t) e->self_of_type[t] = self_energy_host(e, t);
     *out = e;
     return MGPU_OK;
 }
@@ -1115,7 +1118,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
         if (n1 > site_stride) return set_error(MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res");
         n1_max = std::max(n1_max, n1);
         ln.kinds[c] = k;
-        if (k != MGPU_MOVE) ln.self_of[c] = self_energy_host(e, t[c]);
+        if (k != MGPU_MOVE) ln.self_of[c] = e->self_of_type[t[c]];
         if (k == MGPU_MOVE && fuse) {
             ln.pair_old[c] = 2 * i_fused; ln.pair_new[c] = 2 * i_fused + 1;
             pit[i_fused++] = PairItem{replica[c], t[c], mc, c, 0};
