@@ -44,6 +44,9 @@ extern "C" {
  *   MGPU_PAIR_BLOCKS_PER_CU=<n> resident pair-sweep workgroups per CU (default 2)
  *   MGPU_PAIR_NO_FUSE=1         trial moves as two single-state sweeps instead of one fused old + new sweep
  *   MGPU_RECIP_PER_K=1          per-k reciprocal kernel even where the row form's LDS tables fit
+ *   MGPU_PAIR_EXACT_FOLD=1      always the multiply / round / fma minimum-image fold in the pair sweep (default: the
+ *                               two-instruction fold min(|d|, L - |d|) whenever every atom of the replicas in a launch
+ *                               lies within one box length of the cell centre, which the engine tracks on the host)
  *   MGPU_DEFER_COMMIT=1         a commit from a lane's resident rows is not launched but folded into the lane's
  *                               next trial (one kernel applies it and sweeps k for the new candidates); bitwise the
  *                               same results, measured no faster than the two launches

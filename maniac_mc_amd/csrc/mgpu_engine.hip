@@ -88,6 +88,7 @@ struct Lane {
     int trial_n1_max = 1;
     std::vector<int> pair_old, pair_new, intra_idx, kinds;   // per-candidate rows of the trial in flight
     std::vector<double> self_of;                              // per-candidate Ewald self term (host constant)
+    std::vector<char> cand_ok;                                // per candidate: its sites are within the fast fold's range
     std::vector<double> h_lj, h_cc;                           // pair energies of the trial being collected
     // A commit of the lane's last trial that has been accepted by the host but not launched: the lane's next
     // trial_submit folds it into its k sweep (trial_k_kernel); anything else that needs the engine's state flushes it
@@ -128,6 +129,9 @@ struct mgpu_engine {
     std::vector<int> kx, ky, kz;
     std::vector<double> k2mag, form_factor, weights;
     std::vector<int> h_nmol;  // [R][n_res]
+    // [R][n_res]: 1 while every site ever written for (replica, type) lies within one box length of the cell centre
+    // on every axis -- the condition under which the pair sweep may fold separations with two instructions per axis
+    std::vector<char> in_range;
     double rc = 0, tol = 0, alpha = 0, volume = 0;
     int box_type = 0, kmax[3] = {0, 0, 0}, nk = 0;
     double box_matrix[9]{}, bounds_lo[3]{}, reciprocal[9]{}, metrics[9]{};
@@ -152,6 +156,7 @@ struct mgpu_engine {
     int pair_nsplit = 1;             // waves per pair-sweep item: an engine constant (see engine_nsplit)
     std::vector<double> self_of_type; // ComputeEwaldSelfInteractionSingleMol per residue type (host constant)
     bool pair_fuse = true;           // trial moves sweep old + new together (MGPU_PAIR_NO_FUSE=1: tuning / A-B only)
+    bool pair_fast_fold = true;      // two-instruction minimum-image fold where the atoms' range allows it (MGPU_PAIR_EXACT_FOLD=1: off)
     bool recip_force_per_k = false;  // MGPU_RECIP_PER_K=1: per-k reciprocal kernel even where the row form fits (tests)
     bool defer_commits = false;      // MGPU_DEFER_COMMIT=1: resident-row commits ride in the lane's next k sweep (trial_k_kernel)
     double *d_res_q = nullptr;
@@ -238,6 +243,19 @@ int check_candidate(const mgpu_engine *e, int c, int replica, int t, int m, bool
     return MGPU_OK;
 }
 
+// every coordinate of `n_sites` sites within 0.99 box lengths of the cell centre (orthorhombic axes)
+bool sites_in_range(const mgpu_engine *e, const double *sites, int n_sites) {
+    for (int i = 0; i < n_sites; ++i)
+        for (int d = 0; d < 3; ++d)
+            if (!(std::fabs(sites[3 * (size_t)i + d] - e->bx.ctr[d]) <= 0.99 * e->bx.L[d])) return false;
+    return true;
+}
+bool replica_in_range(const mgpu_engine *e, int replica) {
+    for (int t = 0; t < e->tp.n_res; ++t)
+        if (!e->in_range[(size_t)replica * e->tp.n_res + t]) return false;
+    return true;
+}
+
 // Waves per pair-sweep item.  One wave sweeps every nsplit-th 64-atom unit of the item's replica and the split
 // partials are added in split order, so the last bits of a pair energy depend on nsplit: it is therefore an
 // ENGINE CONSTANT (a function of the topology's capacity only) -- never of how many candidates share a launch
@@ -287,7 +305,7 @@ int upload_sites(mgpu_engine *e, const double *sites, int n_rows, int site_strid
 // inter-kernel gap less per batch; d_lj / d_c are unused).
 int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, int common_n1, int site_stride,
                 int nsplit, double *d_lj, double *d_c, bool ordered = false, double2 *host_partials = nullptr,
-                bool fused = false) {
+                bool fused = false, bool fast_fold = false) {
     const int n_work = n_items * nsplit;
     int rc = MGPU_OK;
     if (fused && (!host_partials || ordered || e->bx.triclinic || common_n1 < 1 || common_n1 > kMaxFusedSites))
@@ -305,11 +323,14 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
     hipExtLaunchKernelGGL((pair_sweep_kernel<NS, ORD, TRI, ##__VA_ARGS__>), dim3(grid), dim3(kPairBlock), e->coul_bytes, ln.stream, \
                           a, b, 0, e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab,     \
                        d_items, (const double *)ln.d_sites.p, site_stride, nsplit, n_work, d_part)
+    // fast_fold: every atom of the replicas involved lies within one box length of the cell centre (tracked on the
+    // host), so the register-site kernels may fold separations with two instructions per axis (image_r2_fast)
+    const bool ff = fast_fold && !ordered && !e->bx.triclinic && e->pair_fast_fold;
     if (fused) {
         switch (common_n1) {
-            case 1: MGPU_LAUNCH_PAIR(1, false, false, true); break;
-            case 2: MGPU_LAUNCH_PAIR(2, false, false, true); break;
-            default: MGPU_LAUNCH_PAIR(3, false, false, true); break;   // kMaxFusedSites (4 sites x 2 states spills)
+            case 1: if (ff) MGPU_LAUNCH_PAIR(1, false, false, true, true); else MGPU_LAUNCH_PAIR(1, false, false, true); break;
+            case 2: if (ff) MGPU_LAUNCH_PAIR(2, false, false, true, true); else MGPU_LAUNCH_PAIR(2, false, false, true); break;
+            default: if (ff) MGPU_LAUNCH_PAIR(3, false, false, true, true); else MGPU_LAUNCH_PAIR(3, false, false, true); break;   // kMaxFusedSites (4 sites x 2 states spills)
         }
     } else if (e->bx.triclinic) {
         if (ordered) MGPU_LAUNCH_PAIR(0, true, true);
@@ -318,10 +339,10 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
         MGPU_LAUNCH_PAIR(0, true, false);
     } else {
         switch (common_n1) {
-            case 1: MGPU_LAUNCH_PAIR(1, false, false); break;
-            case 2: MGPU_LAUNCH_PAIR(2, false, false); break;
-            case 3: MGPU_LAUNCH_PAIR(3, false, false); break;
-            case 4: MGPU_LAUNCH_PAIR(4, false, false); break;
+            case 1: if (ff) MGPU_LAUNCH_PAIR(1, false, false, false, true); else MGPU_LAUNCH_PAIR(1, false, false); break;
+            case 2: if (ff) MGPU_LAUNCH_PAIR(2, false, false, false, true); else MGPU_LAUNCH_PAIR(2, false, false); break;
+            case 3: if (ff) MGPU_LAUNCH_PAIR(3, false, false, false, true); else MGPU_LAUNCH_PAIR(3, false, false); break;
+            case 4: if (ff) MGPU_LAUNCH_PAIR(4, false, false, false, true); else MGPU_LAUNCH_PAIR(4, false, false); break;
             default: MGPU_LAUNCH_PAIR(0, false, false); break;
         }
     }
@@ -559,6 +580,7 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     e->epsilon.assign(epsilon, epsilon + (size_t)n_types * n_types);
     e->sigma.assign(sigma, sigma + (size_t)n_types * n_types);
     e->h_nmol.assign((size_t)n_replicas * n_res, 0);
+    e->in_range.assign((size_t)n_replicas * n_res, 1);
 
     Topo &tp = e->tp;
     tp.n_res = n_res; tp.n_types = n_types; tp.max_atom = max_atom;
@@ -572,11 +594,15 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     }
     tp.n_cap_atoms = off;
     e->pair_fuse = std::getenv("MGPU_PAIR_NO_FUSE") == nullptr;
+    e->pair_fast_fold = std::getenv("MGPU_PAIR_EXACT_FOLD") == nullptr;
     e->recip_force_per_k = std::getenv("MGPU_RECIP_PER_K") != nullptr;
     e->defer_commits = std::getenv("MGPU_DEFER_COMMIT") != nullptr;
 
     BoxDev &bx = e->bx;
-    for (int d = 0; d < 3; ++d) { bx.L[d] = box_matrix[d * 3 + d]; bx.invL[d] = 1.0 / bx.L[d]; bx.kmax[d] = e->kmax[d]; }
+    for (int d = 0; d < 3; ++d) {
+        bx.L[d] = box_matrix[d * 3 + d]; bx.invL[d] = 1.0 / bx.L[d]; bx.kmax[d] = e->kmax[d];
+        bx.ctr[d] = bounds_lo[d] + 0.5 * bx.L[d];
+    }
     std::memcpy(bx.rcp, e->reciprocal, sizeof(double) * 9);
     std::memcpy(bx.m, box_matrix, sizeof(double) * 9);
     bx.triclinic = e->box_type == 3 ? 1 : 0;
@@ -802,6 +828,7 @@ int mgpu_replica_set_molecules(mgpu_engine *e, int replica, int t, int n_mol, co
         HIP_TRY(hipMemcpy(e->d_pos + ((size_t)replica * 3 + d) * tp.n_cap_atoms + tp.seg_off[t], st + d * seg,
                           seg * sizeof(double), hipMemcpyHostToDevice));
     e->h_nmol[replica * tp.n_res + t] = n_mol;
+    e->in_range[(size_t)replica * tp.n_res + t] = sites_in_range(e, sites, n_mol * n1) ? 1 : 0;
     HIP_TRY(hipMemcpy(e->d_nmol + replica * tp.n_res + t, &n_mol, sizeof(int), hipMemcpyHostToDevice));
     return MGPU_OK;
 }
@@ -863,7 +890,10 @@ int mgpu_replica_copy(mgpu_engine *e, int dst, int src) {
                            hipMemcpyDeviceToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->d_A + (size_t)dst * e->n_slots, e->d_A + (size_t)src * e->n_slots, e->n_slots * sizeof(double2),
                            hipMemcpyDeviceToDevice, e->stream));
-    for (int t = 0; t < tp.n_res; ++t) e->h_nmol[dst * tp.n_res + t] = e->h_nmol[src * tp.n_res + t];
+    for (int t = 0; t < tp.n_res; ++t) {
+        e->h_nmol[dst * tp.n_res + t] = e->h_nmol[src * tp.n_res + t];
+        e->in_range[(size_t)dst * tp.n_res + t] = e->in_range[(size_t)src * tp.n_res + t];
+    }
     return sync_stream(e);
 }
 
@@ -977,7 +1007,10 @@ int mgpu_pair_energy_candidates(mgpu_engine *e, int n, const int *replica, const
     if (any_sites && (rc = upload_sites(e, sites, n, site_stride))) return rc;
     double *d_lj = (double *)e->d_out.p, *d_c = d_lj + n;
     const int nsplit = e->pair_nsplit;
-    if ((rc = launch_pair(e, e->lanes[0], (const PairItem *)e->d_items.p, n, common_site_count(e, items), site_stride, nsplit, d_lj, d_c))) return rc;
+    bool fast = true;
+    for (int c = 0; c < n; ++c) fast = fast && replica_in_range(e, replica[c]);
+    if ((rc = launch_pair(e, e->lanes[0], (const PairItem *)e->d_items.p, n, common_site_count(e, items), site_stride, nsplit, d_lj, d_c,
+                          false, nullptr, false, fast))) return rc;
     HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_out.p, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     if ((rc = sync_stream(e))) return rc;
     std::memcpy(e_nc, e->h_out.p, n * sizeof(double));
@@ -1110,6 +1143,8 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     const int n_fused = fuse ? n_moves : 0;
     int i_fused = 0, i_single = 0;
     PairItem *pit_single = pit + n_fused;
+    bool fast = true;                 // all replicas of this trial within the fast fold's range
+    ln.cand_ok.assign(n, 1);          // and per candidate: would committing it keep its replica there
     for (int c = 0; c < n; ++c) {
         const int k = kind ? kind[c] : MGPU_MOVE;
         const int mc = (k == MGPU_CREATION) ? -1 : m[c];
@@ -1118,6 +1153,8 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
         if (n1 > site_stride) return set_error(MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res");
         n1_max = std::max(n1_max, n1);
         ln.kinds[c] = k;
+        fast = fast && replica_in_range(e, replica[c]);
+        if (k != MGPU_DELETION) ln.cand_ok[c] = sites_in_range(e, sites + (size_t)c * site_stride * 3, n1) ? 1 : 0;
         if (k != MGPU_MOVE) ln.self_of[c] = e->self_of_type[t[c]];
         if (k == MGPU_MOVE && fuse) {
             ln.pair_old[c] = 2 * i_fused; ln.pair_new[c] = 2 * i_fused + 1;
@@ -1196,12 +1233,12 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
         ln.deferred.active = false;
     }
     if (n_fused) {
-        if ((rc = launch_pair(e, ln, d_pit, n_fused, common, site_stride, nsplit, nullptr, nullptr, false, d_part, true)))
+        if ((rc = launch_pair(e, ln, d_pit, n_fused, common, site_stride, nsplit, nullptr, nullptr, false, d_part, true, fast)))
             return rc;
     }
     if (n_single) {
         if ((rc = launch_pair(e, ln, d_pit + n_fused, n_single, std::max(common, 0), site_stride, nsplit, nullptr, nullptr, false,
-                              d_part + 2 * (size_t)n_fused * nsplit)))
+                              d_part + 2 * (size_t)n_fused * nsplit, false, fast)))
             return rc;
     }
     if (!fused_k && (rc = launch_recip(e, ln, d_rit, n, n1_max, site_stride, false, e->d_A, d_un, d_uo)))
@@ -1287,6 +1324,7 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
     int n_items = 0;
     std::vector<char> seen(e->n_replicas, 0);
     std::vector<int> new_counts;  // (index into h_nmol, value) pairs applied after validation
+    std::vector<int> range_lost;  // (replica, type) entries whose atoms leave the fast fold's range with this commit
     bool any_sites = false;
     int n1_max = 1;
     for (int c = 0; c < n; ++c) {
@@ -1309,6 +1347,10 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
         if (kind[c] != MGPU_DELETION) {
             any_sites = true;
             it.src = c;
+            // the accepted sites become resident atoms: keep the replica's range flag honest
+            const bool ok = sites ? sites_in_range(e, sites + (size_t)c * site_stride * 3, e->tp.n1[t[c]])
+                                  : (c < (int)ln.cand_ok.size() && ln.cand_ok[c]);
+            if (!ok) range_lost.push_back(idx);
             if (e->tp.n1[t[c]] > site_stride) return set_error(MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res");
         }
         n1_max = std::max(n1_max, e->tp.n1[t[c]]);
@@ -1363,6 +1405,7 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
             return rc;
     }
     for (size_t i = 0; i < new_counts.size(); i += 2) e->h_nmol[new_counts[i]] = new_counts[i + 1];
+    for (int idx : range_lost) e->in_range[idx] = 0;
     return MGPU_OK;
 }
 

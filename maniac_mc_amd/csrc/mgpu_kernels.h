@@ -59,6 +59,7 @@ struct Topo {
 
 struct BoxDev {
     double L[3], invL[3];         // orthorhombic edge lengths box%matrix(d,d)
+    double ctr[3];                // centre of the primary cell (orthorhombic): bounds_lo + L / 2
     double rcp[9];                // box%reciprocal, row-major
     double m[9];                  // box%matrix, row-major (cell vectors are its columns)
     int triclinic;                // box%type == 3: 27-image search instead of the per-axis fold
@@ -126,6 +127,18 @@ __device__ __forceinline__ double image_r2(double dx, double dy, double dz, cons
     }
 }
 
+// Minimum-image r^2 for a raw separation known to satisfy |d| < 1.5 L on every axis (orthorhombic): the folded
+// magnitude is min(|d|, L - |d|) -- two instructions per axis (the negation / absolute value are operand modifiers)
+// instead of multiply, round, fused multiply-add.  Same value as min_image(): for |d| <= L/2 it is |d| itself, beyond
+// it is L - |d|, one rounding of the same real number as fma(-L, +-1, d); L - |d| < 0 (L < |d| < 1.5 L) squares to
+// the right thing.  The engine launches the kernels built with it only when every atom of the replicas involved lies
+// within one box length of the cell centre (it tracks that on the host) and folds the candidate's own sites first.
+__device__ __forceinline__ double image_r2_fast(double dx, double dy, double dz, const BoxDev &bx) {
+    const double ax = fabs(dx), ay = fabs(dy), az = fabs(dz);
+    const double mx = fmin(ax, bx.L[0] - ax), my = fmin(ay, bx.L[1] - ay), mz = fmin(az, bx.L[2] - az);
+    return fma(mz, mz, fma(my, my, mx * mx));
+}
+
 // 1/sqrt(x): v_rsq_f64 (2^-24 relative) + one Newton step with its second-order term; measured
 // max relative error 1.4e-16 on gfx950 (tools/probe_math.hip), the same as ocml's rsqrt.
 __device__ __forceinline__ double fast_rsqrt(double x) {
@@ -181,11 +194,11 @@ __device__ __attribute__((noinline)) double coul_slow(double s, double alpha, bo
 // One site-atom pair: Lennard-Jones inside the cutoff (energy_utils.f90:417-424) and
 // erfc(alpha r)/r for every distance (energy_utils.f90:427-432).  Generic (per-lane flags) form used
 // by the site-major and NS = 0 sweeps; the register-site hot path inlines the same arithmetic.
-template <bool GUARD_R0, bool TRI>
+template <bool GUARD_R0, bool TRI, bool FASTW = false>
 __device__ __forceinline__ void pair_term(double dx, double dy, double dz, const BoxDev &bx, double qq,
                                           double eps4, double sig2, bool do_lj, bool do_c,
                                           const char *__restrict__ coul_tab, double &elj, double &ec) {
-    const double r2 = image_r2<TRI>(dx, dy, dz, bx);
+    const double r2 = FASTW ? image_r2_fast(dx, dy, dz, bx) : image_r2<TRI>(dx, dy, dz, bx);
     if (do_lj) {
         const double s2 = sig2 * fast_rcp(r2);
         const double s6 = s2 * s2 * s2;
@@ -218,13 +231,14 @@ __device__ __forceinline__ void pair_term(double dx, double dy, double dz, const
 // ComputeOldEnergy and ComputeNewEnergy (monte_carlo_utils.f90:380-395 / :275-330); each state's sums are
 // formed exactly as the unfused sweep forms them, and the work unit writes two partials {old, new}.
 // ------------------------------------------------------------------------------------------
-template <int NS, bool ORDERED, bool TRI, bool FUSED = false>
+template <int NS, bool ORDERED, bool TRI, bool FUSED = false, bool FASTW = false>
 __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_kernel(
     Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
     const char *__restrict__ coul_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
     int site_stride, int nsplit, int n_work, double2 *__restrict__ partials) {
     static_assert(!FUSED || (NS > 0 && !ORDERED && !TRI), "the fused old + new sweep is a register-site, unordered, orthorhombic path");
+    static_assert(!FASTW || (NS > 0 && !ORDERED && !TRI), "the two-instruction fold is a register-site, unordered, orthorhombic path");
     constexpr int NTY = NS > 0 ? NS : 1;                  // sites of the molecule (charge / type per site)
     constexpr int NST = FUSED ? 2 : 1;                    // states swept together (old, new)
     constexpr int NREG = NTY * NST;                       // register-resident sites: state-major, [state][site]
@@ -281,6 +295,17 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                 }
                 rq[a] = res_q[it.t * tp.max_atom + a];
                 rty[a] = res_atype[it.t * tp.max_atom + a];
+                if constexpr (FASTW) {
+                    // fold the item's own sites into the cell around its centre (a no-op for sites already there):
+                    // with every atom within one box length of the centre, |separation| < 1.5 L on every axis
+#pragma unroll
+                    for (int st = 0; st < NST; ++st) {
+                        const int k = st * NTY + a;
+                        rx[k] = fma(-bx.L[0], rint((rx[k] - bx.ctr[0]) * bx.invL[0]), rx[k]);     // x - n L: exact no-op for n = 0
+                        ry[k] = fma(-bx.L[1], rint((ry[k] - bx.ctr[1]) * bx.invL[1]), ry[k]);
+                        rz[k] = fma(-bx.L[2], rint((rz[k] - bx.ctr[2]) * bx.invL[2]), rz[k]);
+                    }
+                }
                 // wave-uniform values, but parked in VGPRs: the sweep already needs ~100 SGPRs for box,
                 // pointers and per-plane parameters, and spilled SGPRs cost v_readlane in the hot loop
                 asm volatile("" : "+v"(rx[a]), "+v"(ry[a]), "+v"(rz[a]));
@@ -374,7 +399,8 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                                     bool any_below = false;
 #pragma unroll
                                     for (int s = 0; s < NREG; ++s) {
-                                        r2[s] = image_r2<TRI>(xj - rx[s], yj - ry[s], zj - rz[s], bx);
+                                        r2[s] = FASTW ? image_r2_fast(xj - rx[s], yj - ry[s], zj - rz[s], bx)
+                                                      : image_r2<TRI>(xj - rx[s], yj - ry[s], zj - rz[s], bx);
                                     }
 #pragma unroll
                                     for (int s = 0; s < NREG; ++s) {
@@ -466,7 +492,7 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                             const bool do_c = qj_on && (fabs(qs) >= kErrorTol);
                             if (valid) {
                                 double e1 = 0.0, e2 = 0.0;
-                                pair_term<ORDERED, TRI>(xj - sx, yj - sy, zj - sz, bx, qs * qj, pt.x, pt.y, true, true, s_coul, e1, e2);
+                                pair_term<ORDERED, TRI, FASTW>(xj - sx, yj - sy, zj - sz, bx, qs * qj, pt.x, pt.y, true, true, s_coul, e1, e2);
                                 elj_s += (pt.x != 0.0) ? e1 : 0.0;
                                 ec_s += do_c ? e2 : 0.0;
                             }

@@ -479,3 +479,50 @@ def test_structure_factor_add_primitive(refcpu_mod):
     assert eng.num_molecules(0, 0) == n and np.array_equal(eng.get_molecules(0, 0), s.all_sites(0))
     assert np.max(np.abs(eng.structure_factor(0) - A0)) > 1e-3
     eng.close()
+
+
+def test_fast_fold_range_tracking():
+    """The register-site pair sweeps fold separations with two instructions per axis (min(|d|, L - |d|)), which is
+    the minimum image only while |d| < 1.5 L: the engine folds a candidate's own sites into the cell first and
+    tracks on the host whether every resident atom lies within one box length of the cell centre; replicas that do
+    not take the exact kernels.  Resident atoms and committed candidates moved by whole lattice vectors -- far outside
+    that range -- must therefore change nothing."""
+    s = synth.spce_box(5, seed=12)
+    L = float(s.box_matrix[0, 0])
+    eng = Engine.from_system(s, n_replicas=3)
+    n = int(s.n_mol[0])
+    base = s.all_sites(0)
+    # replica 1: every third molecule moved by lattice vectors of up to three box lengths (out of the fast range)
+    far = base.copy()
+    shift = np.zeros((n, 1, 3))
+    shift[::3, 0, :] = np.array([3 * L, -2 * L, L])
+    shift[1::3, 0, 0] = -3 * L
+    far = far + shift
+    eng.set_molecules(1, 0, far)
+    for r in range(3):
+        eng.init_structure_factor(r, True)
+    rng = np.random.default_rng(4)
+    m = rng.choice(n, 16, replace=False).astype(np.int32)
+    cand = base[m] + rng.uniform(-0.3, 0.3, (16, 1, 3))
+    t0 = np.zeros(16, np.int32)
+    o0, n0 = eng.trial_energy_candidates(np.zeros(16, np.int32), t0, m, cand)
+    o1, n1 = eng.trial_energy_candidates(np.ones(16, np.int32), t0, m, cand)
+    # lattice shifts are exact in the fold but not in the phases: agreement to rounding, far below the parity bar
+    assert np.max(np.abs(o1 - o0)) < 1e-6 and np.max(np.abs(n1 - n0)) < 1e-6
+    # candidates themselves given far away: folded by the kernel
+    o2, n2 = eng.trial_energy_candidates(np.zeros(16, np.int32), t0, m, cand + np.array([2 * L, -L, 4 * L])[None, None, :])
+    assert np.array_equal(o2, o0) and np.max(np.abs(n2 - n0)) < 1e-6
+    # a far candidate COMMITTED on replica 2 makes that replica leave the fast range; later sweeps stay right
+    eng.commit_candidates([2], [0], [m[0]], [MGPU_MOVE], cand[:1] + np.array([3 * L, 0.0, -2 * L])[None, None, :], [1])
+    eng.commit_candidates([0], [0], [m[0]], [MGPU_MOVE], cand[:1], [1])
+    oa, na = eng.trial_energy_candidates(np.zeros(15, np.int32), t0[1:], m[1:], cand[1:])
+    ob, nb = eng.trial_energy_candidates(np.full(15, 2, np.int32), t0[1:], m[1:], cand[1:])
+    assert np.max(np.abs(oa - ob)) < 1e-6 and np.max(np.abs(na - nb)) < 1e-6
+    # mixed batch over in-range and out-of-range replicas in one launch (exact kernels for the whole launch)
+    rep = np.array([0, 1, 2, 0, 1, 2], dtype=np.int32)
+    om, nm_ = eng.trial_energy_candidates(rep, t0[:6], m[1:7], cand[1:7])
+    for c in range(6):
+        ref_o = (oa if rep[c] == 0 else (ob if rep[c] == 2 else None))
+        if ref_o is not None:
+            assert np.max(np.abs(om[c] - ref_o[c])) < 1e-6
+    eng.close()
