@@ -152,7 +152,7 @@ struct mgpu_engine {
     char *d_coul_tab = nullptr;      // Coulomb table rows (build_coulomb_table), staged into LDS by the pair sweep
     size_t coul_bytes = 0;
     int n_cu = 256;                  // compute units of the device
-    int pair_blocks_per_cu = 2;      // resident pair-sweep workgroups per CU (VGPR / LDS bound)
+    int pair_blocks_per_cu = kPairBlock >= 1024 ? 1 : 2;      // resident pair-sweep workgroups per CU (VGPR / LDS bound)
     int pair_nsplit = 1;             // waves per pair-sweep item: an engine constant (see engine_nsplit)
     std::vector<double> self_of_type; // ComputeEwaldSelfInteractionSingleMol per residue type (host constant)
     bool pair_fuse = true;           // trial moves sweep old + new together (MGPU_PAIR_NO_FUSE=1: tuning / A-B only)

@@ -142,7 +142,7 @@ int build_coulomb_table(double alpha, double s_max, std::vector<CoulRow> &rows, 
     const int per_oct = 1 << kCoulM, n_oct = emax - kCoulEmin + 1;
     rows.assign((size_t)n_oct * per_oct + 1, CoulRow{});          // last row stays all zero (clamp target)
     *idx_base = (1023 + kCoulEmin) * per_oct;
-    constexpr int N = 7;
+    constexpr int N = kCoulDeg + 1;           // Chebyshev nodes = coefficients of a row
     const long double pi = 3.14159265358979323846264338327950288L;
     long double node[N], cosjk[N][N];
     for (int k = 0; k < N; ++k) {
@@ -190,7 +190,7 @@ int build_coulomb_table(double alpha, double s_max, std::vector<CoulRow> &rows, 
             const int sh = kCoulM - (kCoulEmin + o);
             for (int i = 0; i < 5; ++i) row.c[i] = (double)ldexpl(tc[i], sh * i);
             row.c5 = (float)ldexpl(tc[5], sh * 5);
-            row.c6 = (float)ldexpl(tc[6], sh * 6);
+            row.c6 = kCoulDeg >= 6 ? (float)ldexpl(tc[kCoulDeg >= 6 ? 6 : 5], sh * 6) : 0.0f;
         }
     return MGPU_OK;
 }
@@ -211,8 +211,8 @@ double coulomb_table_eval_host(const std::vector<CoulRow> &rows, int idx_base, d
     std::memcpy(&a, &ab, 8);
     const double t = s - a;
     const CoulRow &r = rows[row];
-    double p = (double)r.c6;
-    p = std::fma(p, t, (double)r.c5);
+    double p = (double)r.c5;
+    if (kCoulDeg >= 6) p = std::fma((double)r.c6, t, (double)r.c5);
     for (int i = 4; i >= 0; --i) p = std::fma(p, t, r.c[i]);
     return p;
 }

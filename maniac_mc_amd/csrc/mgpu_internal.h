@@ -23,12 +23,22 @@ int ewald_setup(const double metrics[9], double *rc, double *tol, double *alpha,
 int ewald_kvectors(const double rcp[9], double alpha, const int kmax[3], int nk, int *kx, int *ky, int *kz,
                    double *k2mag, double *ff, double *w);
 
-// Coulomb table rows (see build_coulomb_table in mgpu_host_setup.cpp)
-constexpr int kCoulM = 6;        // top mantissa bits used for the row index: 64 rows per octave of r^2
+// Coulomb table rows (see build_coulomb_table in mgpu_host_setup.cpp).  MGPU_COUL_M = top mantissa bits of r^2 used for
+// the row index: 6 -> 64 rows per octave, degree-6 rows (5 fp64 + 2 fp32 coefficients); 7 -> 128 rows per octave, degree-5
+// rows (5 fp64 + 1 fp32): the same truncation error ((2^-6)^7 = (2^-7)^6), one FMA and one conversion fewer per pair
+// term, twice the LDS -- which no longer fits two workgroups per CU, so the pair sweep then runs as one 1024-thread
+// workgroup per CU sharing one table.  Measured on MI355X (4096 evaluations per launch): 7 -> 166-167 us, 6 -> 169-171 us,
+// with a relative error of 2.9e-15 instead of 1.5e-15 for alpha r in [1, 2] (tests/test_coulomb_table.py) and an LDS
+// footprint that grows twice as fast with the box: 2 % is not worth that, 6 stays the default.
+#ifndef MGPU_COUL_M
+#define MGPU_COUL_M 6
+#endif
+constexpr int kCoulM = MGPU_COUL_M;
+constexpr int kCoulDeg = kCoulM == 7 ? 5 : 6;     // polynomial degree of a row
 constexpr int kCoulEmin = -2;    // table starts at r^2 = 2^-2 (r = 0.5 A); below it the slow path runs
 struct CoulRow {
     double c[5];
-    float c5, c6;
+    float c5, c6;                // c6 unused (zero) for degree-5 rows
 };
 static_assert(sizeof(CoulRow) == 48, "CoulRow must be three 16-byte LDS reads");
 int build_coulomb_table(double alpha, double s_max, std::vector<CoulRow> &rows, int *idx_base);

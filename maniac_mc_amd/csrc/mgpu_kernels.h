@@ -36,7 +36,7 @@ constexpr int kBlock = 256;       // threads per workgroup = 4 waves, one per SI
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kSiteChunk = 32;    // candidate sites staged in LDS per pass (generic path)
 #ifndef MGPU_PAIR_BLOCK
-#define MGPU_PAIR_BLOCK 512
+#define MGPU_PAIR_BLOCK (MGPU_COUL_M == 7 ? 1024 : 512)   // 128 rows per octave: one workgroup per CU shares the (larger) table
 #endif
 #ifndef MGPU_PAIR_MINWAVES
 #define MGPU_PAIR_MINWAVES 4   // <= 128 VGPRs: two 8-wave workgroups per CU (measured best, tools/bench_kernels.py)
@@ -173,8 +173,8 @@ __device__ __forceinline__ double coul_lds(double s, const char *__restrict__ ta
     const double2 *r = reinterpret_cast<const double2 *>(tab + __umul24(row, 48));
     const double2 c01 = r[0], c23 = r[1], c4f = r[2];
     const double c5 = (double)__int_as_float(__double2loint(c4f.y));
-    const double c6 = (double)__int_as_float(__double2hiint(c4f.y));
-    double p = fma(c6, t, c5);
+    double p = c5;
+    if constexpr (kCoulDeg >= 6) p = fma((double)__int_as_float(__double2hiint(c4f.y)), t, c5);
     p = fma(p, t, c4f.x);
     p = fma(p, t, c23.y);
     p = fma(p, t, c23.x);
