@@ -411,7 +411,7 @@ def main():
         # fp64 vector peak: every VALU instruction slot counted as one 64-lane FMA (2 flop), i.e. achieved =
         # VALU wave-instructions x 128 / launch time.  The instruction count per launch is the PMC figure
         # (SQ_INSTS_VALU of the same batch shape); the launch time is measured live by the dispatch events.
-        pmc = pmc_summary("pair_sweep_kernel<3, false, false, true>") or pmc_summary("pair_sweep_kernel")
+        pmc = pmc_summary("pair_sweep_kernel<3, false, false, true") or pmc_summary("pair_sweep_kernel")
         pmc_evals = pmc["evals"] if pmc else 2048.0
         scale = evals_per_launch / pmc_evals
         valu_instr = pmc["valu_instr_per_launch"] * scale if pmc and pmc.get("valu_instr_per_launch") else None
@@ -446,7 +446,7 @@ def main():
             "ns_per_dE_eval_note": "wall time per Delta-E evaluation per GPU (pair sweep + k sweep), host loop included",
             "roofline": {"bound": "valu", "bound_note": "fp64 vector issue (the contract's hbm / mfma do not apply: measured HBM-side "
                                                          "traffic is 0.34 x the algorithmic bytes, no MFMA-shaped work; SURVEY 8(d))",
-                         "kernel": "pair_sweep_kernel<3,false,false,true> (old + new state of a trial move in one sweep)",
+                         "kernel": "pair_sweep_kernel<3,false,false,true,true> (old + new state of a trial move in one sweep, two-instruction fold)",
                          "achieved": valu_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": valu_tflops / FP64_VECTOR_PEAK_TFLOPS if valu_tflops else None,
                          "traffic": pmc["hbm_bytes_per_launch"] * scale if pmc and pmc.get("hbm_bytes_per_launch") else None,
