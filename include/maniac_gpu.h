@@ -159,7 +159,12 @@ int mgpu_engine_get_kvectors(const mgpu_engine *e, int *kx, int *ky, int *kz, do
  * Replica state (replaces the module-global primary%mol_com / site_offset / num_residues)
  * ---------------------------------------------------------------------------------------- */
 
-/* Load all molecules of residue type t of one replica.  sites[n_mol][atoms_in_res[t]][3]. */
+/* Load all molecules of residue type t of one replica.  sites[n_mol][atoms_in_res[t]][3].
+ * Coordinates need not lie inside the primary cell (energies use minimum images, as ComputeDistance does).  The engine
+ * notes whether every site it is ever given for a (replica, type) -- here or as a committed candidate -- lies within
+ * 0.99 box lengths of the cell centre on every axis; while that holds for all replicas of a launch (it always does for
+ * molecules whose centres of mass are kept in the cell, as ApplyPBC keeps them) the pair sweep uses a cheaper, bit-identical
+ * form of the minimum-image fold; otherwise it takes the general one.  Results do not depend on which. */
 int mgpu_replica_set_molecules(mgpu_engine *e, int replica, int t, int n_mol, const double *sites);
 int mgpu_replica_get_molecules(mgpu_engine *e, int replica, int t, int *n_mol, double *sites);
 int mgpu_replica_num_molecules(const mgpu_engine *e, int replica, int t, int *n_mol);
