@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Long-run consistency check of the farm at the benchmark size (not part of the test-suite: minutes of GPU time).
+
+    python tools/long_run_check.py [--replicas 512] [--lanes 4] [--steps 4000] [--gcmc]
+After the run every sampled chain's running energies must equal a from-scratch evaluation of its final configuration
+and its A(k) a fresh S(k); prints the worst deviations."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from maniac_mc_amd import synth  # noqa: E402
+from maniac_mc_amd.fortran_host import FortranFarm  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--replicas", type=int, default=512)
+    ap.add_argument("--lanes", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--gcmc", action="store_true", help="CO2 in the 50 A box with insertion / deletion instead of SPC/E NVT")
+    a = ap.parse_args()
+    if a.gcmc:
+        s = synth.co2_box(64, seed=13)
+        V = 50.0 ** 3
+        fug = np.geomspace(20.0, 160.0, 8)[np.arange(a.replicas) % 8] / V
+        farm = FortranFarm(s, a.replicas, seed=5, translation_step=1.0, rotation_step=0.6, n_threads=8, n_lanes=a.lanes,
+                           mol_capacity=[400], gcmc=dict(p_translation=0.25, p_rotation=0.25, fugacity=fug))
+        keys = ("non_coulomb", "coulomb", "recip_coulomb", "ewald_self", "intra_coulomb")
+    else:
+        s = synth.spce_box(15)
+        farm = FortranFarm(s, a.replicas, seed=5, translation_step=0.3, rotation_step=0.3, n_threads=8, n_lanes=a.lanes)
+        keys = ("non_coulomb", "coulomb", "recip_coulomb")
+    t0 = time.perf_counter()
+    acc = farm.run(a.steps)
+    el = time.perf_counter() - t0
+    eng = farm.eng
+    worst_e, worst_a = 0.0, 0.0
+    sample = sorted(set(np.linspace(0, a.replicas - 1, 12).astype(int).tolist()))
+    for r in sample:
+        e = eng.system_energy(r)
+        run = farm.energy(r)
+        worst_e = max(worst_e, max(abs(run[i] - e[k]) for i, k in enumerate(keys)))
+        A = eng.structure_factor(r)
+        eng.init_structure_factor(r, True)
+        worst_a = max(worst_a, float(np.max(np.abs(A - eng.structure_factor(r)))))
+    print(f"{'GCMC CO2' if a.gcmc else 'SPC/E 10125 atoms'}: {a.replicas} chains x {a.steps} steps on {a.lanes} lanes, "
+          f"{farm.trials} trials, {acc} accepted in {el:.1f} s ({acc / el:.3e} accepted/s); over {len(sample)} sampled chains: "
+          f"max |running - recomputed energy| = {worst_e:.3e} K, max |A - S(k)| = {worst_a:.3e}")
+    farm.close()
+    ok = worst_e < 1e-4 and worst_a < 1e-7
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
