@@ -20,6 +20,11 @@ import sys
 import time
 
 ORIG_AFFINITY = os.sched_getaffinity(0)      # before any OpenMP runtime binds this thread to its place
+# nested teams of the Fortran driver's lane-thread mode: in the environment before ANY OpenMP runtime starts
+# (numpy / torch may load one on import)
+os.environ.setdefault("OMP_MAX_ACTIVE_LEVELS", "2")
+os.environ.setdefault("KMP_HOT_TEAMS_MAX_LEVEL", "2")
+os.environ.setdefault("KMP_HOT_TEAMS_MODE", "1")
 
 import numpy as np
 
@@ -32,23 +37,49 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 fp64 lanes x 2 flop x 2.4 GHz (spec)
 FP64_SUSTAINED_TFLOPS = 61.0    # tools/probe_fma.hip on MI355X: what back-to-back v_fma_f64 sustains (clock under load)
-PMC_SUMMARY = os.path.join("profiles", "r02", "pmc_latest.json")
+FLOP_PER_PAIR = 64.0            # ~64 fp64 flops per site-atom pair term incl. erfc (the ALGORITHMIC flop count)
+PMC_DIR = os.path.join("profiles", "r03")
 
 
-def pmc_summary(kernel_substr):
-    """Static figures from the committed rocprofv3 --pmc passes (tools/pmc_passes.sh; PMC cannot be collected
-    from inside this process): HBM-side bytes (FETCH_SIZE doubled per the gfx950 calibration + WRITE_SIZE),
-    VALU instructions and VALU-busy share per launch of tools/bench_kernels.py's batch (1024 trial moves =
-    2048 evaluations per pair-sweep launch, as in the default bench).  None if the summary is absent."""
+def lib_sha256():
+    import hashlib
+    from maniac_mc_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def pmc_summary(workload, kernel_substr):
+    """Static figures from the committed rocprofv3 --pmc passes (tools/pmc_passes.sh; PMC cannot be collected from
+    inside this process): HBM-side bytes (FETCH_SIZE doubled per the gfx950 calibration + WRITE_SIZE), VALU
+    instructions and VALU-busy share of tools/bench_kernels.py's launch group for this workload, summed over the
+    kernels whose name contains `kernel_substr` (a GCMC step launches two pair-sweep instantiations).  The summary
+    names the sha256 of the libmaniac_hip.so it was taken from: if that is not the library loaded now, the
+    counters are STALE and only that fact is returned.  None if there is no summary."""
+    path = os.path.join(PMC_DIR, f"pmc_{workload}.json")
     try:
-        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
+        with open(os.path.join(ROOT, path)) as f:
             d = json.load(f)
-        for name, e in d["kernels"].items():
-            if kernel_substr in name:
-                return dict(e, build=d.get("build"), kernel=name, evals=float(d.get("evaluations_per_pair_launch", 2048)))
     except Exception:
-        pass
-    return None
+        return None
+    out = {"path": path, "build": d.get("build"), "lib_sha256": d.get("lib_sha256"),
+           "evals": float(d.get("evaluations_per_launch_group") or 0.0), "stale": d.get("lib_sha256") != lib_sha256(), "kernels": []}
+    if out["stale"] or not out["evals"]:
+        return out
+    hbm = valu = 0.0
+    busy_w = lds_w = wsum = 0.0
+    for name, e in d["kernels"].items():
+        if kernel_substr not in name:
+            continue
+        out["kernels"].append(name)
+        hbm += e.get("hbm_bytes_per_launch", 0.0)
+        valu += e.get("valu_instr_per_launch", 0.0)
+        w = e.get("avg_us_under_pmc", 0.0)
+        busy_w += w * e.get("valu_busy", 0.0)
+        lds_w += w * e.get("lds_busy", 0.0)
+        wsum += w
+    out.update(hbm_bytes_per_eval=hbm / out["evals"], valu_instr_per_eval=valu / out["evals"],
+               valu_busy=busy_w / wsum if wsum else None, lds_busy=lds_w / wsum if wsum else None, us_under_pmc=wsum)
+    return out
 
 
 def cpu_baseline(system, translation_step, rotation_step, budget_s=15.0, seed=3, all_cores_budget_s=6.0):
@@ -216,47 +247,135 @@ def plan_host_threads(n_threads_req, local_world):
     return max(1, min(8, cores // max(1, local_world)))
 
 
+def cpu_baseline_gcmc(system, t_act, p_move, translation_step, rotation_step, fugacity, budget_s=12.0, seed=3):
+    """Grand-canonical workloads: the reference itself (oracle/_ref, 1 thread; the C restatement if that build is
+    absent) evaluating the same kinds of trial -- translation / rotation with probability p_move, else insertion or
+    deletion 50 / 50 -- one after the other on the workload's INITIAL configuration for a bounded time.  Every trial is
+    evaluated and then undone (the acceptance test is applied for the count only), so the sample stays at the initial
+    molecule count; energies per trial are what ComputeOldEnergy / ComputeNewEnergy compute."""
+    from oracle import reflib, refcpu
+    kind = "reference" if reflib.available() else "port"
+    n = int(system.n_mol[t_act])
+    if kind == "reference":
+        X = reflib.Reference(system)
+    else:
+        X = refcpu.RefCPU(system, mol_capacity=n + 2)
+    e_sys = X.system_energy()
+    X.all_fourier_terms()
+    X.init_amplitude(True)
+    X.set_energy_recip(e_sys["recip_coulomb"])
+    rng = np.random.default_rng(seed)
+    T = system.temperature
+    volume = float(abs(np.linalg.det(system.box_matrix)))
+    L = np.diag(system.box_matrix)
+    tmpl = system.offsets[t_act][0]
+    trials = accepted = evals = 0
+    t0 = time.perf_counter()
+    while True:
+        u = rng.random()
+        if u < p_move:
+            m = int(rng.integers(0, n))
+            com, off = X.get_molecule(t_act, m)
+            X.save_fourier(t_act, m)
+            old = X.old_energy(t_act, m, 0)
+            if rng.random() <= 0.5:
+                X.set_molecule(t_act, m, X.apply_pbc(com + (rng.random(3) - 0.5) * translation_step), off)
+            else:
+                rot = X.rotation_matrix(int(rng.random() * 3) + 1, (rng.random() - 0.5) * rotation_step)
+                X.set_molecule(t_act, m, com, off @ rot.T)
+            new = X.new_energy(t_act, m, 0)
+            prob = min(1.0, np.exp(-(new[5] - old[5]) / T))
+            X.set_molecule(t_act, m, com, off)
+            X.restore_fourier(t_act, m)
+            evals += 2
+        elif rng.random() < 0.5:
+            A0 = X.amplitude()
+            old = X.old_energy(t_act, n, 1)
+            X.set_num_residues(t_act, n + 1)
+            X.save_fourier(t_act, n)
+            rot = X.rotation_matrix(int(rng.random() * 3) + 1, rng.random() * 2 * np.pi)
+            X.set_molecule(t_act, n, system.bounds_lo + L * rng.random(3), tmpl @ rot.T)
+            new = X.new_energy(t_act, n, 1)
+            prob = min(1.0, fugacity * volume / (n + 1) * np.exp(-(new[5] - old[5]) / T))
+            X.set_num_residues(t_act, n)
+            X.set_amplitude(A0)
+            evals += 1
+        else:
+            m = int(rng.integers(0, n))
+            A0 = X.amplitude()
+            old = X.old_energy(t_act, m, 2)
+            X.save_fourier(t_act, m)
+            u_new = X.recip_singlemol(t_act, m, 2)
+            # new%total of a deletion: only the reciprocal term survives (monte_carlo_utils.f90:301-309)
+            prob = min(1.0, n / (fugacity * volume) * np.exp(-(u_new - old[5]) / T))
+            X.set_amplitude(A0)
+            evals += 1
+        trials += 1
+        accepted += rng.random() <= prob
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    return {"value": accepted / el, "unit": "accepted MC moves/s", "cores": 1, "kind": kind,
+            "sample": f"{trials} sequential trials ({evals} Delta-E evaluations; moves with probability {p_move:g}, else "
+                      f"insertion / deletion) on the workload's initial {system.n_atoms}-atom configuration in {el:.1f} s, "
+                      "each evaluated and undone",
+            "trial_moves_per_s": trials / el, "ns_per_dE_eval": el / max(1, evals) * 1e9, "acceptance": accepted / max(1, trials)}
+
+
+WORKLOADS = {
+    # name: default chains per GPU, lanes, what BASELINE.json calls it
+    "spce": dict(replicas=8192, lanes=4, config="metric workload: 10 125-atom SPC/E box (configs[1] recipe at 15^3)"),
+    "co2_gcmc": dict(replicas=2048, lanes=2, config="configs[2]: GCMC of CO2 in a 50 A box, insertion / deletion at one fugacity"),
+    "framework_water": dict(replicas=2048, lanes=2, config="configs[3] stand-in: 2208-atom framework + 4-site water, full move set"),
+    "co2_isotherm": dict(replicas=2048, lanes=2, config="configs[4]: 8 fugacity points dealt over the ranks"),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--replicas", type=int, default=None,
-                    help="independent chains per GPU (default: 8192 for the SPC/E workload, 2048 for the isotherm, whose small "
-                         "boxes are host-bound)")
+                    help="independent chains per GPU (default: 8192 for the SPC/E workload, 2048 for the grand-canonical ones)")
     ap.add_argument("--n-side", type=int, default=15, help="SPC/E lattice side (15 -> 10 125 atoms)")
     ap.add_argument("--host", choices=["fortran", "python"], default="fortran",
-                    help="Metropolis driver: the Fortran farm (mc_farm.f90, two overlapped lanes) or the numpy one")
+                    help="Metropolis driver: the Fortran farm (mc_farm.f90, overlapped lanes) or the numpy one")
     ap.add_argument("--host-threads", type=int, default=0,
                     help="OpenMP threads of the Fortran driver per GPU (0: min(8, cores available / ranks on the node))")
     ap.add_argument("--no-pin", action="store_true", help="do not bind the host threads to the GPU's NUMA node")
     ap.add_argument("--lanes", type=int, default=None,
                     help="submission lanes (chain groups in flight) of the Fortran driver: the host prepares / resolves one "
-                         "group while the GPU evaluates the others (measured: 2048 chains x 2 lanes 5.6 M, 8192 x 4 lanes 6.9 M "
-                         "accepted moves/s; kernels of different lanes overlap, which stretches their individual durations); "
-                         "default 4 (SPC/E) or 2 (isotherm)")
+                         "group while the GPU evaluates the others; default 4 (SPC/E) or 2 (grand-canonical workloads)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of the 1-core reference leg")
     ap.add_argument("--cpu-all-cores-budget", type=float, default=6.0,
-                    help="seconds of the labelled all-core OpenMP leg of the C restatement (0: skip)")
+                    help="seconds of the labelled all-core OpenMP leg of the C restatement (0: skip; SPC/E workload only)")
     ap.add_argument("--settle-s", type=float, default=0.5,
                     help="untimed settle phase after the warm-up steps, seconds of the same step (0: none)")
-    ap.add_argument("--workload", choices=["spce", "co2_isotherm"], default="spce",
-                    help="spce: the 10 125-atom SPC/E box, translation / rotation (BASELINE metric, default); co2_isotherm: "
-                         "configs[4], GCMC of CO2 in a 50 A box, 8 fugacity points dealt over the ranks, per-block gather "
-                         "of the uptake (molecule-count) histogram")
+    ap.add_argument("--sustained-steps", type=int, default=1000,
+                    help="a second, self-timed window of this many steps after the timed region when --steps is smaller "
+                         "(reported as `sustained`; 0: none)")
+    ap.add_argument("--fugacity-n", type=float, default=None,
+                    help="grand-canonical workloads: fugacity as the ideal-gas molecule count f V (default 100 for co2_gcmc, "
+                         "40 for framework_water)")
+    ap.add_argument("--workload", choices=list(WORKLOADS), default="spce",
+                    help="spce: the 10 125-atom SPC/E box, translation / rotation (BASELINE metric, default); co2_gcmc: "
+                         "configs[2]; framework_water: configs[3]; co2_isotherm: configs[4] (8 fugacity points dealt over "
+                         "the ranks, per-block gather of the uptake histogram)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: every rank reports its placement (device, host threads, fugacity points) and "
                          "rank 0 prints the rank-ordered table gathered over the process group")
     ap.add_argument("--dump-counts", default=None, help="directory: every rank writes its chains' final molecule counts (tests)")
     args = ap.parse_args()
 
+    wl = args.workload
     if args.replicas is None:
-        args.replicas = 8192 if args.workload == "spce" else 2048
+        args.replicas = WORKLOADS[wl]["replicas"]
     if args.lanes is None:
-        args.lanes = 4 if args.workload == "spce" else 2
+        args.lanes = WORKLOADS[wl]["lanes"]
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not launched:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
@@ -275,12 +394,12 @@ def main():
         if world > 1:
             import torch.distributed as dist
             dist.init_process_group("gloo" if args.dist_backend != "gloo" else args.dist_backend)
-        pts = isotherm_points_of_rank(rank, world) if args.workload == "co2_isotherm" else []
+        pts = isotherm_points_of_rank(rank, world) if wl == "co2_isotherm" else []
         row = [float(rank), float(local_rank), float(device), float(args.host_threads), float(args.replicas),
                float(len(pts)), float(pts[0] if pts else -1)]
         table, _ = exchange.gather_block_stats(row)
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "workload": args.workload,
+            print(json.dumps({"dry_run": True, "n_gpus": world, "workload": wl,
                               "ranks": [dict(rank=int(r[0]), local_rank=int(r[1]), device=int(r[2]), host_threads=int(r[3]),
                                              replicas=int(r[4]), fugacity_points=int(r[5]), first_point=int(r[6]))
                                         for r in table]}))
@@ -307,29 +426,61 @@ def main():
         from maniac_mc_amd.fortran_host import FortranFarm as Farm
     else:
         from maniac_mc_amd.farm import ReplicaFarm as Farm
+    if wl != "spce" and args.host != "fortran":
+        sys.exit("bench.py: the grand-canonical workloads run on the Fortran farm")
     kw = dict(n_threads=args.host_threads, n_lanes=args.lanes) if args.host == "fortran" else {}
     R = args.replicas
-    iso_pts, fug_grid = None, None
-    if args.workload == "spce":
+    iso_pts, fug_grid, point_of_chain = None, None, None
+    t_act, p_move, fug_one = 0, 1.0, None        # active residue type, share of translation + rotation, the fugacity
+    if wl == "spce":
         system = synth.spce_box(args.n_side)
         t_step, r_step = 0.3, 0.3
+        moves = "50% translation / 50% rotation, 0.3 A / 0.3 rad, 300 K"
         farm = Farm(system, R, device=device, seed=1000 + rank,
                     translation_step=t_step, rotation_step=r_step, p_translation=0.5, **kw)
+    elif wl == "framework_water":
+        # configs[3] stand-in: inactive 2208-atom framework, 4-site water adsorbate, full move set
+        system = synth.framework_water_box()
+        volume = float(np.prod(np.diag(system.box_matrix)))
+        t_act, p_move = 1, 0.5
+        fug_one = (args.fugacity_n if args.fugacity_n else 40.0) / volume
+        t_step, r_step = 0.5, 0.5
+        moves = "25% translation / 25% rotation / 50% insertion-deletion, 0.5 A / 0.5 rad, 300 K"
+        farm = Farm(system, R, device=device, seed=1000 + rank, translation_step=t_step, rotation_step=r_step,
+                    mol_capacity=[1, 256], gcmc=dict(p_translation=0.25, p_rotation=0.25, fugacity=fug_one), **kw)
     else:
-        if args.host != "fortran":
-            sys.exit("bench.py: the isotherm workload runs on the Fortran farm")
-        # configs[2] / [4]: rigid 3-site CO2, empty-ish cubic 50 A box (Nk = 2975), 25 % translation, 25 % rotation,
-        # 50 % insertion / deletion; this rank's chains are split evenly over the fugacity points it holds
+        # configs[2] / [4]: rigid 3-site CO2, empty-ish cubic 50 A box (Nk = 2975)
         system = synth.co2_box(64, seed=13)
         volume = float(np.prod(np.diag(system.box_matrix)))
-        fug_grid = isotherm_fugacities(volume)
-        iso_pts = isotherm_points_of_rank(rank, world)
-        point_of_chain = np.array([iso_pts[(i * len(iso_pts)) // R] for i in range(R)])
         t_step, r_step = 1.0, 0.6
+        if wl == "co2_gcmc":
+            # configs[2]: insertion / deletion only, one fugacity
+            p_move = 0.0
+            fug_one = (args.fugacity_n if args.fugacity_n else 100.0) / volume
+            fug = fug_one
+            moves = "100% insertion / deletion (50 / 50), 300 K"
+        else:
+            # configs[4]: 25 % translation, 25 % rotation, 50 % insertion / deletion; this rank's chains are split evenly
+            # over the fugacity points it holds
+            p_move = 0.5
+            fug_grid = isotherm_fugacities(volume)
+            iso_pts = isotherm_points_of_rank(rank, world)
+            point_of_chain = np.array([iso_pts[(i * len(iso_pts)) // R] for i in range(R)])
+            fug = fug_grid[point_of_chain]
+            moves = "25% translation / 25% rotation / 50% insertion-deletion, 300 K"
         farm = Farm(system, R, device=device, seed=1000 + rank, translation_step=t_step, rotation_step=r_step,
-                    mol_capacity=[400], gcmc=dict(p_translation=0.25, p_rotation=0.25, fugacity=fug_grid[point_of_chain]), **kw)
+                    mol_capacity=[400], gcmc=dict(p_translation=p_move / 2, p_rotation=p_move / 2, fugacity=fug), **kw)
     eng = farm.eng
-    N, Nk = system.n_atoms, eng.nk
+    N0, Nk = system.n_atoms, eng.nk
+    n1 = int(system.topo.atoms_in_res[t_act])
+
+    def evals_done():
+        """Delta-E evaluations so far: a translation / rotation trial costs two (old, new), an insertion or a
+        deletion one"""
+        if not hasattr(farm, "counters"):
+            return 2.0 * farm.trials if hasattr(farm, "trials") else 0.0
+        c = farm.counters()
+        return 2.0 * (c["trial_translations"] + c["trial_rotations"]) + c["trial_creations"] + c["trial_deletions"]
 
     # profiling on BEFORE the warm-up: the first event-carrying dispatch of a stream costs ~7 ms once
     eng.profile_enable(True)
@@ -353,37 +504,61 @@ def main():
 
     fence()
     trials0 = farm.trials if hasattr(farm, "trials") else 0
+    evals0 = evals_done()
     t0 = time.perf_counter()
     accepted = farm.run(args.steps)
     # the path's one real exchange step: per-block all-gather of every rank's counters and
-    # molecule-count histogram (NVT: a single bin per rank, the message size is the same; isotherm: one
-    # histogram of the chains' current N per fugacity point, ISOTHERM_POINTS x 5001 bins)
+    # molecule-count histogram (NVT: a single bin per rank, the message size is the same; grand-canonical: one
+    # histogram of the chains' current N per fugacity point, ISOTHERM_POINTS x 5001 bins for the isotherm)
     nbins = 5001
     trials_now = float(farm.trials - trials0) if hasattr(farm, "trials") else float(args.steps * R)
-    if args.workload == "spce":
+    evals_now = evals_done() - evals0
+    counts = None
+    if wl == "spce":
         hist = exchange.molecule_count_histogram([int(system.n_mol[0])] * R, nbins)
     else:
         counts = farm.counts()[:, 0]
-        hist = np.concatenate([exchange.molecule_count_histogram(counts[point_of_chain == p], nbins)
-                               for p in range(ISOTHERM_POINTS)])
-    sums_by_rank, hist_by_rank = exchange.gather_block_stats([float(accepted), trials_now], hist)
+        if wl == "co2_isotherm":
+            hist = np.concatenate([exchange.molecule_count_histogram(counts[point_of_chain == p], nbins)
+                                   for p in range(ISOTHERM_POINTS)])
+        else:
+            hist = exchange.molecule_count_histogram(counts, nbins)
+    sums_by_rank, hist_by_rank = exchange.gather_block_stats([float(accepted), trials_now, evals_now], hist)
     fence()
     elapsed = exchange.max_over_ranks(time.perf_counter() - t0)
-    tot_acc, tot_trials = float(sums_by_rank[:, 0].sum()), float(sums_by_rank[:, 1].sum())
+    tot_acc, tot_trials, tot_evals = (float(sums_by_rank[:, k].sum()) for k in range(3))
     assert int(hist_by_rank.sum()) == R * world
-    if args.dump_counts and args.workload == "co2_isotherm":
+    if args.dump_counts and wl == "co2_isotherm":
         os.makedirs(args.dump_counts, exist_ok=True)
         np.savez(os.path.join(args.dump_counts, f"rank{rank}.npz"), counts=counts, point_of_chain=point_of_chain)
 
     n_pair, ms_pair = eng.profile_get(_lib.KERNEL_PAIR)
     n_rec, ms_rec = eng.profile_get(_lib.KERNEL_RECIP)
     n_com, ms_com = eng.profile_get(_lib.KERNEL_COMMIT)
+    timers1 = farm.timers() if hasattr(farm, "timers") else None
 
-    # The same pair-sweep batch launched alone (outside the timed region, rank 0): with several lanes in
-    # flight the kernels of different lanes share the CUs, which raises throughput but stretches every
-    # kernel's own duration; this gives the kernel's un-shared time for comparison.
+    # A second, self-timed window when the timed region is a short sample (the driver's --steps 20 is ~17 ms):
+    # the same step for --sustained-steps more steps, same fences, reported beside the headline figure.
+    sustained = None
+    if args.sustained_steps > args.steps:
+        fence()
+        ts0 = time.perf_counter()
+        acc_s = farm.run(args.sustained_steps)
+        acc_s = float(exchange.gather_block_stats([float(acc_s)], hist)[0][:, 0].sum())
+        fence()
+        el_s = exchange.max_over_ranks(time.perf_counter() - ts0)
+        sustained = {"steps": args.sustained_steps, "value": acc_s / el_s, "unit": "accepted MC moves/s",
+                     "ms_per_step": el_s / args.sustained_steps * 1e3, "timed_region_s": el_s,
+                     "note": "second self-timed window after the headline region (same step, same fences)"}
+    elif args.sustained_steps > 0:
+        sustained = {"steps": args.steps, "value": tot_acc / elapsed, "unit": "accepted MC moves/s",
+                     "ms_per_step": elapsed / args.steps * 1e3, "timed_region_s": elapsed, "note": "the timed region itself"}
+
+    # The dominant kernel's batch launched alone (outside the timed region, rank 0): with several lanes in flight
+    # the kernels of different lanes share the CUs, which raises throughput but stretches every kernel's own
+    # duration; this gives the kernel's un-shared time for comparison.
     iso_us = None
-    if rank == 0 and args.host == "fortran" and args.workload == "spce":
+    if rank == 0 and args.host == "fortran" and wl == "spce":
         rng = np.random.default_rng(5)
         n_l = max(1, R // farm.n_lanes)
         m_iso = rng.integers(0, int(system.n_mol[0]), n_l).astype(np.int32)
@@ -396,114 +571,136 @@ def main():
     eng.profile_enable(False)
 
     if rank == 0:
-        # algorithmic bytes per Delta-E evaluation: 36 N + 52 Nk; the pair sweep owns
-        # the 36 N part (x, y, z, q fp64 + int32 type per atom), the k sweep the 52 Nk part.
-        bytes_pair_eval = 36.0 * N
-        bytes_eval = 36.0 * N + 52.0 * Nk
-        # the Fortran driver splits the replicas over the engine's lanes: each launch carries one group
         n_lanes = farm.n_lanes if args.host == "fortran" else 1
-        evals_per_launch = (2 * R) / n_lanes
-        avg_pair_s = ms_pair / max(1, n_pair) * 1e-3
-        alg_gbs = bytes_pair_eval * evals_per_launch / avg_pair_s / 1e9 if n_pair else 0.0
-        evals_total = 2.0 * tot_trials
-        # The pair sweep is bound by fp64 VALU issue, not by HBM (its measured memory-side traffic is a third of the
-        # algorithmic bytes and it sits at ~80 % VALU-busy), so the headline fraction is VALU work against the
-        # fp64 vector peak: every VALU instruction slot counted as one 64-lane FMA (2 flop), i.e. achieved =
-        # VALU wave-instructions x 128 / launch time.  The instruction count per launch is the PMC figure
-        # (SQ_INSTS_VALU of the same batch shape); the launch time is measured live by the dispatch events.
-        pmc = pmc_summary("pair_sweep_kernel<3, false, false, true") or pmc_summary("pair_sweep_kernel")
-        pmc_evals = pmc["evals"] if pmc else 2048.0
-        scale = evals_per_launch / pmc_evals
-        valu_instr = pmc["valu_instr_per_launch"] * scale if pmc and pmc.get("valu_instr_per_launch") else None
-        # (a) per launch, in the pipeline: with several lanes in flight the kernels of different lanes share the
-        #     device, so a launch's begin-to-end time includes waiting for CUs -- what rocprofv3 reports too;
-        # (b) job level: the pair sweep's VALU work of ALL launches of the timed region over the region's wall time
-        #     (every other kernel, every gap and the host's share included) -- the headline `achieved` / `frac`;
-        # (c) isolated: the same batch launched alone after the timed region (the kernel's own efficiency).
-        launch_tflops = valu_instr * 128.0 / avg_pair_s / 1e12 if (valu_instr and n_pair) else None
-        valu_tflops = valu_instr * 128.0 * n_pair / elapsed / 1e12 if (valu_instr and n_pair) else None
-        iso = None
-        if iso_us:
-            iso = {"avg_launch_us": iso_us,
-                   "achieved": valu_instr * 128.0 / (iso_us * 1e-6) / 1e12 if valu_instr else None,
-                   "frac": valu_instr * 128.0 / (iso_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if valu_instr else None,
-                   "algorithmic_hbm_GBs": bytes_pair_eval * evals_per_launch / (iso_us * 1e-6) / 1e9,
-                   "note": "same batch launched alone after the timed region; in the timed region the kernels of "
-                           "the lanes overlap on the device"}
+        evals_rank = evals_now                                   # this rank's evaluations in the timed region
+        # mean atom count of this rank's chains now (the grand-canonical boxes fill / drain during the run)
+        n_act_mean = float(np.mean(counts)) if counts is not None else float(system.n_mol[t_act])
+        N = N0 + (n_act_mean - float(system.n_mol[t_act])) * n1
+        # ---- algorithmic work per Delta-E evaluation: 36 N + 52 Nk bytes; 64 flop per site-atom pair
+        bytes_pair_eval, bytes_k_eval = 36.0 * N, 52.0 * Nk
+        flop_eval = FLOP_PER_PAIR * n1 * max(0.0, N - n1)
+        us = lambda ms, n: ms / max(1, n) * 1e3
+        kernels = {"pair_sweep": {"launches": n_pair, "avg_launch_us": us(ms_pair, n_pair), "total_ms": ms_pair},
+                   "k_sweep": {"launches": n_rec, "avg_launch_us": us(ms_rec, n_rec), "total_ms": ms_rec},
+                   "commit": {"launches": n_com, "avg_launch_us": us(ms_com, n_com), "total_ms": ms_com}}
+        ms_all = ms_pair + ms_rec + ms_com
+        for k in kernels.values():
+            k["share_of_kernel_time"] = k["total_ms"] / ms_all if ms_all else None
+        k_launches = max(1, n_rec)
+        evals_per_k_launch = evals_rank / k_launches             # one k sweep per lane step covers every candidate of it
+        pair_dominant = wl in ("spce", "framework_water")
+        if pair_dominant:
+            # Pair sweep: bound by fp64 vector issue, not by HBM (measured HBM-side traffic is a fraction of the
+            # algorithmic bytes).  achieved = ALGORITHMIC flops (64 per site-atom pair term) over time.
+            pmc = pmc_summary(wl, "pair_sweep_kernel")
+            fresh = bool(pmc) and not pmc["stale"] and pmc.get("valu_instr_per_eval") is not None
+            job_tflops = evals_rank * flop_eval / elapsed / 1e12
+            launch_tflops = evals_rank * flop_eval / (ms_pair * 1e-3) / 1e12 if ms_pair else None
+            roof = {"bound": "valu", "bound_note": "fp64 vector issue (the contract's hbm / mfma do not apply: measured HBM-side "
+                                                   "traffic is a fraction of the algorithmic bytes and there is no MFMA-shaped work; SURVEY 8(d))",
+                    "kernel": "pair_sweep_kernel (trial moves: old + new state in one sweep; insertions / deletions: one state)",
+                    "achieved": job_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": job_tflops / FP64_VECTOR_PEAK_TFLOPS,
+                    "achieved_basis": f"ALGORITHMIC flops: {FLOP_PER_PAIR:g} per site-atom pair term x {n1} sites x (N - {n1}) atoms = "
+                                      f"{flop_eval / 1e6:.3f} MFLOP per evaluation (SURVEY 8(d)), N = {N:.0f} (mean over the chains); "
+                                      "job level: all evaluations of the timed region / timed_region_s (every other kernel, every gap "
+                                      "and the host's share included)",
+                    "flop_per_evaluation": flop_eval, "evaluations": evals_rank,
+                    "per_launch": {"achieved": launch_tflops, "frac": launch_tflops / FP64_VECTOR_PEAK_TFLOPS if launch_tflops else None,
+                                   "avg_launch_us": us(ms_pair, n_pair), "launches": n_pair,
+                                   "note": "same flops over the SUM of the pair-sweep launches' begin-to-end times (dispatch events in the "
+                                           f"timed region, what rocprofv3 --kernel-trace shows): with {n_lanes} lanes in flight a launch's "
+                                           "time includes waiting for CUs held by the other lanes' kernels"},
+                    "traffic": pmc["hbm_bytes_per_eval"] * evals_rank / max(1, n_pair) if fresh else None,
+                    "traffic_per_evaluation": pmc["hbm_bytes_per_eval"] if fresh else None,
+                    "traffic_source": (f"static: {pmc['path']} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, build {pmc['build']}, "
+                                       f"libmaniac_hip.so sha256 {pmc['lib_sha256'][:16]} = the library loaded now; per evaluation x "
+                                       "this run's evaluations per launch)") if fresh else
+                                      ("STALE: " + pmc["path"] + " was taken from another build of libmaniac_hip.so" if pmc else "none"),
+                    "valu_issue": {"instr_per_evaluation": pmc["valu_instr_per_eval"], "valu_busy": pmc["valu_busy"], "lds_busy": pmc["lds_busy"],
+                                   "issue_slots_frac_of_peak": pmc["valu_instr_per_eval"] * evals_rank * 128.0 / elapsed / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                   "note": "VALU wave-instructions (SQ_INSTS_VALU, static PMC) x 128 flop-slots / timed_region_s / fp64 vector "
+                                           "peak: issue-slot utilisation (integer, compare and conversion instructions count as slots), "
+                                           "not a flop rate"} if fresh else None,
+                    "hbm": {"algorithmic_bytes_per_evaluation": bytes_pair_eval,
+                            "algorithmic_equivalent_GBs": bytes_pair_eval * evals_rank / (ms_pair * 1e-3) / 1e9 if ms_pair else None,
+                            "peak": HBM_PEAK_GBS,
+                            "note": "36 N bytes per evaluation (SURVEY 8(d)) / pair-sweep time: an algorithmic figure served mostly from "
+                                    "L2 / Infinity Cache, NOT an HBM utilisation"}}
+            if iso_us:
+                ev_l = 2.0 * max(1, R // n_lanes)
+                roof["isolated"] = {"avg_launch_us": iso_us, "achieved": ev_l * flop_eval / (iso_us * 1e-6) / 1e12,
+                                    "frac": ev_l * flop_eval / (iso_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                    "note": "one lane's batch launched alone after the timed region (the kernel's own efficiency)"}
+        else:
+            # k sweep: one pass over A(k) per candidate, HBM-bound: 52 Nk algorithmic bytes per evaluation
+            pmc = pmc_summary(wl if wl != "co2_isotherm" else "co2_gcmc", "recip_rows_kernel<false")
+            fresh = bool(pmc) and not pmc["stale"] and pmc.get("hbm_bytes_per_eval") is not None
+            gbs = bytes_k_eval * evals_rank / (ms_rec * 1e-3) / 1e9 if ms_rec else None
+            roof = {"bound": "hbm", "kernel": "recip_rows_kernel<false,true> (k sweep: old and new reciprocal energy of every candidate from one pass over A(k))",
+                    "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS if gbs else None,
+                    "achieved_basis": f"ALGORITHMIC bytes: 52 Nk = {bytes_k_eval:.0f} B per evaluation (SURVEY 8(d)) x "
+                                      f"{evals_per_k_launch:.0f} evaluations per launch / the k sweep's average launch time (dispatch events "
+                                      "in the timed region)",
+                    "avg_launch_us": us(ms_rec, n_rec), "launches": n_rec, "evaluations_per_launch": evals_per_k_launch,
+                    "traffic": pmc["hbm_bytes_per_eval"] * evals_per_k_launch if fresh else None,
+                    "traffic_per_evaluation": pmc["hbm_bytes_per_eval"] if fresh else None,
+                    "traffic_source": (f"static: {pmc['path']} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, build {pmc['build']}, "
+                                       f"libmaniac_hip.so sha256 {pmc['lib_sha256'][:16]} = the library loaded now; per evaluation x "
+                                       "this run's evaluations per launch)") if fresh else
+                                      ("STALE: " + pmc["path"] + " was taken from another build of libmaniac_hip.so" if pmc else "none"),
+                    "job_frac": evals_rank * (bytes_pair_eval + bytes_k_eval) / elapsed / 1e9 / HBM_PEAK_GBS,
+                    "job_frac_note": "all evaluations x (36 N + 52 Nk) algorithmic bytes / timed_region_s / HBM peak"}
+        roof["kernels"] = kernels
         out = {
             "metric": "MC moves/sec", "value": tot_acc / elapsed, "unit": "accepted MC moves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "settle_steps": settle_steps, "timed_region_s": elapsed,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"spce_{system.n_mol[0]}mol_{N}atoms_lj_cut_coul_long_ewald_Nk{Nk}",
+            "config": {"workload": {"spce": f"spce_{system.n_mol[0]}mol_{N0}atoms_lj_cut_coul_long_ewald_Nk{Nk}",
+                                    "co2_gcmc": f"co2_gcmc_50A_box_Nk{Nk}_fV{fug_one * volume:g}" if fug_one else None,
+                                    "framework_water": f"framework2208_water4site_gcmc_Nk{Nk}_fV{fug_one * volume:g}" if fug_one else None,
+                                    "co2_isotherm": f"co2_isotherm_{ISOTHERM_POINTS}fugacities_50A_box_Nk{Nk}"}[wl],
+                       "baseline_config": WORKLOADS[wl]["config"],
                        "replicas_per_gpu": R, "host_driver": args.host, "host_threads": args.host_threads if args.host == "fortran" else 1,
-                       "lanes": farm.n_lanes if args.host == "fortran" else 1, "host_cores": pinned, "moves": "50% translation / 50% rotation, 0.3 A / 0.3 rad, 300 K",
-                       "trials_per_step": R * world, "dE_evals_per_step": 2 * R * world, "parallelism": f"replicas x{world}"},
+                       "lanes": n_lanes, "host_cores": pinned, "moves": moves,
+                       "trials_per_step": R * world, "parallelism": f"replicas x{world}"},
             "trial_moves_per_s": tot_trials / elapsed,
             "acceptance": tot_acc / max(1.0, tot_trials),
-            "ns_per_dE_eval": elapsed / evals_total * 1e9 * world,
+            "dE_evals_per_s": tot_evals / elapsed,
+            "ns_per_dE_eval": elapsed / max(1.0, tot_evals) * 1e9 * world,
             "ns_per_dE_eval_note": "wall time per Delta-E evaluation per GPU (pair sweep + k sweep), host loop included",
-            "roofline": {"bound": "valu", "bound_note": "fp64 vector issue (the contract's hbm / mfma do not apply: measured HBM-side "
-                                                         "traffic is 0.34 x the algorithmic bytes, no MFMA-shaped work; SURVEY 8(d))",
-                         "kernel": "pair_sweep_kernel<3,false,false,true,true> (old + new state of a trial move in one sweep, two-instruction fold)",
-                         "achieved": valu_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": valu_tflops / FP64_VECTOR_PEAK_TFLOPS if valu_tflops else None,
-                         "traffic": pmc["hbm_bytes_per_launch"] * scale if pmc and pmc.get("hbm_bytes_per_launch") else None,
-                         "traffic_source": f"static: {PMC_SUMMARY} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch, build "
-                                           f"{pmc.get('build') if pmc else None}; not a measurement of this run)",
-                         "frac_basis": "job level: VALU instruction slots of all pair-sweep launches of the timed region (x 128 flop) / "
-                                       "timed_region_s / fp64 vector peak; per_launch and isolated give the other two views",
-                         "avg_launch_us": avg_pair_s * 1e6, "launches": n_pair, "evaluations_per_launch": evals_per_launch,
-                         "per_launch": {"avg_launch_us": avg_pair_s * 1e6, "achieved": launch_tflops,
-                                        "frac": launch_tflops / FP64_VECTOR_PEAK_TFLOPS if launch_tflops else None,
-                                        "note": "dispatch events in the timed region (what rocprofv3 --kernel-trace shows): with "
-                                                f"{n_lanes} lanes in flight a launch's begin-to-end time includes waiting for CUs "
-                                                "held by the other lanes' kernels"},
-                         "valu": {"instr_per_launch": valu_instr, "valu_busy": pmc.get("valu_busy") if pmc else None,
-                                  "lds_busy": pmc.get("lds_busy") if pmc else None,
-                                  "frac_of_sustained_fma_rate": valu_tflops / FP64_SUSTAINED_TFLOPS if valu_tflops else None,
-                                  "sustained_peak": FP64_SUSTAINED_TFLOPS,
-                                  "source": f"static: {PMC_SUMMARY} (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x busy cycles)); "
-                                            "sustained peak from tools/probe_fma.hip"},
-                         "hbm": {"algorithmic_bytes_per_launch": bytes_pair_eval * evals_per_launch,
-                                 "algorithmic_equivalent_GBs": alg_gbs, "peak": HBM_PEAK_GBS,
-                                 "algorithmic_frac": alg_gbs / HBM_PEAK_GBS,
-                                 "note": "36 N bytes per evaluation (SURVEY 8(d)) / launch time: an algorithmic figure served mostly "
-                                         "from L2 / Infinity Cache, NOT an HBM utilisation"},
-                         "isolated": iso,
-                         "job_frac": (evals_total / world / elapsed) * bytes_eval / 1e9 / HBM_PEAK_GBS,
-                         "recip_avg_launch_us": ms_rec / max(1, n_rec) * 1e3, "commit_avg_launch_us": ms_com / max(1, n_com) * 1e3},
+            "roofline": roof,
         }
-        if args.workload == "co2_isotherm":
+        if sustained:
+            out["sustained"] = sustained
+        if counts is not None:
+            out["molecules_per_chain"] = {"mean": float(np.mean(counts)), "min": int(np.min(counts)), "max": int(np.max(counts)),
+                                          "initial": int(system.n_mol[t_act]), "atoms_mean": N}
+        if wl == "co2_isotherm":
             # configs[4]: GCMC isotherm.  Trials are move SELECTIONS that reach the engine (no-op selections of the
-            # reference -- empty type, full type -- are skipped by the host); an insertion / deletion costs ONE
-            # evaluation, so the SPC/E roofline figures do not carry over: report the launch times only.
+            # reference -- empty type, full type -- are skipped by the host)
             hist_pts = hist_by_rank.reshape(world, ISOTHERM_POINTS, nbins).sum(axis=0)
             nn = np.arange(nbins)
-            out["config"] = {"workload": f"co2_isotherm_{ISOTHERM_POINTS}fugacities_50A_box_Nk{Nk}", "replicas_per_gpu": R,
-                             "host_driver": args.host, "host_threads": args.host_threads, "lanes": farm.n_lanes,
-                             "host_cores": pinned, "moves": "25% translation / 25% rotation / 50% insertion-deletion, 300 K",
-                             "parallelism": f"replicas x{world}; fugacity points dealt round-robin over the ranks"}
+            out["config"]["parallelism"] = f"replicas x{world}; fugacity points dealt round-robin over the ranks"
             out["isotherm"] = [{"fugacity_molecules_per_A3": float(fug_grid[p]), "chains": int(hist_pts[p].sum()),
                                 "mean_N": float((hist_pts[p] * nn).sum() / max(1, hist_pts[p].sum())),
                                 "N_min": int(nn[hist_pts[p] > 0].min()) if hist_pts[p].sum() else None,
                                 "N_max": int(nn[hist_pts[p] > 0].max()) if hist_pts[p].sum() else None}
                                for p in range(ISOTHERM_POINTS)]
+        if wl != "spce":
             out["exchange"] = {"collective": "all_gather", "backend": args.dist_backend if world > 1 else None,
-                               "bytes_per_rank": int(hist.nbytes + 16), "per": "block (= the timed region)"}
-            out["roofline"] = {"bound": "valu", "kernel": "pair_sweep_kernel (fused old + new for moves, single state for insertions / deletions)",
-                               "achieved": None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
-                               "avg_launch_us": avg_pair_s * 1e6, "launches": n_pair,
-                               "recip_avg_launch_us": ms_rec / max(1, n_rec) * 1e3, "commit_avg_launch_us": ms_com / max(1, n_com) * 1e3,
-                               "note": "not the BASELINE metric's workload: launch times only"}
-            for k in ("ns_per_dE_eval", "ns_per_dE_eval_note"):
-                out.pop(k, None)
-        if hasattr(farm, "timers"):
-            out["host_seconds"] = {k: v - timers0[k] for k, v in farm.timers().items()}   # timed region only
-        if world == 1 and not args.no_cpu_baseline and args.workload == "spce":
-            out["cpu_baseline"] = cpu_baseline(system, t_step, r_step, budget_s=args.cpu_budget,
-                                                all_cores_budget_s=args.cpu_all_cores_budget)
+                               "bytes_per_rank": int(hist.nbytes + 24), "per": "block (= the timed region)"}
+        if timers0 is not None:
+            out["host_seconds"] = {k: v - timers0[k] for k, v in timers1.items()}   # timed region only
+        if world == 1 and not args.no_cpu_baseline:
+            if wl == "spce":
+                out["cpu_baseline"] = cpu_baseline(system, t_step, r_step, budget_s=args.cpu_budget,
+                                                    all_cores_budget_s=args.cpu_all_cores_budget)
+            else:
+                f_cpu = fug_one if fug_one is not None else float(fug_grid[ISOTHERM_POINTS // 2])
+                out["cpu_baseline"] = cpu_baseline_gcmc(system, t_act, p_move, t_step, r_step, f_cpu, budget_s=args.cpu_budget)
         print(json.dumps(out))
     farm.close()
     if dist is not None:

@@ -80,6 +80,7 @@ struct Lane {
     std::vector<hipEvent_t> ev_pool;
     ProfileSlot prof[MGPU_KERNEL_COUNT];
     int n_submitted = 0;          // candidates of the trial in flight (0 = none)
+    bool dirty = false;           // something was queued on the stream since its last synchronise (asynchronous entry points)
     int last_trial_n = 0, last_trial_stride = 0;   // shape of the site rows still resident in d_sites
     int n_pair_items = 0, n_split = 1;   // reduced pair-energy entries of the trial in flight (2 per fused item + 1 per single)
     int n_fused = 0;                      // of which the first 2 * n_fused belong to fused (old + new) items
@@ -215,6 +216,7 @@ int prof_collect(mgpu_engine *e, Lane &ln) {
 
 int sync_lane(mgpu_engine *e, Lane &ln) {
     HIP_TRY(hipStreamSynchronize(ln.stream));
+    ln.dirty = false;
     return prof_collect(e, ln);
 }
 int sync_stream(mgpu_engine *e) { return sync_lane(e, e->lanes[0]); }
@@ -224,8 +226,11 @@ int sync_stream(mgpu_engine *e) { return sync_lane(e, e->lanes[0]); }
 int flush_all_deferred(mgpu_engine *e);
 int sync_all_lanes(mgpu_engine *e) {
     if (int rc = flush_all_deferred(e)) return rc;
+    // lane 0 doubles as the synchronous path's stream (those entry points synchronise it themselves before they
+    // return); the other lanes only carry work queued by the asynchronous entry points, which mark them dirty
     for (auto &ln : e->lanes)
-        if (int rc = sync_lane(e, ln)) return rc;
+        if (&ln == &e->lanes[0] || ln.dirty || !ln.pending.empty())
+            if (int rc = sync_lane(e, ln)) return rc;
     return MGPU_OK;
 }
 
@@ -243,11 +248,14 @@ int check_candidate(const mgpu_engine *e, int c, int replica, int t, int m, bool
     return MGPU_OK;
 }
 
-// every coordinate of `n_sites` sites within 0.99 box lengths of the cell centre (orthorhombic axes)
+// every coordinate of `n_sites` sites within kFastFoldRange box lengths of the cell centre (orthorhombic axes): two
+// such sites are less than 1.5 L apart on every axis, the fast fold's precondition.  Molecules whose centre of mass is
+// wrapped into the cell (ApplyPBC) qualify as long as their radius stays below a quarter of the box.
+constexpr double kFastFoldRange = 0.745;
 bool sites_in_range(const mgpu_engine *e, const double *sites, int n_sites) {
     for (int i = 0; i < n_sites; ++i)
         for (int d = 0; d < 3; ++d)
-            if (!(std::fabs(sites[3 * (size_t)i + d] - e->bx.ctr[d]) <= 0.99 * e->bx.L[d])) return false;
+            if (!(std::fabs(sites[3 * (size_t)i + d] - e->bx.ctr[d]) <= kFastFoldRange * e->bx.L[d])) return false;
     return true;
 }
 bool replica_in_range(const mgpu_engine *e, int replica) {
@@ -436,6 +444,7 @@ int launch_deferred(mgpu_engine *e, Lane &ln, const AcceptBits &bits) {
 int flush_deferred(mgpu_engine *e, Lane &ln) {
     if (!ln.deferred.active) return MGPU_OK;
     ln.deferred.active = false;
+    ln.dirty = true;
     return launch_deferred(e, ln, ln.deferred.bits);
 }
 int flush_all_deferred(mgpu_engine *e) {
@@ -871,6 +880,8 @@ int mgpu_replica_set_num_molecules(mgpu_engine *e, int replica, int t, int n_mol
     if (n_mol < 0 || n_mol > e->tp.cap[t]) return set_error(MGPU_ERR_CAPACITY, "n_mol exceeds mol_capacity");
     if ((rc = use_device(e))) return rc;
     if ((rc = sync_all_lanes(e))) return rc;
+    // a larger count exposes slots the range flag was never computed for (zero-filled, or stale coordinates)
+    if (n_mol > e->h_nmol[replica * e->tp.n_res + t]) e->in_range[(size_t)replica * e->tp.n_res + t] = 0;
     e->h_nmol[replica * e->tp.n_res + t] = n_mol;
     HIP_TRY(hipMemcpy(e->d_nmol + replica * e->tp.n_res + t, &n_mol, sizeof(int), hipMemcpyHostToDevice));
     return MGPU_OK;
@@ -987,7 +998,7 @@ int mgpu_pair_energy_candidates(mgpu_engine *e, int n, const int *replica, const
     if (n < 0 || !replica || !t || !m || !e_nc || !e_c) return set_error(MGPU_ERR_INVALID_ARG, "pair_energy_candidates: bad argument");
     int rc = use_device(e);
     if (rc) return rc;
-    if ((rc = flush_all_deferred(e))) return rc;
+    if ((rc = sync_all_lanes(e))) return rc;
     std::vector<PairItem> items(n);
     bool any_sites = false;
     for (int c = 0; c < n; ++c) {
@@ -1008,7 +1019,11 @@ int mgpu_pair_energy_candidates(mgpu_engine *e, int n, const int *replica, const
     double *d_lj = (double *)e->d_out.p, *d_c = d_lj + n;
     const int nsplit = e->pair_nsplit;
     bool fast = true;
-    for (int c = 0; c < n; ++c) fast = fast && replica_in_range(e, replica[c]);
+    for (int c = 0; c < n && fast; ++c) {
+        fast = replica_in_range(e, replica[c]);
+        if (fast && !(use_resident && use_resident[c]))
+            fast = sites_in_range(e, sites + (size_t)c * site_stride * 3, e->tp.n1[t[c]]);
+    }
     if ((rc = launch_pair(e, e->lanes[0], (const PairItem *)e->d_items.p, n, common_site_count(e, items), site_stride, nsplit, d_lj, d_c,
                           false, nullptr, false, fast))) return rc;
     HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_out.p, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -1025,7 +1040,7 @@ int mgpu_recip_energy_candidates(mgpu_engine *e, int n, const int *replica, cons
     if (n < 0 || !replica || !t || !m || !kind || !u) return set_error(MGPU_ERR_INVALID_ARG, "recip_energy_candidates: bad argument");
     int rc = use_device(e);
     if (rc) return rc;
-    if ((rc = flush_all_deferred(e))) return rc;
+    if ((rc = sync_all_lanes(e))) return rc;
     std::vector<RecipItem> items(n);
     bool any_sites = false;
     int n1_max = 1;
@@ -1069,7 +1084,7 @@ int mgpu_intra_energy_candidates(mgpu_engine *e, int n, const int *replica, cons
     if (n < 0 || !replica || !t || !m || !u) return set_error(MGPU_ERR_INVALID_ARG, "intra_energy_candidates: bad argument");
     int rc = use_device(e);
     if (rc) return rc;
-    if ((rc = flush_all_deferred(e))) return rc;
+    if ((rc = sync_all_lanes(e))) return rc;
     std::vector<PairItem> items(n);
     bool any_sites = false;
     for (int c = 0; c < n; ++c) {
@@ -1109,6 +1124,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
                              const int *kind, const double *sites, int site_stride) {
     if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "trial_submit: the lane still holds an un-waited trial");
     int rc;
+    ln.dirty = true;
     // from here on the rows of the lane's previous trial are gone (the staging block below may be regrown and is
     // overwritten): a failed submit must not leave them committable "from the lane's resident rows"
     ln.last_trial_n = 0;
@@ -1154,7 +1170,10 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
         n1_max = std::max(n1_max, n1);
         ln.kinds[c] = k;
         fast = fast && replica_in_range(e, replica[c]);
-        if (k != MGPU_DELETION) ln.cand_ok[c] = sites_in_range(e, sites + (size_t)c * site_stride * 3, n1) ? 1 : 0;
+        if (k != MGPU_DELETION) {
+            ln.cand_ok[c] = sites_in_range(e, sites + (size_t)c * site_stride * 3, n1) ? 1 : 0;
+            fast = fast && ln.cand_ok[c];          // the candidate's own sites are swept in this launch
+        }
         if (k != MGPU_MOVE) ln.self_of[c] = e->self_of_type[t[c]];
         if (k == MGPU_MOVE && fuse) {
             ln.pair_old[c] = 2 * i_fused; ln.pair_new[c] = 2 * i_fused + 1;
@@ -1313,6 +1332,7 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
     int rc;
     const size_t site_bytes = sites ? (size_t)n * site_stride * 3 * sizeof(double) : 0;
     if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "commit_submit: wait for the lane's trial first");
+    ln.dirty = true;
     if ((rc = flush_deferred(e, ln))) return rc;
     // the pinned staging block may still feed the H2D copy of the lane's previous commit
     if (ln.commit_staged) {
@@ -1469,7 +1489,7 @@ int mgpu_trial_energy_candidates(mgpu_engine *e, int n, const int *replica, cons
         return set_error(MGPU_ERR_INVALID_ARG, "trial_energy_candidates: bad argument");
     int rc = use_device(e);
     if (rc) return rc;
-    if ((rc = flush_all_deferred(e))) return rc;
+    if ((rc = sync_all_lanes(e))) return rc;
     if ((rc = trial_submit_impl(e, e->lanes[0], n, replica, t, m, nullptr, sites, site_stride))) return rc;
     return trial_wait_impl(e, e->lanes[0], old_energy, new_energy, 3);
 }
@@ -1481,7 +1501,7 @@ int mgpu_commit_candidates(mgpu_engine *e, int n, const int *replica, const int 
     if (n < 0 || !replica || !t || !m || !kind || !accept) return set_error(MGPU_ERR_INVALID_ARG, "commit_candidates: bad argument");
     int rc = use_device(e);
     if (rc) return rc;
-    if ((rc = flush_all_deferred(e))) return rc;
+    if ((rc = sync_all_lanes(e))) return rc;
     if ((rc = commit_submit_impl(e, e->lanes[0], n, replica, t, m, kind, sites, site_stride, accept))) return rc;
     return sync_stream(e);
 }

@@ -129,10 +129,13 @@ __device__ __forceinline__ double image_r2(double dx, double dy, double dz, cons
 
 // Minimum-image r^2 for a raw separation known to satisfy |d| < 1.5 L on every axis (orthorhombic): the folded
 // magnitude is min(|d|, L - |d|) -- two instructions per axis (the negation / absolute value are operand modifiers)
-// instead of multiply, round, fused multiply-add.  Same value as min_image(): for |d| <= L/2 it is |d| itself, beyond
-// it is L - |d|, one rounding of the same real number as fma(-L, +-1, d); L - |d| < 0 (L < |d| < 1.5 L) squares to
-// the right thing.  The engine launches the kernels built with it only when every atom of the replicas involved lies
-// within one box length of the cell centre (it tracks that on the host) and folds the candidate's own sites first.
+// instead of multiply, round, fused multiply-add.  Same value as min_image() applied to the SAME raw separation d:
+// for |d| <= L/2 it is |d| itself, beyond it is L - |d|, one rounding of the same real number as fma(-L, +-1, d);
+// L - |d| < 0 (L < |d| < 1.5 L) squares to the right thing.  (Only a separation within one rounding of exactly L/2 can
+// come out as the other of two equally near images: |d'| differs by an ulp of L there.)  The engine launches the
+// kernels built with it only when every resident atom of the replicas involved AND every candidate site of the launch
+// lies within kFastFoldRange box lengths of the cell centre on every axis (it tracks that on the host), so that any
+// two of them are less than 1.5 L apart; nothing is refolded, so both kernel families see the same d.
 __device__ __forceinline__ double image_r2_fast(double dx, double dy, double dz, const BoxDev &bx) {
     const double ax = fabs(dx), ay = fabs(dy), az = fabs(dz);
     const double mx = fmin(ax, bx.L[0] - ax), my = fmin(ay, bx.L[1] - ay), mz = fmin(az, bx.L[2] - az);
@@ -295,17 +298,6 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                 }
                 rq[a] = res_q[it.t * tp.max_atom + a];
                 rty[a] = res_atype[it.t * tp.max_atom + a];
-                if constexpr (FASTW) {
-                    // fold the item's own sites into the cell around its centre (a no-op for sites already there):
-                    // with every atom within one box length of the centre, |separation| < 1.5 L on every axis
-#pragma unroll
-                    for (int st = 0; st < NST; ++st) {
-                        const int k = st * NTY + a;
-                        rx[k] = fma(-bx.L[0], rint((rx[k] - bx.ctr[0]) * bx.invL[0]), rx[k]);     // x - n L: exact no-op for n = 0
-                        ry[k] = fma(-bx.L[1], rint((ry[k] - bx.ctr[1]) * bx.invL[1]), ry[k]);
-                        rz[k] = fma(-bx.L[2], rint((rz[k] - bx.ctr[2]) * bx.invL[2]), rz[k]);
-                    }
-                }
                 // wave-uniform values, but parked in VGPRs: the sweep already needs ~100 SGPRs for box,
                 // pointers and per-plane parameters, and spilled SGPRs cost v_readlane in the hot loop
                 asm volatile("" : "+v"(rx[a]), "+v"(ry[a]), "+v"(rz[a]));

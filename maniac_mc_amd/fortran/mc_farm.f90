@@ -153,16 +153,22 @@ contains
     subroutine seed_farm_rng(seed, n_chains)
         integer, intent(in) :: seed, n_chains
         integer :: n, i
-        integer(c_int) :: rc
         integer, allocatable :: s(:)
         call random_seed(size=n)
         allocate(s(n))
         s = seed + 37 * [(i - 1, i = 1, n)]
         call random_seed(put=s)
+        call seed_chain_streams(seed, n_chains)
+    end subroutine seed_farm_rng
+
+    ! the chains' own xoshiro256+ states only (the intrinsic generator is left alone)
+    subroutine seed_chain_streams(seed, n_chains)
+        integer, intent(in) :: seed, n_chains
+        integer(c_int) :: rc
         if (allocated(F%cxs)) deallocate(F%cxs)
         allocate(F%cxs(4, n_chains))
         rc = mgpu_rng_seed_streams(int(seed, c_long_long), int(n_chains, c_int), F%cxs)
-    end subroutine seed_farm_rng
+    end subroutine seed_chain_streams
 
     ! NRAND uniform numbers in [0, 1) from chain r's generator: top 53 bits of (s1 + s4) mod 2^64.  The sum is
     ! formed without relying on signed overflow: q = floor((s1 + s4) / 4) from the operands' upper 62 bits plus the
@@ -825,7 +831,8 @@ contains
     end subroutine mfarm_recalibrate
 
     ! Test hook: seed n_chains generators as mfarm_create would and return the first n_per numbers of each stream,
-    ! u(n_per, n_chains) (does not touch a live farm's generators).
+    ! u(n_per, n_chains).  A live farm's chain generators are set aside and put back, and the intrinsic generator
+    ! (rng_kind 0, the reference's stream) is not reseeded.
     subroutine mfarm_rng_sample(seed, n_chains, n_per, u) bind(C, name="mfarm_rng_sample")
         integer(c_int), value :: seed, n_chains, n_per
         real(c_double), intent(out) :: u(n_per, n_chains)
@@ -833,7 +840,7 @@ contains
         real(real64) :: v(NRAND)
         integer :: r, k, got
         if (allocated(F%cxs)) call move_alloc(F%cxs, keep)
-        call seed_farm_rng(int(seed), int(n_chains))
+        call seed_chain_streams(int(seed), int(n_chains))
         do r = 1, n_chains
             got = 0
             do while (got < n_per)

@@ -55,7 +55,7 @@ def test_isotherm_two_gloo_ranks_on_one_gpu_histogram_matches_rank_counts(tmp_pa
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
     out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--workload", "co2_isotherm",
                           "--replicas", "64", "--steps", "120", "--warmup", "10", "--settle-s", "0", "--device", "0",
-                          "--no-pin", "--host-threads", "2", "--dump-counts", str(tmp_path)],
+                          "--no-pin", "--host-threads", "2", "--sustained-steps", "0", "--dump-counts", str(tmp_path)],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     d = _last_json(out.stdout)

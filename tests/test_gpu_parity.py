@@ -483,10 +483,10 @@ def test_structure_factor_add_primitive(refcpu_mod):
 
 def test_fast_fold_range_tracking():
     """The register-site pair sweeps fold separations with two instructions per axis (min(|d|, L - |d|)), which is
-    the minimum image only while |d| < 1.5 L: the engine folds a candidate's own sites into the cell first and
-    tracks on the host whether every resident atom lies within one box length of the cell centre; replicas that do
-    not take the exact kernels.  Resident atoms and committed candidates moved by whole lattice vectors -- far outside
-    that range -- must therefore change nothing."""
+    the minimum image only while |d| < 1.5 L: the engine tracks on the host whether every resident atom and every
+    candidate site of a launch lies within 0.745 box lengths of the cell centre; launches that do not qualify take
+    the exact kernels.  Resident atoms and candidates moved by whole lattice vectors -- far outside that range -- must
+    therefore change nothing."""
     s = synth.spce_box(5, seed=12)
     L = float(s.box_matrix[0, 0])
     eng = Engine.from_system(s, n_replicas=3)
@@ -509,7 +509,8 @@ def test_fast_fold_range_tracking():
     o1, n1 = eng.trial_energy_candidates(np.ones(16, np.int32), t0, m, cand)
     # lattice shifts are exact in the fold but not in the phases: agreement to rounding, far below the parity bar
     assert np.max(np.abs(o1 - o0)) < 1e-6 and np.max(np.abs(n1 - n0)) < 1e-6
-    # candidates themselves given far away: folded by the kernel
+    # candidates themselves given far away: the launch takes the exact kernels, whose old-state sums are bit for bit
+    # those of the fast-fold launch above
     o2, n2 = eng.trial_energy_candidates(np.zeros(16, np.int32), t0, m, cand + np.array([2 * L, -L, 4 * L])[None, None, :])
     assert np.array_equal(o2, o0) and np.max(np.abs(n2 - n0)) < 1e-6
     # a far candidate COMMITTED on replica 2 makes that replica leave the fast range; later sweeps stay right
@@ -526,3 +527,67 @@ def test_fast_fold_range_tracking():
         if ref_o is not None:
             assert np.max(np.abs(om[c] - ref_o[c])) < 1e-6
     eng.close()
+
+
+def test_fast_fold_is_bitwise_the_exact_fold():
+    """The two-instruction fold and the round-based fold are applied to the same raw separation, so the kernels built
+    with either must return identical bits -- for molecules whose sites straddle the cell faces (H atoms of SPC/E
+    molecules whose centre of mass sits within 1 A of a wall lie OUTSIDE the primary cell) as for any other.  Two
+    engines on the same configuration, one created with MGPU_PAIR_EXACT_FOLD=1 (read at engine creation): trial moves
+    (fused old + new sweep), single-state sweeps (insertion / deletion / resident), committed moves, all array_equal."""
+    import os
+    s = synth.spce_box(6, seed=21)
+    L = float(s.box_matrix[0, 0])
+    # push a third of the molecules against the walls: centre of mass within 0.6 A of a face on a random axis
+    rng = np.random.default_rng(8)
+    n = int(s.n_mol[0])
+    com = s.com[0].copy()
+    for i in range(0, n, 3):
+        ax = int(rng.integers(0, 3))
+        com[i, ax] = (1 if rng.random() < 0.5 else -1) * (L / 2 - rng.uniform(0.0, 0.6)) + float(s.bounds_lo[ax] + L / 2)
+    s.com[0][:] = com
+    sites_all = s.all_sites(0)
+    lo, hi = s.bounds_lo, s.bounds_lo + L
+    outside = np.any((sites_all < lo) | (sites_all > hi), axis=(1, 2))
+    assert outside.sum() >= n // 6, "the test needs molecules straddling the cell faces"
+    engines = []
+    for exact in (False, True):
+        if exact:
+            os.environ["MGPU_PAIR_EXACT_FOLD"] = "1"
+        try:
+            e = Engine.from_system(s, n_replicas=2)
+        finally:
+            os.environ.pop("MGPU_PAIR_EXACT_FOLD", None)
+        for r in range(2):
+            e.init_structure_factor(r, True)
+        engines.append(e)
+    fast, exact = engines
+    m = np.concatenate([np.flatnonzero(outside)[:12], rng.choice(n, 12, replace=False)]).astype(np.int32)
+    k = m.shape[0]
+    # candidates: translated across the nearest wall and wrapped like ApplyPBC (centre of mass back in the cell)
+    cand = sites_all[m] + rng.uniform(-0.9, 0.9, (k, 1, 3))
+    c_com = com[m] + (cand[:, 0] - sites_all[m][:, 0])
+    wrap = lo + np.mod(c_com - lo, L) - c_com
+    cand = cand + wrap[:, None, :]
+    rep = (np.arange(k) % 2).astype(np.int32)
+    t0 = np.zeros(k, np.int32)
+    of, nf = fast.trial_energy_candidates(rep, t0, m, cand)
+    oe, ne = exact.trial_energy_candidates(rep, t0, m, cand)
+    assert np.array_equal(of, oe) and np.array_equal(nf, ne)
+    for use_res in (None, np.zeros(k, np.int32)):
+        a_f = fast.pair_energy_candidates(rep, t0, m, None if use_res is None else cand, use_res)
+        a_e = exact.pair_energy_candidates(rep, t0, m, None if use_res is None else cand, use_res)
+        assert np.array_equal(a_f[0], a_e[0]) and np.array_equal(a_f[1], a_e[1])
+    kinds = np.where(np.arange(k) % 3 == 0, MGPU_CREATION, np.where(np.arange(k) % 3 == 1, MGPU_DELETION, MGPU_MOVE)).astype(np.int32)
+    gf = fast.gcmc_trial(rep, t0, m, kinds, cand)
+    ge = exact.gcmc_trial(rep, t0, m, kinds, cand)
+    assert np.array_equal(gf[0], ge[0]) and np.array_equal(gf[1], ge[1])
+    # commit two straddling candidates on both engines and sweep again
+    acc = np.zeros(k, np.int32); acc[:2] = 1
+    for e in engines:
+        e.commit_candidates(rep, t0, m, np.zeros(k, np.int32), cand, acc)
+    of, nf = fast.trial_energy_candidates(rep[2:], t0[2:], m[2:], cand[2:])
+    oe, ne = exact.trial_energy_candidates(rep[2:], t0[2:], m[2:], cand[2:])
+    assert np.array_equal(of, oe) and np.array_equal(nf, ne)
+    for e in engines:
+        e.close()
