@@ -244,7 +244,10 @@ def plan_host_threads(n_threads_req, local_world):
     cores = usable_cores()
     if n_threads_req > 0:
         return n_threads_req
-    return max(1, min(8, cores // max(1, local_world)))
+    # six threads per GPU: measured round 3 on the 16-CPU boxes (SPC/E: 4 / 6 / 8 threads 7.40 / 7.40 / 7.35 M accepted moves/s,
+    # GPU-bound; CO2 GCMC 8192 x 4 lanes: 2 / 4 / 6 / 8 / 12 / 16 threads 7.8 / 9.3 / 10.5 / 6.6 / 7.3 / 6.7 M -- beyond six the
+    # regions' fork / join and the threads' spinning cost more than the extra threads bring)
+    return max(1, min(6, cores // max(1, local_world)))
 
 
 def cpu_baseline_gcmc(system, t_act, p_move, translation_step, rotation_step, fugacity, budget_s=12.0, seed=3):
@@ -325,9 +328,12 @@ def cpu_baseline_gcmc(system, t_act, p_move, translation_step, rotation_step, fu
 WORKLOADS = {
     # name: default chains per GPU, lanes, what BASELINE.json calls it
     "spce": dict(replicas=8192, lanes=4, config="metric workload: 10 125-atom SPC/E box (configs[1] recipe at 15^3)"),
-    "co2_gcmc": dict(replicas=2048, lanes=2, config="configs[2]: GCMC of CO2 in a 50 A box, insertion / deletion at one fugacity"),
-    "framework_water": dict(replicas=2048, lanes=2, config="configs[3] stand-in: 2208-atom framework + 4-site water, full move set"),
-    "co2_isotherm": dict(replicas=2048, lanes=2, config="configs[4]: 8 fugacity points dealt over the ranks"),
+    # the grand-canonical boxes are small (a few hundred atoms): per lane step the fixed host costs (OpenMP regions, HIP calls)
+    # weigh as much as the kernels, so they run MANY chains on TWO lanes (measured round 3, co2_gcmc: 2048 x 2 5.4 M,
+    # 8192 x 4 6.6 M, 8192 x 2 11.2 M, 16384 x 2 13.7 M accepted moves/s)
+    "co2_gcmc": dict(replicas=16384, lanes=2, config="configs[2]: GCMC of CO2 in a 50 A box, insertion / deletion at one fugacity"),
+    "framework_water": dict(replicas=8192, lanes=2, config="configs[3] stand-in: 2208-atom framework + 4-site water, full move set"),
+    "co2_isotherm": dict(replicas=16384, lanes=2, config="configs[4]: 8 fugacity points dealt over the ranks"),
 }
 
 
@@ -337,12 +343,12 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--replicas", type=int, default=None,
-                    help="independent chains per GPU (default: 8192 for the SPC/E workload, 2048 for the grand-canonical ones)")
+                    help="independent chains per GPU (default: 8192 for the SPC/E and framework workloads, 16384 for the CO2 ones)")
     ap.add_argument("--n-side", type=int, default=15, help="SPC/E lattice side (15 -> 10 125 atoms)")
     ap.add_argument("--host", choices=["fortran", "python"], default="fortran",
                     help="Metropolis driver: the Fortran farm (mc_farm.f90, overlapped lanes) or the numpy one")
     ap.add_argument("--host-threads", type=int, default=0,
-                    help="OpenMP threads of the Fortran driver per GPU (0: min(8, cores available / ranks on the node))")
+                    help="OpenMP threads of the Fortran driver per GPU (0: min(6, cores available / ranks on the node))")
     ap.add_argument("--no-pin", action="store_true", help="do not bind the host threads to the GPU's NUMA node")
     ap.add_argument("--lanes", type=int, default=None,
                     help="submission lanes (chain groups in flight) of the Fortran driver: the host prepares / resolves one "

@@ -157,11 +157,24 @@ struct mgpu_engine {
     int pair_nsplit = 1;             // waves per pair-sweep item: an engine constant (see engine_nsplit)
     std::vector<double> self_of_type; // ComputeEwaldSelfInteractionSingleMol per residue type (host constant)
     bool pair_fuse = true;           // trial moves sweep old + new together (MGPU_PAIR_NO_FUSE=1: tuning / A-B only)
+    int pair_fuse_max = kMaxFusedSites;   // largest molecule whose trial moves are fused (MGPU_PAIR_FUSE_MAX: up to kMaxFusedSitesWide)
     bool pair_fast_fold = true;      // two-instruction minimum-image fold where the atoms' range allows it (MGPU_PAIR_EXACT_FOLD=1: off)
     bool recip_force_per_k = false;  // MGPU_RECIP_PER_K=1: per-k reciprocal kernel even where the row form fits (tests)
     bool defer_commits = false;      // MGPU_DEFER_COMMIT=1: resident-row commits ride in the lane's next k sweep (trial_k_kernel)
     double *d_res_q = nullptr;
     int *d_res_atype = nullptr;
+    // frozen residues (inactive, n1 >= 64): site_perm[t][a] = position of the caller's site a in the engine's
+    // atom-type-sorted order (identity for every other residue type); d_grp_tab = their group records
+    std::vector<std::vector<int>> site_perm;
+    std::vector<char> frozen;        // [n_res]
+    bool any_frozen = false;
+    int4 *d_grp_tab = nullptr;
+    int *d_atom_ty = nullptr;        // [Ncap] 0-based atom type of every slot (pair_flat_kernel fetches it per lane)
+    // Register-site sweeps of this engine go through pair_flat_kernel (one software-pipelined loop over all units of
+    // a work unit) instead of the plane-by-plane pair_sweep_kernel: chosen at creation for topologies with short planes
+    // (every plane-major residue type has at most kFlatMaxCap molecule slots) or a frozen residue; MGPU_PAIR_FLAT=0 / 1
+    // overrides (tuning / A-B).  Orthorhombic boxes only; a site-major ACTIVE residue (n1 >= 64) keeps the other kernel.
+    bool pair_flat = false;
     int *d_atom_res = nullptr, *d_atom_mol = nullptr;
     double *d_atom_q = nullptr;
     double2 *d_phase_tab = nullptr;  // [ktot][Ncap] scratch for S(k)
@@ -293,6 +306,27 @@ int engine_nsplit(const mgpu_engine *e) {
     return ns;
 }
 
+// Candidate rows of a frozen residue type (an inactive framework given as an explicit candidate: rare) are handed over
+// in the caller's site order and live on the device in the engine's atom-type-sorted order: permute such rows in place.
+void permute_frozen_rows(const mgpu_engine *e, double *rows, int n_rows, int site_stride, const int *t) {
+    std::vector<double> tmp;
+    for (int c = 0; c < n_rows; ++c) {
+        if (t[c] < 0 || t[c] >= e->tp.n_res || !e->frozen[t[c]]) continue;
+        const int n1 = e->tp.n1[t[c]];
+        if (n1 > site_stride) continue;                       // the caller reports the error
+        double *r = rows + (size_t)c * site_stride * 3;
+        tmp.assign(r, r + (size_t)n1 * 3);
+        const int *perm = e->site_perm[t[c]].data();
+        for (int a = 0; a < n1; ++a)
+            for (int d = 0; d < 3; ++d) r[(size_t)perm[a] * 3 + d] = tmp[(size_t)a * 3 + d];
+    }
+}
+bool any_frozen(const mgpu_engine *e, int n, const int *t) {
+    for (int c = 0; c < n; ++c)
+        if (t[c] >= 0 && t[c] < e->tp.n_res && e->frozen[t[c]]) return true;
+    return false;
+}
+
 int upload_sites(Lane &ln, const double *sites, int n_rows, int site_stride) {
     if (!sites || n_rows == 0) return MGPU_OK;
     ln.last_trial_n = 0;
@@ -302,8 +336,31 @@ int upload_sites(Lane &ln, const double *sites, int n_rows, int site_stride) {
     HIP_TRY(hipMemcpyAsync(ln.d_sites.p, sites, bytes, hipMemcpyHostToDevice, ln.stream));
     return MGPU_OK;
 }
-int upload_sites(mgpu_engine *e, const double *sites, int n_rows, int site_stride) {
+// synchronous entry points: rows go straight from the caller's memory unless a frozen residue type is among them
+int upload_sites(mgpu_engine *e, const double *sites, int n_rows, int site_stride, const int *t) {
+    if (sites && n_rows > 0 && any_frozen(e, n_rows, t)) {
+        const size_t bytes = (size_t)n_rows * site_stride * 3 * sizeof(double);
+        int rc = e->h_stage.reserve(bytes);
+        if (rc) return rc;
+        std::memcpy(e->h_stage.p, sites, bytes);
+        permute_frozen_rows(e, (double *)e->h_stage.p, n_rows, site_stride, t);
+        if ((rc = upload_sites(e->lanes[0], (const double *)e->h_stage.p, n_rows, site_stride))) return rc;
+        HIP_TRY(hipStreamSynchronize(e->lanes[0].stream));   // h_stage is reused by other entry points
+        return MGPU_OK;
+    }
     return upload_sites(e->lanes[0], sites, n_rows, site_stride);
+}
+
+// resident workgroups per CU of a pair-sweep instantiation (asked of the runtime once per instantiation)
+template <auto Kernel>
+int resident_blocks(size_t dyn_lds) {
+    static int nb = 0;
+    if (nb == 0) {
+        int v = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, Kernel, kPairBlock, dyn_lds) != hipSuccess || v < 1) v = 1;
+        nb = std::min(v, 4);
+    }
+    return nb;
 }
 
 // launch the pair sweep + finalize for items already on the device; results land in d_lj / d_c.
@@ -316,13 +373,13 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
                 bool fused = false, bool fast_fold = false) {
     const int n_work = n_items * nsplit;
     int rc = MGPU_OK;
-    if (fused && (!host_partials || ordered || e->bx.triclinic || common_n1 < 1 || common_n1 > kMaxFusedSites))
+    if (fused && (!host_partials || ordered || e->bx.triclinic || common_n1 < 1 || common_n1 > e->pair_fuse_max))
         return set_error(MGPU_ERR_STATE, "launch_pair: fused sweep needs register sites, an orthorhombic box and a partials buffer");
     if (!host_partials && (rc = ln.d_partials.reserve((size_t)n_work * sizeof(double2)))) return rc;
     double2 *d_part = host_partials ? host_partials : (double2 *)ln.d_partials.p;
     // persistent waves: 2 workgroups of 8 waves per CU (VGPRs: 4 waves per SIMD at <= 128), never more
     // workgroups than there is work for
-    const int per_cu = e->pair_blocks_per_cu;
+    const int per_cu = (fused && common_n1 > kMaxFusedSites) ? 1 : e->pair_blocks_per_cu;
     const int grid = std::max(1, std::min((n_work + kPairWaves - 1) / kPairWaves, e->n_cu * per_cu));
     hipEvent_t a = nullptr, b = nullptr;
     rc = prof_begin(e, ln, MGPU_KERNEL_PAIR, &a, &b);
@@ -334,11 +391,54 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
     // fast_fold: every atom of the replicas involved lies within one box length of the cell centre (tracked on the
     // host), so the register-site kernels may fold separations with two instructions per axis (image_r2_fast)
     const bool ff = fast_fold && !ordered && !e->bx.triclinic && e->pair_fast_fold;
-    if (fused) {
+    // fz: the topology has a frozen residue (inactive framework, sites sorted by atom type): the register-site kernels
+    // built with the per-lane-charge plane sweep
+    const bool fz = e->any_frozen;
+#define MGPU_PAIR_FF_FZ(NS, FU)                                                                   \
+    do {                                                                                          \
+        if (ff && fz) MGPU_LAUNCH_PAIR(NS, false, false, FU, true, true);                         \
+        else if (ff) MGPU_LAUNCH_PAIR(NS, false, false, FU, true, false);                         \
+        else if (fz) MGPU_LAUNCH_PAIR(NS, false, false, FU, false, true);                         \
+        else MGPU_LAUNCH_PAIR(NS, false, false, FU, false, false);                                \
+    } while (0)
+    // the flat kernels are latency-bound: as many workgroups per CU as their registers and the LDS table allow
+#define MGPU_LAUNCH_FLAT_1(NS, FU, FW)                                                                                  \
+    do {                                                                                                               \
+        const int nb = resident_blocks<&pair_flat_kernel<NS, FU, FW>>(e->coul_bytes);                                  \
+        const int grid_f = std::max(1, std::min((n_work + kPairWaves - 1) / kPairWaves, e->n_cu * nb));               \
+        hipExtLaunchKernelGGL((pair_flat_kernel<NS, FU, FW>), dim3(grid_f), dim3(kPairBlock), e->coul_bytes, ln.stream, a, b, 0, \
+                              e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab,   \
+                              d_items, (const double *)ln.d_sites.p, site_stride, nsplit, n_work, d_part);                   \
+    } while (0)
+#define MGPU_LAUNCH_FLAT(NS, FU)                                                                                        \
+    do {                                                                                                               \
+        if (ff) MGPU_LAUNCH_FLAT_1(NS, FU, true);                                                                      \
+        else MGPU_LAUNCH_FLAT_1(NS, FU, false);                                                                        \
+    } while (0)
+    const bool flat = e->pair_flat && !ordered && !e->bx.triclinic && common_n1 >= 1 && common_n1 <= kMaxFusedSitesWide;
+    if (flat && fused) {
         switch (common_n1) {
-            case 1: if (ff) MGPU_LAUNCH_PAIR(1, false, false, true, true); else MGPU_LAUNCH_PAIR(1, false, false, true); break;
-            case 2: if (ff) MGPU_LAUNCH_PAIR(2, false, false, true, true); else MGPU_LAUNCH_PAIR(2, false, false, true); break;
-            default: if (ff) MGPU_LAUNCH_PAIR(3, false, false, true, true); else MGPU_LAUNCH_PAIR(3, false, false, true); break;   // kMaxFusedSites (4 sites x 2 states spills)
+            case 1: MGPU_LAUNCH_FLAT(1, true); break;
+            case 2: MGPU_LAUNCH_FLAT(2, true); break;
+            case 3: MGPU_LAUNCH_FLAT(3, true); break;
+            case 4: MGPU_LAUNCH_FLAT(4, true); break;
+            default: MGPU_LAUNCH_FLAT(5, true); break;
+        }
+    } else if (flat) {
+        switch (common_n1) {
+            case 1: MGPU_LAUNCH_FLAT(1, false); break;
+            case 2: MGPU_LAUNCH_FLAT(2, false); break;
+            case 3: MGPU_LAUNCH_FLAT(3, false); break;
+            case 4: MGPU_LAUNCH_FLAT(4, false); break;
+            default: MGPU_LAUNCH_FLAT(5, false); break;
+        }
+    } else if (fused) {
+        switch (common_n1) {
+            case 1: MGPU_PAIR_FF_FZ(1, true); break;
+            case 2: MGPU_PAIR_FF_FZ(2, true); break;
+            case 3: MGPU_PAIR_FF_FZ(3, true); break;
+            case 4: MGPU_PAIR_FF_FZ(4, true); break;   // wide instantiations: 2 waves per SIMD, one workgroup per CU
+            default: MGPU_PAIR_FF_FZ(5, true); break;
         }
     } else if (e->bx.triclinic) {
         if (ordered) MGPU_LAUNCH_PAIR(0, true, true);
@@ -347,13 +447,17 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
         MGPU_LAUNCH_PAIR(0, true, false);
     } else {
         switch (common_n1) {
-            case 1: if (ff) MGPU_LAUNCH_PAIR(1, false, false, false, true); else MGPU_LAUNCH_PAIR(1, false, false); break;
-            case 2: if (ff) MGPU_LAUNCH_PAIR(2, false, false, false, true); else MGPU_LAUNCH_PAIR(2, false, false); break;
-            case 3: if (ff) MGPU_LAUNCH_PAIR(3, false, false, false, true); else MGPU_LAUNCH_PAIR(3, false, false); break;
-            case 4: if (ff) MGPU_LAUNCH_PAIR(4, false, false, false, true); else MGPU_LAUNCH_PAIR(4, false, false); break;
+            case 1: MGPU_PAIR_FF_FZ(1, false); break;
+            case 2: MGPU_PAIR_FF_FZ(2, false); break;
+            case 3: MGPU_PAIR_FF_FZ(3, false); break;
+            case 4: MGPU_PAIR_FF_FZ(4, false); break;
+            case 5: MGPU_PAIR_FF_FZ(5, false); break;
             default: MGPU_LAUNCH_PAIR(0, false, false); break;
         }
     }
+#undef MGPU_PAIR_FF_FZ
+#undef MGPU_LAUNCH_FLAT
+#undef MGPU_LAUNCH_FLAT_1
 #undef MGPU_LAUNCH_PAIR
     rc = prof_end(e, ln, MGPU_KERNEL_PAIR, a, b);
     if (rc) return rc;
@@ -598,12 +702,62 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
         tp.n1[t] = atoms_in_res[t];
         tp.cap[t] = mol_capacity[t];
         tp.seg_off[t] = off;
-        tp.site_major[t] = atoms_in_res[t] >= 64 ? 1 : 0;
+        tp.site_major[t] = atoms_in_res[t] >= 64 ? (is_active[t] == 0 && std::getenv("MGPU_NO_FROZEN") == nullptr ? 2 : 1) : 0;
         off += atoms_in_res[t] * mol_capacity[t];
     }
     tp.n_cap_atoms = off;
+    // frozen residues: stable sort of the sites by atom type -> one group per type present
+    std::vector<int4> grp_tab;
+    e->site_perm.resize(n_res);
+    e->frozen.assign(n_res, 0);
+    for (int t = 0; t < n_res; ++t) {
+        std::vector<int> &perm = e->site_perm[t];
+        perm.resize(tp.n1[t]);
+        tp.n_grp[t] = 0;
+        tp.grp_off[t] = (int)grp_tab.size();
+        if (tp.site_major[t] != 2) {
+            for (int a = 0; a < tp.n1[t]; ++a) perm[a] = a;
+            continue;
+        }
+        e->frozen[t] = 1;
+        e->any_frozen = true;
+        std::vector<int> order(tp.n1[t]);
+        for (int a = 0; a < tp.n1[t]; ++a) order[a] = a;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            return atom_types[(size_t)t * max_atom + a] < atom_types[(size_t)t * max_atom + b];
+        });
+        int cur_ty = -1;
+        for (int pos = 0; pos < tp.n1[t]; ++pos) {
+            const int a = order[pos], ty = atom_types[(size_t)t * max_atom + a] - 1;
+            perm[a] = pos;
+            if (ty != cur_ty) {
+                grp_tab.push_back(make_int4(pos, 0, ty, 0));
+                tp.n_grp[t] += 1;
+                cur_ty = ty;
+            }
+            grp_tab.back().y += 1;
+        }
+    }
+    {
+        constexpr int kFlatMaxCap = 1024;       // <= 16 units per plane
+        bool short_planes = true, ok = true;
+        for (int t = 0; t < n_res; ++t) {
+            if (tp.site_major[t] == 1) ok = false;
+            if (tp.site_major[t] == 0 && tp.cap[t] > kFlatMaxCap) short_planes = false;
+        }
+        if ((int)grp_tab.size() > kMaxGrp) ok = false;
+        int planes = 0;                        // one lane of the wave builds one plane's record
+        for (int t = 0; t < n_res; ++t) planes += tp.site_major[t] == 2 ? tp.cap[t] * tp.n_grp[t] : tp.n1[t];
+        if (planes > kFlatMaxPlanes) ok = false;
+        e->pair_flat = ok && (short_planes || e->any_frozen);
+        if (const char *ov = std::getenv("MGPU_PAIR_FLAT")) e->pair_flat = ok && std::atoi(ov) != 0;
+        for (size_t g = 0; g < grp_tab.size() && g < (size_t)kMaxGrp; ++g) {
+            tp.grp_start[g] = grp_tab[g].x; tp.grp_cnt[g] = grp_tab[g].y; tp.grp_ty[g] = grp_tab[g].z;
+        }
+    }
     e->pair_fuse = std::getenv("MGPU_PAIR_NO_FUSE") == nullptr;
     e->pair_fast_fold = std::getenv("MGPU_PAIR_EXACT_FOLD") == nullptr;
+    if (const char *ov = std::getenv("MGPU_PAIR_FUSE_MAX")) e->pair_fuse_max = std::max(1, std::min(std::atoi(ov), kMaxFusedSitesWide));
     e->recip_force_per_k = std::getenv("MGPU_RECIP_PER_K") != nullptr;
     e->defer_commits = std::getenv("MGPU_DEFER_COMMIT") != nullptr;
 
@@ -671,16 +825,25 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     bx.n_slots = e->n_slots;
     std::vector<double2> ptab((size_t)n_types * n_types);
     for (int i = 0; i < n_types * n_types; ++i) ptab[i] = make_double2(4.0 * epsilon[i], sigma[i] * sigma[i]);
+    // device site templates in the ENGINE's site order (frozen residues: sorted by atom type); the host copies
+    // e->charges / e->atom_types keep the caller's order (self energies are summed in the reference's order)
     std::vector<int> atype0((size_t)n_res * max_atom, 0);
+    std::vector<double> q_dev((size_t)n_res * max_atom, 0.0);
     for (int t = 0; t < n_res; ++t)
-        for (int a = 0; a < atoms_in_res[t]; ++a) atype0[(size_t)t * max_atom + a] = atom_types[(size_t)t * max_atom + a] - 1;
-    std::vector<int> a_res(tp.n_cap_atoms), a_mol(tp.n_cap_atoms);
+        for (int a = 0; a < atoms_in_res[t]; ++a) {
+            const int ap = e->site_perm[t][a];
+            atype0[(size_t)t * max_atom + ap] = atom_types[(size_t)t * max_atom + a] - 1;
+            q_dev[(size_t)t * max_atom + ap] = charges[(size_t)t * max_atom + a];
+        }
+    std::vector<int> a_res(tp.n_cap_atoms), a_mol(tp.n_cap_atoms), a_ty(tp.n_cap_atoms);
     std::vector<double> a_q(tp.n_cap_atoms);
     for (int t = 0; t < n_res; ++t)
         for (int m = 0; m < tp.cap[t]; ++m)
             for (int a = 0; a < tp.n1[t]; ++a) {
-                const int j = tp.site_major[t] ? tp.seg_off[t] + m * tp.n1[t] + a : tp.seg_off[t] + a * tp.cap[t] + m;
+                const int ap = e->site_perm[t][a];
+                const int j = tp.site_major[t] ? tp.seg_off[t] + m * tp.n1[t] + ap : tp.seg_off[t] + ap * tp.cap[t] + m;
                 a_res[j] = t; a_mol[j] = m; a_q[j] = charges[(size_t)t * max_atom + a];
+                a_ty[j] = atom_types[(size_t)t * max_atom + a] - 1;
             }
 
     auto fail = [&](int code) { mgpu_engine_destroy(e); return code; };
@@ -748,7 +911,16 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     }
     HIP_TRY_E(hipMemcpy(e->d_kw, kw.data(), e->nk * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY_E(hipMemcpy(e->d_pair_tab, ptab.data(), ptab.size() * sizeof(double2), hipMemcpyHostToDevice));
-    HIP_TRY_E(hipMemcpy(e->d_res_q, e->charges.data(), e->charges.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY_E(hipMemcpy(e->d_res_q, q_dev.data(), q_dev.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (!grp_tab.empty()) {
+        HIP_TRY_E(hipMalloc(&e->d_grp_tab, grp_tab.size() * sizeof(int4)));
+        HIP_TRY_E(hipMemcpy(e->d_grp_tab, grp_tab.data(), grp_tab.size() * sizeof(int4), hipMemcpyHostToDevice));
+    }
+    HIP_TRY_E(hipMalloc(&e->d_atom_ty, ncap * sizeof(int)));
+    HIP_TRY_E(hipMemcpy(e->d_atom_ty, a_ty.data(), ncap * sizeof(int), hipMemcpyHostToDevice));
+    tp.grp_tab = e->d_grp_tab;
+    tp.slot_q = e->d_atom_q;
+    tp.slot_ty = e->d_atom_ty;
     HIP_TRY_E(hipMemcpy(e->d_res_atype, atype0.data(), atype0.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY_E(hipMemcpy(e->d_atom_res, a_res.data(), ncap * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY_E(hipMemcpy(e->d_atom_mol, a_mol.data(), ncap * sizeof(int), hipMemcpyHostToDevice));
@@ -767,7 +939,7 @@ int mgpu_engine_destroy(mgpu_engine *e) {
     for (void *p : {(void *)e->d_pos, (void *)e->d_nmol, (void *)e->d_A, (void *)e->d_kpack, (void *)e->d_kw,
                     (void *)e->d_pair_tab, (void *)e->d_coul_tab, (void *)e->d_res_q, (void *)e->d_res_atype, (void *)e->d_atom_res,
                     (void *)e->d_atom_mol, (void *)e->d_atom_q, (void *)e->d_phase_tab, (void *)e->d_S, (void *)e->d_trj,
-                    (void *)e->d_tw, (void *)e->d_kslot, (void *)e->d_rrows})
+                    (void *)e->d_tw, (void *)e->d_kslot, (void *)e->d_rrows, (void *)e->d_grp_tab, (void *)e->d_atom_ty})
         if (p) (void)hipFree(p);
     e->h_stage.release();
     for (auto &ln : e->lanes) {
@@ -827,9 +999,10 @@ int mgpu_replica_set_molecules(mgpu_engine *e, int replica, int t, int n_mol, co
     if (rc) return rc;
     double *st = (double *)e->h_stage.p;
     std::memset(st, 0, 3 * seg * sizeof(double));
+    const int *perm = e->site_perm[t].data();
     for (int m = 0; m < n_mol; ++m)
         for (int a = 0; a < n1; ++a) {
-            const size_t j = tp.site_major[t] ? (size_t)m * n1 + a : (size_t)a * cap + m;
+            const size_t j = tp.site_major[t] ? (size_t)m * n1 + perm[a] : (size_t)a * cap + m;
             for (int d = 0; d < 3; ++d) st[d * seg + j] = sites[((size_t)m * n1 + a) * 3 + d];
         }
     if ((rc = sync_all_lanes(e))) return rc;
@@ -858,9 +1031,10 @@ int mgpu_replica_get_molecules(mgpu_engine *e, int replica, int t, int *n_mol, d
     for (int d = 0; d < 3; ++d)
         HIP_TRY(hipMemcpy(st + d * seg, e->d_pos + ((size_t)replica * 3 + d) * tp.n_cap_atoms + tp.seg_off[t],
                           seg * sizeof(double), hipMemcpyDeviceToHost));
+    const int *perm = e->site_perm[t].data();
     for (int m = 0; m < nm; ++m)
         for (int a = 0; a < n1; ++a) {
-            const size_t j = tp.site_major[t] ? (size_t)m * n1 + a : (size_t)a * cap + m;
+            const size_t j = tp.site_major[t] ? (size_t)m * n1 + perm[a] : (size_t)a * cap + m;
             for (int d = 0; d < 3; ++d) sites[((size_t)m * n1 + a) * 3 + d] = st[d * seg + j];
         }
     return MGPU_OK;
@@ -983,7 +1157,7 @@ int mgpu_structure_factor_add(mgpu_engine *e, int replica, int t, const double *
     RecipItem it{replica, t, -1, MGPU_FOURIER_ADD, 0, 0};
     if ((rc = ln.d_items2.reserve(sizeof(RecipItem)))) return rc;
     HIP_TRY(hipMemcpyAsync(ln.d_items2.p, &it, sizeof(RecipItem), hipMemcpyHostToDevice, ln.stream));
-    if ((rc = upload_sites(ln, sites, 1, n1))) return rc;
+    if ((rc = upload_sites(e, sites, 1, n1, &t))) return rc;
     if ((rc = launch_recip(e, ln, (const RecipItem *)ln.d_items2.p, 1, n1, n1, true, e->d_A, nullptr))) return rc;
     return sync_stream(e);
 }
@@ -1015,7 +1189,7 @@ int mgpu_pair_energy_candidates(mgpu_engine *e, int n, const int *replica, const
     if ((rc = e->d_out.reserve((size_t)2 * n * sizeof(double)))) return rc;
     if ((rc = e->h_out.reserve((size_t)2 * n * sizeof(double)))) return rc;
     HIP_TRY(hipMemcpyAsync(e->d_items.p, items.data(), n * sizeof(PairItem), hipMemcpyHostToDevice, e->stream));
-    if (any_sites && (rc = upload_sites(e, sites, n, site_stride))) return rc;
+    if (any_sites && (rc = upload_sites(e, sites, n, site_stride, t))) return rc;
     double *d_lj = (double *)e->d_out.p, *d_c = d_lj + n;
     const int nsplit = e->pair_nsplit;
     bool fast = true;
@@ -1061,7 +1235,7 @@ int mgpu_recip_energy_candidates(mgpu_engine *e, int n, const int *replica, cons
     if ((rc = e->d_out.reserve((size_t)n * sizeof(double)))) return rc;
     if ((rc = e->h_out.reserve((size_t)n * sizeof(double)))) return rc;
     HIP_TRY(hipMemcpyAsync(e->d_items2.p, items.data(), n * sizeof(RecipItem), hipMemcpyHostToDevice, e->stream));
-    if (any_sites && (rc = upload_sites(e, sites, n, site_stride))) return rc;
+    if (any_sites && (rc = upload_sites(e, sites, n, site_stride, t))) return rc;
     if ((rc = launch_recip(e, e->lanes[0], (const RecipItem *)e->d_items2.p, n, n1_max, site_stride, false, e->d_A, (double *)e->d_out.p)))
         return rc;
     HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -1101,7 +1275,7 @@ int mgpu_intra_energy_candidates(mgpu_engine *e, int n, const int *replica, cons
     if ((rc = e->d_out.reserve((size_t)n * sizeof(double)))) return rc;
     if ((rc = e->h_out.reserve((size_t)n * sizeof(double)))) return rc;
     HIP_TRY(hipMemcpyAsync(e->d_items.p, items.data(), n * sizeof(PairItem), hipMemcpyHostToDevice, e->stream));
-    if (any_sites && (rc = upload_sites(e, sites, n, site_stride))) return rc;
+    if (any_sites && (rc = upload_sites(e, sites, n, site_stride, t))) return rc;
     hipLaunchKernelGGL(intra_kernel, dim3((n + 63) / 64), dim3(64), 0, e->stream, e->tp, e->bx, e->d_pos, e->d_res_q,
                        (const PairItem *)e->d_items.p, n, (const double *)e->d_sites.p, site_stride, (double *)e->d_out.p);
     HIP_TRY(hipGetLastError());
@@ -1133,6 +1307,8 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     const size_t site_bytes = (size_t)n * site_stride * 3 * sizeof(double);
     const size_t pit_cap = 2 * (size_t)n * sizeof(PairItem), rit_bytes = (size_t)n * sizeof(RecipItem);
     const size_t iit_cap = (size_t)n * sizeof(PairItem) + (size_t)n * sizeof(int);       // intra items | pend_idx
+    if (sites == ln.h_in.p && site_bytes + pit_cap + rit_bytes + iit_cap > ln.h_in.bytes)
+        return set_error(MGPU_ERR_INVALID_ARG, "trial_submit: more candidates than the lane's site buffer was sized for");
     if ((rc = ln.h_in.reserve(site_bytes + pit_cap + rit_bytes + iit_cap))) return rc;
     double *h_sites = (double *)ln.h_in.p;
     PairItem *pit = (PairItem *)((char *)ln.h_in.p + site_bytes);
@@ -1155,7 +1331,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     // Trial moves of molecules with a few sites are swept old + new together (fused items, two entries each);
     // insertions, deletions and everything else are single-state items.  Entry layout of the reduced pair
     // energies: [2 i + {0 old, 1 new} for fused item i | 2 n_fused + j for single item j].
-    const bool fuse = e->pair_fuse && !e->bx.triclinic && common >= 1 && common <= kMaxFusedSites;
+    const bool fuse = e->pair_fuse && !e->bx.triclinic && common >= 1 && common <= e->pair_fuse_max;
     const int n_fused = fuse ? n_moves : 0;
     int i_fused = 0, i_single = 0;
     PairItem *pit_single = pit + n_fused;
@@ -1187,7 +1363,8 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
         if (k == MGPU_DELETION) { ln.intra_idx[c] = n_intra; iit[n_intra++] = PairItem{replica[c], t[c], mc, -1, 0}; }
     }
     const int n_single = i_single, n_pair = 2 * n_fused + n_single;     // reduced pair-energy entries
-    std::memcpy(h_sites, sites, site_bytes);
+    if (sites != h_sites) std::memcpy(h_sites, sites, site_bytes);        // rows built in place (mgpu_lane_site_buffer): no copy
+    if (any_frozen(e, n, t)) permute_frozen_rows(e, h_sites, n, site_stride, t);
     const size_t iit_bytes = (size_t)n_intra * sizeof(PairItem);
     // results in device memory, copied out once: [split partials of the pair sweep (n_pair * nsplit complex-sized
     // records, reduced on the host in trial_wait) | u_old | u_new | intra]
@@ -1415,6 +1592,7 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
         if (any_sites && sites) {
             ln.last_trial_n = 0;
             std::memcpy(ln.h_commit.p, sites, site_bytes);
+            if (any_frozen(e, n, t)) permute_frozen_rows(e, (double *)ln.h_commit.p, n, site_stride, t);
             if ((rc = ln.d_sites.reserve(site_bytes))) return rc;
             HIP_TRY(hipMemcpyAsync(ln.d_sites.p, ln.h_commit.p, site_bytes, hipMemcpyHostToDevice, ln.stream));
         }
@@ -1432,6 +1610,27 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
 static int check_lane(const mgpu_engine *e, int lane) {
     if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
     if (lane < 0 || lane >= kLanes) return set_error(MGPU_ERR_INVALID_ARG, "lane out of range");
+    return MGPU_OK;
+}
+
+static size_t trial_staging_bytes(int n, int site_stride) {
+    return (size_t)n * site_stride * 3 * sizeof(double) + 2 * (size_t)n * sizeof(PairItem) + (size_t)n * sizeof(RecipItem) +
+           (size_t)n * sizeof(PairItem) + (size_t)n * sizeof(int);
+}
+
+int mgpu_lane_site_buffer(mgpu_engine *e, int lane, int n_max, int site_stride, double **sites) {
+    int rc = check_lane(e, lane);
+    if (rc) return rc;
+    if (n_max < 1 || site_stride < 1 || !sites) return set_error(MGPU_ERR_INVALID_ARG, "lane_site_buffer: bad argument");
+    if ((rc = use_device(e))) return rc;
+    Lane &ln = e->lanes[lane];
+    if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "lane_site_buffer: the lane holds an un-waited trial");
+    // a regrown block would leave the previous trial's item image dangling
+    ln.last_trial_n = 0;
+    ln.d_trial_items = nullptr;
+    ln.h_trial_items = nullptr;
+    if ((rc = ln.h_in.reserve(trial_staging_bytes(n_max, site_stride)))) return rc;
+    *sites = (double *)ln.h_in.p;
     return MGPU_OK;
 }
 

@@ -16,8 +16,11 @@
 //                                        ONE site index, so charge / atom type / LJ pair are
 //                                        wave-uniform and whole LJ or Coulomb halves are skipped
 //                                        by a scalar branch (SPC/E: LJ for 1 of 9 site pairs);
-//   site-major  (n1 >= 64, frameworks):  seg_off[t] + m * n1 + a     -> a wave sweeps 64 sites of
-//                                        one molecule, per-lane charge / type.
+//   site-major  (n1 >= 64):              seg_off[t] + m * n1 + a     -> a wave sweeps 64 sites of
+//                                        one molecule, per-lane charge / type;
+//   frozen      (inactive, n1 >= 64:     the same slots, with the residue's sites renumbered by atom type (the engine
+//                frameworks)             translates at the API boundary): a wave sweeps 64 sites of ONE atom type, so
+//                                        the LJ pair is wave-uniform again and only the charge is per lane.
 // All arithmetic is IEEE fp64.  Reductions use a fixed tree (wave butterfly -> LDS -> ordered
 // sum over waves -> ordered sum over splits): results are bitwise reproducible run to run.
 #ifndef MGPU_KERNELS_H
@@ -44,7 +47,10 @@ constexpr int kSiteChunk = 32;    // candidate sites staged in LDS per pass (gen
 constexpr int kPairBlock = MGPU_PAIR_BLOCK;   // pair sweep: persistent waves share one LDS Coulomb table
 constexpr int kPairWaves = kPairBlock / 64;
 constexpr int kMaxTypes = 16;     // atom types (LDS pair table 16 x 16 x 16 B = 4 KiB)
-constexpr int kMaxFusedSites = 3; // trial moves of molecules up to this size sweep old + new together (2 NS register sites)
+constexpr int kMaxGrp = 32;       // atom-type groups of all frozen residues of a topology together
+constexpr int kFlatMaxPlanes = 64;  // planes of a replica pair_flat_kernel handles (one lane builds one plane's record)
+constexpr int kMaxFusedSites = 3; // trial moves of molecules up to this size sweep old + new together (2 NS register sites) at 4 waves per SIMD
+constexpr int kMaxFusedSitesWide = 5;   // ... and up to this size in the wide instantiations (<= 256 VGPRs, 2 waves per SIMD; engine switch)
 
 struct Topo {
     int n_res;
@@ -54,7 +60,19 @@ struct Topo {
     int n1[kMaxRes];              // nb%atom_in_residue
     int cap[kMaxRes];             // molecule slots
     int seg_off[kMaxRes];         // first atom slot of the residue type
-    int site_major[kMaxRes];
+    int site_major[kMaxRes];      // 0 plane-major, 1 site-major, 2 frozen: site-major with the sites sorted by atom type
+    // frozen residues (inactive, n1 >= 64: frameworks): the residue's sites are renumbered so that sites of one atom
+    // type are contiguous; grp_tab[grp_off[t] + g] = {first sorted site, count, 0-based atom type, 0} for its n_grp[t]
+    // groups.  A wave then sweeps 64 consecutive sites of ONE atom type: the (4 epsilon, sigma^2) of every
+    // (candidate site, group) pair is wave-uniform and the scalar LJ / Coulomb skips of the plane-major sweep apply;
+    // only the charge is per lane (frameworks carry per-atom charges).
+    int n_grp[kMaxRes];
+    int grp_off[kMaxRes];
+    const int4 *grp_tab;
+    const double *slot_q;         // [n_cap_atoms] charge of every atom slot (same for all replicas)
+    const int *slot_ty;           // [n_cap_atoms] 0-based atom type of every atom slot
+    // the same group records by value (read through the scalar cache by pair_flat_kernel's unit generator)
+    int grp_start[kMaxGrp], grp_cnt[kMaxGrp], grp_ty[kMaxGrp];
 };
 
 struct BoxDev {
@@ -234,8 +252,11 @@ __device__ __forceinline__ void pair_term(double dx, double dy, double dz, const
 // ComputeOldEnergy and ComputeNewEnergy (monte_carlo_utils.f90:380-395 / :275-330); each state's sums are
 // formed exactly as the unfused sweep forms them, and the work unit writes two partials {old, new}.
 // ------------------------------------------------------------------------------------------
-template <int NS, bool ORDERED, bool TRI, bool FUSED = false, bool FASTW = false>
-__global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_kernel(
+// FROZ: the topology has frozen residues (inactive frameworks stored sorted by atom type, per-lane charges): only then
+// is the per-lane-charge variant of the hot path compiled in, so the kernels of every other topology keep their
+// register budget.
+template <int NS, bool ORDERED, bool TRI, bool FUSED = false, bool FASTW = false, bool FROZ = false>
+__global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MGPU_PAIR_MINWAVES) void pair_sweep_kernel(
     Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
     const char *__restrict__ coul_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
@@ -328,12 +349,136 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                 const int nm = nm_r[t2], n2 = tp.n1[t2];
                 if (nm == 0) continue;
                 const bool same_t = (t2 == it.t) && (it.m >= 0);
-                if (!tp.site_major[t2]) {
-                    // plane-major: unit = (site index a2, 64 consecutive molecules); q / type uniform
+                // ---- hot path of the register-site sweeps: one "plane" = a run of `nm` atoms that share their atom
+                //      type (plane-major: site a2 of every molecule, charge uniform too; frozen: one atom-type group of
+                //      one molecule, charge per lane), swept in units of 64, branch-free per unit, NS independent
+                //      dependency chains, next unit's coordinates prefetched while this one computes ----
+                [[maybe_unused]] auto plane_sweep = [&](auto plq_tag, const double *pxp, const double *pyp, const double *pzp,
+                                                        const double *pqp, int nm, bool excl, int dummy_m, double qj, int tyj, int key) {
+                    constexpr bool PLQ = decltype(plq_tag)::value;      // per-lane charge (frozen groups)
                     const int cpp = (nm + 63) >> 6;
+                    const bool qj_on = PLQ || fabs(qj) >= kErrorTol;
+                    double e4[NTY], sg2[NTY], qq[NTY];
+                    bool lj[NTY], c_on[NTY];
+                    bool any_c = false, all_c = true, any_lj = false;
+#pragma unroll
+                    for (int s = 0; s < NTY; ++s) {
+                        const double2 pt = pair_tab[rty[s] * nt + tyj];     // scalar load
+                        e4[s] = pt.x; sg2[s] = pt.y;
+                        lj[s] = pt.x != 0.0;                               // epsilon = 0 contributes 0
+                        c_on[s] = qj_on && (fabs(rq[s]) >= kErrorTol);      // energy_utils.f90:430
+                        qq[s] = c_on[s] ? (PLQ ? rq[s] : rq[s] * qj) : 0.0;
+                        any_c = any_c || c_on[s]; all_c = all_c && c_on[s]; any_lj = any_lj || lj[s];
+                    }
+                    if (!(any_c || any_lj)) return;
+                    int c = split - (key * cpp) % nsplit;    // units are dealt round-robin
+                    if (c < 0) c += nsplit;
+                    if (c >= cpp) return;
+                    // A unit is "special" when some lane must be masked off: the tail chunk of the
+                    // plane, the chunk holding the excluded molecule, or any chunk of an ordered sweep.
+                    // Ordinary units skip the masks entirely.
+                    auto is_special = [&](int cc) {
+                        return ORDERED || (cc == cpp - 1 && (nm & 63) != 0) || (excl && cc == (it.m >> 6));
+                    };
+                    // wq: the lane's weight in the Coulomb sums -- 1 / 0 (valid / masked off) where the charge is
+                    // uniform, the lane's own charge (0 where masked off or below CoulombEnergy's 1e-10 threshold) for
+                    // a frozen group
+                    auto fetch = [&](int cc, bool special, double &x, double &y, double &z, double &wq, bool &ok) {
+                        int m2 = cc * 64 + lane;
+                        ok = true;
+                        if (special) {
+                            ok = m2 < nm;
+                            if (excl) ok = ok && (ORDERED ? (m2 > it.m) : (m2 != it.m));
+                            m2 = ok ? m2 : dummy_m;
+                        }
+                        x = pxp[m2]; y = pyp[m2]; z = pzp[m2];
+                        if constexpr (PLQ) {
+                            const double q = pqp[m2];
+                            wq = (ok && fabs(q) >= kErrorTol) ? q : 0.0;
+                        } else {
+                            wq = ok ? 1.0 : 0.0;
+                        }
+                    };
+                    double acc[NREG];
+#pragma unroll
+                    for (int s = 0; s < NREG; ++s) acc[s] = 0.0;
+                    // ALL_C: every site is charged -> the NS Coulomb chains form one basic block
+                    auto sweep_plane = [&](auto all_tag) {
+                        constexpr bool ALL_C = decltype(all_tag)::value;
+                        auto unit = [&](double xj, double yj, double zj, double wq, bool valid) {
+                            const double rc2l = valid ? bx.rc2 : -1.0;
+                            double r2[NREG], g[NREG];
+                            bool any_below = false;
+#pragma unroll
+                            for (int s = 0; s < NREG; ++s) {
+                                r2[s] = FASTW ? image_r2_fast(xj - rx[s], yj - ry[s], zj - rz[s], bx)
+                                              : image_r2<TRI>(xj - rx[s], yj - ry[s], zj - rz[s], bx);
+                            }
+#pragma unroll
+                            for (int s = 0; s < NREG; ++s) {
+                                if (!ALL_C && !c_on[s % NTY]) { g[s] = 0.0; continue; }
+                                bool below;
+                                g[s] = coul_lds(r2[s], s_coul, bx.coul_idx_base, bx.coul_last_row, below);
+                                any_below = any_below || below;
+                            }
+                            if (any_below) {   // r < 0.5 A somewhere in the wave: rare slow path
+#pragma unroll
+                                for (int s = 0; s < NREG; ++s)
+                                    if ((ALL_C || c_on[s % NTY]) && r2[s] < 0.25) g[s] = coul_slow(r2[s], bx.alpha, ORDERED);
+                            }
+#pragma unroll
+                            for (int s = 0; s < NREG; ++s)
+                                if (ALL_C || c_on[s % NTY]) acc[s] = fma(wq, g[s], acc[s]);
+                            if (any_lj) {
+#pragma unroll
+                                for (int s = 0; s < NREG; ++s) {
+                                    if (!lj[s % NTY]) continue;
+                                    const double s2 = sg2[s % NTY] * fast_rcp(r2[s]);
+                                    const double s6 = s2 * s2 * s2;
+                                    const double e = e4[s % NTY] * fma(s6, s6, -s6);  // energy_utils.f90:421-423
+                                    elj[s / NTY] += (r2[s] < rc2l) ? e : 0.0;            // energy_utils.f90:417
+                                }
+                            }
+                        };
+                        double xj, yj, zj, wj;
+                        bool valid, special = is_special(c);
+                        fetch(c, special, xj, yj, zj, wj, valid);
+                        for (; c < cpp; c += nsplit) {
+                            double xn = xj, yn = yj, zn = zj, wn = wj;
+                            bool vn = true;
+                            const bool special_n = is_special(c + nsplit);
+                            if (c + nsplit < cpp) fetch(c + nsplit, special_n, xn, yn, zn, wn, vn);
+                            // (a mask-free copy of the unit for ordinary chunks was measured slower:
+                            //  the duplicated body costs more registers than the masks cost cycles)
+                            // uniform charge: the weight is rebuilt from the mask (no second prefetch register pair)
+                            unit(xj, yj, zj, PLQ ? wj : (valid ? 1.0 : 0.0), valid);
+                            xj = xn; yj = yn; zj = zn; valid = vn; special = special_n;
+                            if constexpr (PLQ) wj = wn;
+                        }
+                    };
+                    if (all_c) sweep_plane(std::true_type{});
+                    else sweep_plane(std::false_type{});
+#pragma unroll
+                    for (int s = 0; s < NREG; ++s) ec[s / NTY] = fma(qq[s % NTY], acc[s], ec[s / NTY]);
+                };
+                if (NS > 0 && FROZ && tp.site_major[t2] == 2) {
+                    // frozen residue: one plane per (molecule, atom-type group); the candidate is never one of its molecules
+                    // unless an inactive molecule itself is evaluated (then that whole molecule is skipped)
+                    if constexpr (NS > 0 && FROZ) {
+                        const int ng = tp.n_grp[t2], seg2 = tp.seg_off[t2];
+                        for (int m2 = 0; m2 < nm; ++m2) {
+                            if (same_t && (ORDERED ? (m2 <= it.m) : (m2 == it.m))) continue;
+                            for (int g = 0; g < ng; ++g) {
+                                const int4 gr = tp.grp_tab[tp.grp_off[t2] + g];        // scalar load
+                                const int base = seg2 + m2 * n2 + gr.x;
+                                plane_sweep(std::true_type{}, px + base, py + base, pz + base, tp.slot_q + base, gr.y, false, 0,
+                                            0.0, gr.z, plane_base + m2 * ng + g);
+                            }
+                        }
+                    }
+                } else if (!tp.site_major[t2]) {
+                    // plane-major: unit = (site index a2, 64 consecutive molecules); q / type uniform
                     if constexpr (NS > 0) {
-                        // ---- hot path: branch-free per unit, NS independent dependency chains,
-                        //      next unit's coordinates prefetched while this one computes ----
                         const int cap2 = tp.cap[t2], seg2 = tp.seg_off[t2];
                         int dummy_m = 0;   // a live, never-excluded molecule for masked-off lanes to read
                         if (same_t) {
@@ -343,103 +488,11 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                         for (int a2 = 0; a2 < n2; ++a2) {
                             const double qj = res_q[t2 * tp.max_atom + a2];
                             const int tyj = res_atype[t2 * tp.max_atom + a2];
-                            const bool qj_on = fabs(qj) >= kErrorTol;
-                            double e4[NTY], sg2[NTY], qq[NTY];
-                            bool lj[NTY], c_on[NTY];
-                            bool any_c = false, all_c = true, any_lj = false;
-#pragma unroll
-                            for (int s = 0; s < NTY; ++s) {
-                                const double2 pt = pair_tab[rty[s] * nt + tyj];     // scalar load
-                                e4[s] = pt.x; sg2[s] = pt.y;
-                                lj[s] = pt.x != 0.0;                               // epsilon = 0 contributes 0
-                                c_on[s] = qj_on && (fabs(rq[s]) >= kErrorTol);      // energy_utils.f90:430
-                                qq[s] = c_on[s] ? rq[s] * qj : 0.0;
-                                any_c = any_c || c_on[s]; all_c = all_c && c_on[s]; any_lj = any_lj || lj[s];
-                            }
-                            if (!(any_c || any_lj)) continue;
-                            int c = split - ((plane_base + a2) * cpp) % nsplit;    // units are dealt round-robin
-                            if (c < 0) c += nsplit;
-                            if (c >= cpp) continue;
-                            // A unit is "special" when some lane must be masked off: the tail chunk of the
-                            // plane, the chunk holding the excluded molecule, or any chunk of an ordered sweep.
-                            // Ordinary units skip the masks entirely.
-                            const double *pxp = px + seg2 + a2 * cap2, *pyp = py + seg2 + a2 * cap2, *pzp = pz + seg2 + a2 * cap2;
-                            auto is_special = [&](int cc) {
-                                return ORDERED || (cc == cpp - 1 && (nm & 63) != 0) || (same_t && cc == (it.m >> 6));
-                            };
-                            auto fetch = [&](int cc, bool special, double &x, double &y, double &z, bool &ok) {
-                                int m2 = cc * 64 + lane;
-                                ok = true;
-                                if (special) {
-                                    ok = m2 < nm;
-                                    if (same_t) ok = ok && (ORDERED ? (m2 > it.m) : (m2 != it.m));
-                                    m2 = ok ? m2 : dummy_m;
-                                }
-                                x = pxp[m2]; y = pyp[m2]; z = pzp[m2];
-                            };
-                            double acc[NREG];
-#pragma unroll
-                            for (int s = 0; s < NREG; ++s) acc[s] = 0.0;
-                            // ALL_C: every site is charged -> the NS Coulomb chains form one basic block
-                            auto sweep_plane = [&](auto all_tag) {
-                                constexpr bool ALL_C = decltype(all_tag)::value;
-                                auto unit = [&](auto masked_tag, double xj, double yj, double zj, bool valid) {
-                                    constexpr bool MASKED = decltype(masked_tag)::value;
-                                    const double wgt = (MASKED && !valid) ? 0.0 : 1.0;
-                                    const double rc2l = (MASKED && !valid) ? -1.0 : bx.rc2;
-                                    double r2[NREG], g[NREG];
-                                    bool any_below = false;
-#pragma unroll
-                                    for (int s = 0; s < NREG; ++s) {
-                                        r2[s] = FASTW ? image_r2_fast(xj - rx[s], yj - ry[s], zj - rz[s], bx)
-                                                      : image_r2<TRI>(xj - rx[s], yj - ry[s], zj - rz[s], bx);
-                                    }
-#pragma unroll
-                                    for (int s = 0; s < NREG; ++s) {
-                                        if (!ALL_C && !c_on[s % NTY]) { g[s] = 0.0; continue; }
-                                        bool below;
-                                        g[s] = coul_lds(r2[s], s_coul, bx.coul_idx_base, bx.coul_last_row, below);
-                                        any_below = any_below || below;
-                                    }
-                                    if (any_below) {   // r < 0.5 A somewhere in the wave: rare slow path
-#pragma unroll
-                                        for (int s = 0; s < NREG; ++s)
-                                            if ((ALL_C || c_on[s % NTY]) && r2[s] < 0.25) g[s] = coul_slow(r2[s], bx.alpha, ORDERED);
-                                    }
-#pragma unroll
-                                    for (int s = 0; s < NREG; ++s) acc[s] = MASKED ? fma(wgt, g[s], acc[s]) : acc[s] + g[s];
-                                    if (any_lj) {
-#pragma unroll
-                                        for (int s = 0; s < NREG; ++s) {
-                                            if (!lj[s % NTY]) continue;
-                                            const double s2 = sg2[s % NTY] * fast_rcp(r2[s]);
-                                            const double s6 = s2 * s2 * s2;
-                                            const double e = e4[s % NTY] * fma(s6, s6, -s6);  // energy_utils.f90:421-423
-                                            elj[s / NTY] += (r2[s] < rc2l) ? e : 0.0;            // energy_utils.f90:417
-                                        }
-                                    }
-                                };
-                                double xj, yj, zj;
-                                bool valid, special = is_special(c);
-                                fetch(c, special, xj, yj, zj, valid);
-                                for (; c < cpp; c += nsplit) {
-                                    double xn = xj, yn = yj, zn = zj;
-                                    bool vn = true;
-                                    const bool special_n = is_special(c + nsplit);
-                                    if (c + nsplit < cpp) fetch(c + nsplit, special_n, xn, yn, zn, vn);
-                                    // (a mask-free copy of the unit for ordinary chunks was measured slower:
-                                    //  the duplicated body costs more registers than the masks cost cycles)
-                                    unit(std::true_type{}, xj, yj, zj, valid);
-                                    xj = xn; yj = yn; zj = zn; valid = vn; special = special_n;
-                                }
-                            };
-                            if (all_c) sweep_plane(std::true_type{});
-                            else sweep_plane(std::false_type{});
-#pragma unroll
-                            for (int s = 0; s < NREG; ++s) ec[s / NTY] = fma(qq[s % NTY], acc[s], ec[s / NTY]);
+                            plane_sweep(std::false_type{}, px + seg2 + a2 * cap2, py + seg2 + a2 * cap2, pz + seg2 + a2 * cap2,
+                                        nullptr, nm, same_t, dummy_m, qj, tyj, plane_base + a2);
                         }
                     } else {
-                        const int units = n2 * cpp;
+                        const int cpp = (nm + 63) >> 6, units = n2 * cpp;
                         for (int u = split; u < units; u += nsplit) {
                             const int a2 = u / cpp, m2 = (u - a2 * cpp) * 64 + lane;
                             bool valid = m2 < nm;
@@ -482,12 +535,9 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
                         auto one_site = [&](double sx, double sy, double sz, double qs, int tys, double &elj_s, double &ec_s) {
                             const double2 pt = s_pair[tys * nt + tyj];
                             const bool do_c = qj_on && (fabs(qs) >= kErrorTol);
-                            if (valid) {
-                                double e1 = 0.0, e2 = 0.0;
-                                pair_term<ORDERED, TRI, FASTW>(xj - sx, yj - sy, zj - sz, bx, qs * qj, pt.x, pt.y, true, true, s_coul, e1, e2);
-                                elj_s += (pt.x != 0.0) ? e1 : 0.0;
-                                ec_s += do_c ? e2 : 0.0;
-                            }
+                            const bool do_lj = pt.x != 0.0;                        // epsilon = 0 contributes 0
+                            if (valid && (do_lj || do_c))
+                                pair_term<ORDERED, TRI, FASTW>(xj - sx, yj - sy, zj - sz, bx, qs * qj, pt.x, pt.y, do_lj, do_c, s_coul, elj_s, ec_s);
                         };
                         if constexpr (NS > 0) {
 #pragma unroll
@@ -504,6 +554,262 @@ __global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_ker
         for (int st = 0; st < NST; ++st) {
             const double a = wave_sum(elj[st]), b = wave_sum(ec[st]);
             if (lane == 0) partials[(size_t)w * NST + st] = make_double2(a, b);     // fused: {old, new} per work unit
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Flat pair sweep: the same sums as pair_sweep_kernel's register-site path (NS > 0, unordered, orthorhombic), organised
+// for topologies whose planes are SHORT -- grand-canonical boxes (a plane of a few hundred molecules is a handful of
+// units) and frozen frameworks (one plane per atom-type group).  There the plane-by-plane sweep spends its time on what
+// surrounds the arithmetic: per plane a dependent chain scalar loads -> pointers -> first coordinate load -> wait
+// (~1 us each, measured: a work unit with 9 units of arithmetic took ~18 us), so this kernel walks ALL units of a
+// work unit in ONE software-pipelined loop:
+//   * the lanes of the wave build the work unit's plane table in parallel (lane l = plane l: first slot, atom count,
+//     exclusion, first unit by a wave scan) into a per-wave LDS slab; each of the item's nsplit waves then takes a
+//     CONTIGUOUS share of the unit sequence, so the scalar unit generator is a counter that reads a new plane record
+//     (one LDS broadcast) every few units -- dealing units round-robin made it change planes at every unit, and the
+//     scalar bookkeeping of a plane change outweighed the unit's arithmetic (measured: no faster than plane by plane);
+//   * everything a unit needs is fetched per lane -- x, y, z, the charge (slot_q) and the atom type (slot_ty): 36 bytes
+//     per atom, SURVEY 8(d)'s algorithmic figure -- one unit ahead of the arithmetic, across plane and residue
+//     boundaries; the atom type of a unit is wave-uniform by construction (readfirstlane), so the (4 epsilon, sigma^2)
+//     of a (candidate site, unit) pair is one LDS broadcast read and the LJ half is skipped by a scalar branch where
+//     epsilon = 0; the Coulomb half is skipped where no lane of the unit carries a charge (wave vote);
+//   * the Coulomb sums run over all units of the work unit (acc[site] += q_lane G(r^2)); the candidate's charges are
+//     applied once at the end.
+// Semantics per pair term are those of pair_sweep_kernel: LJ inside the cutoff for epsilon != 0 (energy_utils.f90:417-424),
+// erfc(alpha r)/r for every distance where both charges are at least 1e-10 in magnitude (energy_utils.f90:427-432).
+// ------------------------------------------------------------------------------------------
+template <int NS, bool FUSED, bool FASTW>
+__global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MGPU_PAIR_MINWAVES) void pair_flat_kernel(
+    Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
+    const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
+    const char *__restrict__ coul_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
+    int site_stride, int nsplit, int n_work, double2 *__restrict__ partials) {
+    static_assert(NS > 0, "register sites only");
+    constexpr int NTY = NS;
+    constexpr int NST = FUSED ? 2 : 1;
+    constexpr int NREG = NTY * NST;
+    extern __shared__ __attribute__((aligned(16))) char s_coul[];     // (coul_last_row + 1) x 48 B
+    __shared__ double2 s_pair[kMaxTypes * kMaxTypes];
+    __shared__ int4 s_grp[kMaxGrp];                       // group records of the frozen residues
+    __shared__ int4 s_plane[kPairWaves * kFlatMaxPlanes]; // per wave: the plane table of its current work unit
+
+    if (threadIdx.x < kMaxGrp) s_grp[threadIdx.x] = make_int4(tp.grp_start[threadIdx.x], tp.grp_cnt[threadIdx.x], tp.grp_ty[threadIdx.x], 0);
+    for (int i = threadIdx.x; i < (bx.coul_last_row + 1) * 3; i += kPairBlock)
+        reinterpret_cast<double2 *>(s_coul)[i] = reinterpret_cast<const double2 *>(coul_tab_g)[i];
+    const int nt = tp.n_types;
+    for (int i = threadIdx.x; i < nt * nt; i += kPairBlock) s_pair[i] = pair_tab[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_waves = gridDim.x * kPairWaves;
+
+    for (int w = blockIdx.x * kPairWaves + wave; w < n_work; w += n_waves) {
+        const int item_id = w / nsplit, split = w - item_id * nsplit;
+        const PairItem it = items[item_id];
+        const double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
+        const double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
+        const int *nm_r = nmol + it.replica * tp.n_res;
+        // the replica's molecule counts, requested together (the generator selects among them without a load)
+        int nmv[kMaxRes];
+#pragma unroll
+        for (int i = 0; i < kMaxRes; ++i) nmv[i] = i < tp.n_res ? nm_r[i] : 0;
+
+        // Everything that depends only on the item is requested together -- both states' site coordinates, charges,
+        // atom types, the molecule counts above -- so that the work unit pays ONE memory latency here, not one per site
+        // (a work unit of a grand-canonical box is only a few units of arithmetic long).
+        double rx[NREG], ry[NREG], rz[NREG], rq[NTY];
+        int rty[NTY];
+#pragma unroll
+        for (int a = 0; a < NTY; ++a) {
+            if constexpr (FUSED) {
+                const int j = atom_slot(tp, it.t, it.m, a);            // old state: the resident slot
+                rx[a] = px[j]; ry[a] = py[j]; rz[a] = pz[j];
+                const double *c = cand_sites + ((size_t)it.src * site_stride + a) * 3;   // new state: the candidate row
+                rx[NTY + a] = c[0]; ry[NTY + a] = c[1]; rz[NTY + a] = c[2];
+            } else if (it.src < 0) {
+                const int j = atom_slot(tp, it.t, it.m, a);
+                rx[a] = px[j]; ry[a] = py[j]; rz[a] = pz[j];
+            } else {
+                const double *c = cand_sites + ((size_t)it.src * site_stride + a) * 3;
+                rx[a] = c[0]; ry[a] = c[1]; rz[a] = c[2];
+            }
+            rq[a] = res_q[it.t * tp.max_atom + a];
+            rty[a] = res_atype[it.t * tp.max_atom + a] * nt;          // row of the pair table
+        }
+        // wave-uniform values, parked in VGPRs (the sweep needs its SGPRs for the generator and the box)
+#pragma unroll
+        for (int k = 0; k < NREG; ++k) asm volatile("" : "+v"(rx[k]), "+v"(ry[k]), "+v"(rz[k]));
+        // a site below CoulombEnergy's charge threshold contributes exactly 0 (energy_utils.f90:430): its chain is
+        // still evaluated with the others (one basic block, NREG-way instruction-level parallelism -- a per-site
+        // scalar branch serialises the chains, measured) and weighted 0 at the end
+        bool any_c = false;
+#pragma unroll
+        for (int s = 0; s < NTY; ++s) {
+            const bool on = fabs(rq[s]) >= kErrorTol;
+            any_c = any_c || on;
+            rq[s] = on ? rq[s] : 0.0;
+        }
+
+        // ---- plane table of this work unit, built by the lanes in parallel (lane l = plane l of the replica, residue
+        //      types in order): {first slot, atoms, excluded-molecule flag | dummy molecule << 1, first unit}.  A plane =
+        //      site a2 of every molecule of a plane-major type, or one atom-type group of one molecule of a frozen type.
+        int4 *w_plane = s_plane + wave * kFlatMaxPlanes;
+        int e_off = 0, e_cnt = 0, e_flags = 0;
+        {
+            int first = 0;                                           // planes before residue type i
+#pragma unroll
+            for (int i = 0; i < kMaxRes; ++i) {
+                const int nm2 = nmv[i];                                 // 0 beyond the topology's residue types
+                const bool frozen = tp.site_major[i] == 2;
+                const int npl = nm2 == 0 ? 0 : (frozen ? nm2 * tp.n_grp[i] : tp.n1[i]);
+                const bool same_t = (i == it.t) && (it.m >= 0);
+                const int pl = lane - first;
+                if (pl >= 0 && pl < npl) {
+                    if (frozen) {
+                        const int ng = tp.n_grp[i];
+                        const int m2 = nm2 == 1 ? 0 : pl / ng;
+                        const int4 gr = s_grp[tp.grp_off[i] + (pl - m2 * ng)];
+                        e_off = tp.seg_off[i] + m2 * tp.n1[i] + gr.x;
+                        e_cnt = (same_t && m2 == it.m) ? 0 : gr.y;      // an inactive molecule evaluated itself: skipped whole
+                        e_flags = 0;
+                    } else {
+                        e_off = tp.seg_off[i] + pl * tp.cap[i];
+                        e_cnt = (same_t && nm2 == 1) ? 0 : nm2;         // the only molecule of the type is the excluded one
+                        e_flags = same_t ? (1 | ((it.m == 0 ? 1 : 0) << 1)) : 0;   // dummy: a live, never-excluded molecule
+                    }
+                }
+                first += npl;
+            }
+        }
+        const int e_units = (e_cnt + 63) >> 6;
+        int e_incl = e_units;                                        // inclusive scan over the lanes
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(e_incl, off, 64);
+            e_incl += lane >= off ? v : 0;
+        }
+        const int n_units = __builtin_amdgcn_readlane(e_incl, 63);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        w_plane[lane] = make_int4(e_off, e_cnt, e_flags, e_incl - e_units);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // this wave's share: a contiguous range of the work unit's unit sequence (plane changes stay rare)
+        const int u_begin = (int)(((long long)n_units * split) / nsplit), u_end = (int)(((long long)n_units * (split + 1)) / nsplit);
+        // ---- unit generator (scalar state): plane p of the table, chunk c of it
+        int u = u_begin, p = -1, c = 0, cpp = 0;
+        int p_off = 0, p_cnt = 0, p_excl = -1, p_dummy = 0;
+        bool done = u >= u_end;
+        auto load_plane = [&]() {
+            const int4 e = w_plane[p];                               // LDS broadcast read
+            p_off = __builtin_amdgcn_readfirstlane(e.x);
+            p_cnt = __builtin_amdgcn_readfirstlane(e.y);
+            const int fl = __builtin_amdgcn_readfirstlane(e.z);
+            const int us = __builtin_amdgcn_readfirstlane(e.w);
+            p_excl = (fl & 1) ? it.m : -1;
+            p_dummy = fl >> 1;
+            cpp = (p_cnt + 63) >> 6;
+            c = u - us;
+        };
+        if (!done) {
+            // the plane that holds unit u_begin: the last one whose first unit is not beyond it (empty planes excluded)
+            const unsigned long long mk = __ballot(e_units > 0 && (e_incl - e_units) <= u_begin);
+            p = 63 - __builtin_clzll(mk);
+            load_plane();
+        }
+        auto next_unit = [&]() {
+            ++u;
+            ++c;
+            if (u >= u_end) { done = true; return; }
+            while (c >= cpp) {                                       // next non-empty plane
+                ++p;
+                load_plane();
+            }
+        };
+        // a unit's operands, fetched per lane: masked-off lanes (tail of the plane, the excluded molecule) read the
+        // plane's dummy molecule and carry charge 0 and an LJ cutoff of -1
+        auto fetch = [&](double &x, double &y, double &z, double &q, int &ty, bool &ok) {
+            const int m2 = c * 64 + lane;
+            ok = m2 < p_cnt && m2 != p_excl;
+            const int j = p_off + (ok ? m2 : p_dummy);
+            x = px[j]; y = py[j]; z = pz[j];
+            q = tp.slot_q[j];
+            ty = tp.slot_ty[j];
+        };
+
+        double acc[NREG], elj[NST];
+#pragma unroll
+        for (int s = 0; s < NREG; ++s) acc[s] = 0.0;
+#pragma unroll
+        for (int st = 0; st < NST; ++st) elj[st] = 0.0;
+
+        double xn = 0.0, yn = 0.0, zn = 0.0, qn = 0.0;
+        int tyn = 0;
+        bool vn = false;
+        if (!done) fetch(xn, yn, zn, qn, tyn, vn);
+        while (!done) {
+            const double xj = xn, yj = yn, zj = zn;
+            const bool valid = vn;
+            const double wq = (valid && fabs(qn) >= kErrorTol) ? qn : 0.0;       // energy_utils.f90:430
+            const int tyj = __builtin_amdgcn_readfirstlane(tyn);                   // uniform over the unit
+            next_unit();
+            if (!done) fetch(xn, yn, zn, qn, tyn, vn);
+
+            const double rc2l = valid ? bx.rc2 : -1.0;
+            double r2[NREG];
+#pragma unroll
+            for (int s = 0; s < NREG; ++s)
+                r2[s] = FASTW ? image_r2_fast(xj - rx[s], yj - ry[s], zj - rz[s], bx)
+                              : image_r2<false>(xj - rx[s], yj - ry[s], zj - rz[s], bx);
+            if (any_c && __ballot(wq != 0.0) != 0ull) {
+                double g[NREG];
+                bool any_below = false;
+#pragma unroll
+                for (int s = 0; s < NREG; ++s) {
+                    bool below;
+                    g[s] = coul_lds(r2[s], s_coul, bx.coul_idx_base, bx.coul_last_row, below);
+                    any_below = any_below || below;
+                }
+                if (any_below) {   // r < 0.5 A somewhere in the wave: rare slow path
+#pragma unroll
+                    for (int s = 0; s < NREG; ++s)
+                        if (r2[s] < 0.25) g[s] = coul_slow(r2[s], bx.alpha, false);
+                }
+#pragma unroll
+                for (int s = 0; s < NREG; ++s) acc[s] = fma(wq, g[s], acc[s]);
+            }
+            // (4 epsilon, sigma^2) of every site against this unit's atom type: LDS broadcast reads, requested together
+            double2 pt[NTY];
+            bool lj_on[NTY];
+#pragma unroll
+            for (int s = 0; s < NTY; ++s) pt[s] = s_pair[rty[s] + tyj];
+#pragma unroll
+            for (int s = 0; s < NTY; ++s)
+                lj_on[s] = (__builtin_amdgcn_readfirstlane(__double2hiint(pt[s].x)) | __builtin_amdgcn_readfirstlane(__double2loint(pt[s].x))) != 0;
+#pragma unroll
+            for (int s = 0; s < NTY; ++s) {
+                if (!lj_on[s]) continue;                                           // epsilon = 0 contributes 0
+#pragma unroll
+                for (int st = 0; st < NST; ++st) {
+                    const double rr = r2[st * NTY + s];
+                    const double s2 = pt[s].y * fast_rcp(rr);
+                    const double s6 = s2 * s2 * s2;
+                    const double e = pt[s].x * fma(s6, s6, -s6);                  // energy_utils.f90:421-423
+                    elj[st] += (rr < rc2l) ? e : 0.0;                              // energy_utils.f90:417
+                }
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            double ec = 0.0;
+#pragma unroll
+            for (int s = 0; s < NTY; ++s) ec = fma(rq[s], acc[st * NTY + s], ec);
+            const double a = wave_sum(elj[st]), b = wave_sum(ec);
+            if (lane == 0) partials[(size_t)w * NST + st] = make_double2(a, b);
         }
     }
 }
@@ -527,19 +833,37 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x));
 }
 
-// theta = 2 pi * reciprocal^T r (ComputeAtomPhase, ewald_phase.f90:41-64)
+#ifndef MGPU_PHASE_SINCOSPI
+#define MGPU_PHASE_SINCOSPI 0
+#endif
+// Fractional coordinate f = reciprocal^T r along one axis: ComputeAtomPhase's theta is 2 pi f (ewald_phase.f90:41-64;
+// the same sum in the same association order, without the final factor).
 __device__ __forceinline__ double atom_phase(const BoxDev &bx, int axis, double x, double y, double z) {
     double acc = 0.0;
     acc = acc + bx.rcp[0 * 3 + axis] * x;
     acc = acc + bx.rcp[1 * 3 + axis] * y;
     acc = acc + bx.rcp[2 * 3 + axis] * z;
+#if MGPU_PHASE_SINCOSPI
+    return acc;
+#else
     return kTwoPi * acc;
+#endif
 }
 
-// exp(i k theta) by direct cos / sin of k*theta, as ComputePhaseFactors1D does (ewald_phase.f90:100-109)
+// exp(i k theta), theta = 2 pi f: dcos / dsin of the rounded product k * theta, as ComputePhaseFactors1D
+// (ewald_phase.f90:100-109) -- the default.  MGPU_PHASE_SINCOSPI = 1 evaluates the same phase as sincospi(2 k f) instead
+// (exact argument reduction: k f is rounded once, the doubling is exact, sincospi reduces modulo 2; a third of the
+// instructions of sincos() and 20 SGPRs fewer; both forms carry one rounding of the phase, <= 4e-15 rad at the k of a
+// 50 A box, and differ from each other by that much: < 1e-9 K on a reciprocal energy, every parity test passes with
+// it).  Measured on MI355X (round 3, 2048 items per launch): k sweep 27.4 vs 27.3 us at the SPC/E box, 30.8 vs 31.0 us at
+// the CO2 box -- the table phase is not what the k sweep waits for, so the reference's own form stays.
 __device__ __forceinline__ double2 phase_entry(double theta, int k) {
     double s, c;
+#if MGPU_PHASE_SINCOSPI
+    sincospi(2.0 * ((double)k * theta), &s, &c);      // theta is the fractional coordinate f here
+#else
     sincos((double)k * theta, &s, &c);
+#endif
     return make_double2(c, s);
 }
 
@@ -714,8 +1038,11 @@ struct AcceptBits {
 #ifndef MGPU_RECIP_MINWAVES
 #define MGPU_RECIP_MINWAVES 4   // <= 128 VGPRs: four 4-wave workgroups per CU, 1024 items resident at once
 #endif
+#ifndef MGPU_RECIP_PREFETCH
+#define MGPU_RECIP_PREFETCH 0   // bit 0 (k sweep) / bit 1 (commit): touch A(k) ahead of the phase tables (see recip_rows_kernel)
+#endif
 #ifndef MGPU_RECIP_EARLY_LOAD
-#define MGPU_RECIP_EARLY_LOAD 0   // 1: request the first chunk of A(k) before the phase tables (measured slower, see below)
+#define MGPU_RECIP_EARLY_LOAD 0   // bit 0 (k sweep) / bit 1 (commit): request the first chunk of A(k) before the phase tables (see below)
 #endif
 constexpr int kRecipTaskChunk = 5;
 template <bool COMMIT, bool BOTH>
@@ -771,9 +1098,23 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
             w[c] = (in && !COMMIT) ? tw[t] : make_double2(0.0, 0.0);
         }
     };
-#if MGPU_RECIP_EARLY_LOAD
-    load_chunk(threadIdx.x);
-#endif
+    constexpr bool kEarly = ((MGPU_RECIP_EARLY_LOAD) >> (COMMIT ? 1 : 0)) & 1;
+    if constexpr (kEarly) load_chunk(threadIdx.x);
+    // MGPU_RECIP_PREFETCH (bit 0: k sweep, bit 1: commit): touch one dword of every 128-byte line of this replica's A(k)
+    // right after the site coordinates have been requested, so that HBM delivers A into L2 / Infinity Cache while the
+    // phase tables are built; the values are only consumed at the very end (two live VGPRs), and loads return in
+    // order, so nothing in between waits for them.
+    constexpr bool kPrefetch = ((MGPU_RECIP_PREFETCH) >> (COMMIT ? 1 : 0)) & 1;
+    unsigned pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;
+    [[maybe_unused]] auto prefetch_A = [&]() {
+        const volatile unsigned *line = reinterpret_cast<const volatile unsigned *>(A);
+        const int n_lines = (bx.n_slots * 16 + 127) >> 7;
+        const int l0 = threadIdx.x;
+        if (l0 < n_lines) pf0 = line[l0 * 32];
+        if (l0 + kBlock < n_lines) pf1 = line[(l0 + kBlock) * 32];
+        if (l0 + 2 * kBlock < n_lines) pf2 = line[(l0 + 2 * kBlock) * 32];
+        if (l0 + 3 * kBlock < n_lines) pf3 = line[(l0 + 3 * kBlock) * 32];
+    };
 
     // phase 1: entry (s = set * n1 + a, axis, k >= 0) at s_tab[s * ktot + kofs[axis] + k]
     for (int e = threadIdx.x; e < nss * ktot; e += kBlock) {
@@ -781,17 +1122,21 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
         const int set = s >= n1 ? 1 : 0, a = s - set * n1;
         const int axis = (kk >= kofs[2]) ? 2 : (kk >= kofs[1] ? 1 : 0);
         // an unused site set still gets finite entries: phase 3 multiplies them by XY = 0
-        if ((set == 0 && !use_new) || (set == 1 && !use_old)) { s_tab[e] = make_double2(0.0, 0.0); continue; }
-        double x, y, z;
-        if (set == 0) {
-            const double *c = cand_sites + ((size_t)it.src * site_stride + a) * 3;
-            x = c[0]; y = c[1]; z = c[2];
-        } else {
-            const int j = atom_slot(tp, it.t, it.m, a);
-            x = px[j]; y = py[j]; z = pz[j];
+        const bool used = !((set == 0 && !use_new) || (set == 1 && !use_old));
+        double x = 0.0, y = 0.0, z = 0.0;
+        if (used) {
+            if (set == 0) {
+                const double *c = cand_sites + ((size_t)it.src * site_stride + a) * 3;
+                x = c[0]; y = c[1]; z = c[2];
+            } else {
+                const int j = atom_slot(tp, it.t, it.m, a);
+                x = px[j]; y = py[j]; z = pz[j];
+            }
         }
-        s_tab[e] = phase_entry(atom_phase(bx, axis, x, y, z), kk - kofs[axis]);
+        if constexpr (kPrefetch) { if (e == (int)threadIdx.x) prefetch_A(); }
+        s_tab[e] = used ? phase_entry(atom_phase(bx, axis, x, y, z), kk - kofs[axis]) : make_double2(0.0, 0.0);
     }
+    if constexpr (kPrefetch) { if ((int)threadIdx.x >= nss * ktot) prefetch_A(); }
     for (int a = threadIdx.x; a < n1; a += kBlock) s_q[a] = res_q[it.t * tp.max_atom + a];
     __syncthreads();
 
@@ -817,7 +1162,7 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
     const double2 *zt = s_tab + kofs[2];
     double acc = 0.0, acc0 = 0.0;
     for (int t0 = threadIdx.x; t0 < n_tasks; t0 += kBlock * kRecipTaskChunk) {
-        if (!MGPU_RECIP_EARLY_LOAD || t0 != (int)threadIdx.x) load_chunk(t0);
+        if (!kEarly || t0 != (int)threadIdx.x) load_chunk(t0);
 #pragma unroll
         for (int c = 0; c < kRecipTaskChunk; ++c) {
             const double2 *xy = s_xy + ((rj[c] >> 8) & 0xfffff) * nss;
@@ -846,6 +1191,10 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
         }
     }
 
+    if constexpr (kPrefetch) {
+        // keep the prefetch registers alive up to here: an empty statement that reads them
+        asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3));
+    }
     if (!COMMIT) {
         acc = wave_sum(acc);
         if (BOTH) acc0 = wave_sum(acc0);

@@ -208,6 +208,14 @@ module maniac_gpu
             integer(c_int), intent(in) :: replica(*), t(*), m(*), kind(*), accept(*)
             integer(c_int) :: rc
         end function
+        ! pinned staging of a lane's next trial: candidate rows built in place are not copied again
+        function mgpu_lane_site_buffer(e, lane, n_max, site_stride, sites) bind(C, name="mgpu_lane_site_buffer") result(rc)
+            import :: c_ptr, c_int
+            type(c_ptr), value :: e
+            integer(c_int), value :: lane, n_max, site_stride
+            type(c_ptr), intent(out) :: sites
+            integer(c_int) :: rc
+        end function
         ! mixed batches (moves, insertions, deletions); energies come back as rows of 5
         function mgpu_gcmc_trial_submit(e, lane, n, replica, t, m, kind, sites, site_stride) &
                 bind(C, name="mgpu_gcmc_trial_submit") result(rc)

@@ -42,7 +42,8 @@ module mc_chain
     public :: mchain_reset, mchain_set_box, mchain_set_residue, mchain_set_bonded, mchain_set_tables, &
               mchain_set_moves, mchain_set_reservoir_box, mchain_set_reservoir_residue, mchain_run, &
               mchain_get_energy, mchain_get_counters, mchain_get_counts, mchain_get_molecule, mchain_get_steps, &
-              mchain_set_mode, mchain_set_as_written, mchain_set_log_header, mchain_write_log_header
+              mchain_set_mode, mchain_set_as_written, mchain_set_log_header, mchain_write_log_header, &
+              mchain_set_speculation
 
     real(real64), parameter :: PI = 3.14159265358979323846_real64, TWOPI = 2.0_real64 * PI
     real(real64), parameter :: zero = 0.0_real64, one = 1.0_real64, half = 0.5_real64, three = 3.0_real64
@@ -65,6 +66,26 @@ module mc_chain
     ! the messages the reference logs before the Monte Carlo loop (banner, input echo, data-file summary,
     ! Lorentz-Berthelot listing, Ewald parameters), one per line, prepared by the front end (io_maniac.log_header_lines)
     character(len=:), allocatable, save :: log_header
+    ! Speculative window (fused mode): the next spec_k steps are drawn in the reference's random-number order ASSUMING
+    ! every one of them is rejected -- the state then does not change, so all their trials are trials from the current
+    ! state and are evaluated in ONE batched engine call.  The window is then walked in order with the saved acceptance
+    ! draws; the first accepted step is applied, the generator is put back to its state right after that step's draws
+    ! and the rest of the window is thrown away.  Visited states, random stream and files are those of the sequential
+    ! loop; the engine round trips per step drop by up to 1 / acceptance.  spec_k = 1: the sequential loop.
+    integer, save :: spec_k = 1
+    integer, parameter :: STEP_NOOP = -1, STEP_ABORT = -2
+
+    type :: proposal
+        integer :: t = 0, m = 0, kind = STEP_NOOP, mtype = 0
+        integer :: cand = 0, cand2 = 0                  ! rows of the batch (cand2: the second row of an as-written deletion)
+        integer :: pick = 0                             ! reservoir molecule an insertion copies
+        real(real64) :: com(3) = 0.0_real64, u = 0.0_real64
+        real(real64), allocatable :: off(:, :)          ! (3, n1)
+        integer, allocatable :: rng(:)                  ! generator state after the step's draws
+    end type proposal
+    ! the window's candidate list as handed to the engine (kept for the resident-row commit)
+    integer(c_int), allocatable, save :: w_rep(:), w_t(:), w_m(:), w_kind(:), w_acc(:)
+    integer, save :: w_stride = 1
 
 contains
 
@@ -402,6 +423,12 @@ contains
         close(tmp%log_unit)
     end subroutine mchain_write_log_header
 
+    ! k > 1: speculative windows of k steps in the batched (non-seams) mode; k <= 1: one step at a time
+    subroutine mchain_set_speculation(k) bind(C, name="mchain_set_speculation")
+        integer(c_int), value :: k
+        spec_k = max(1, min(int(k), 64))
+    end subroutine mchain_set_speculation
+
     subroutine mchain_set_as_written(on) bind(C, name="mchain_set_as_written")
         integer(c_int), value :: on
         as_written = on /= 0
@@ -686,6 +713,322 @@ contains
         end if
     end subroutine delete_molecule
 
+
+    !---------------------------------------------------------------------------
+    ! Speculative window.  propose_step draws one step's random numbers exactly as the loop body of MonteCarloLoop and
+    ! the move drivers draw them (type, molecule, move, [insertion / deletion], displacement | angle then axis | position
+    ! then pick / angle then axis, acceptance) and builds the trial geometry WITHOUT touching the chain's state.
+    !---------------------------------------------------------------------------
+    subroutine propose_step(p)
+        type(proposal), intent(out) :: p
+        integer :: t, m, n1, axis, nseed
+        real(real64) :: draw, trial(3), theta, rot(3, 3), u
+        t = pick_residue_type()
+        m = pick_molecule_index(S%res(t)%count)
+        draw = rand_uniform()
+        n1 = S%res(t)%n1
+        p%t = t
+        p%m = m
+        p%kind = STEP_NOOP
+        if (draw <= S%p_translation) then
+            if (m /= 0) then                                             ! Translation returns at once for an empty type
+                p%mtype = TYPE_TRANSLATION
+                p%kind = MGPU_MOVE
+                call random_number(trial)
+                trial = (trial - half) * S%translation_step
+                p%com = S%res(t)%com(:, m) + trial
+                call apply_pbc(p%com, S%box)
+                p%off = S%res(t)%off(:, 1:n1, m)
+                p%u = rand_uniform()
+            end if
+        else if (draw <= S%p_rotation + S%p_translation) then
+            if (n1 /= 1 .and. m /= 0) then
+                p%mtype = TYPE_ROTATION
+                p%kind = MGPU_MOVE
+                p%com = S%res(t)%com(:, m)
+                theta = (rand_uniform() - half) * S%rotation_step        ! ApplyRandomRotation: angle, then axis
+                axis = int(rand_uniform() * three) + 1
+                rot = axis_rotation(axis, theta)
+                p%off = matmul(rot, S%res(t)%off(:, 1:n1, m))
+                p%u = rand_uniform()
+            end if
+        else
+            if (rand_uniform() <= PROB_CREATE_DELETE) then
+                m = S%res(t)%count + 1
+                p%m = m
+                p%mtype = TYPE_CREATION
+                if (m > NB_MAX_MOLECULE .or. m > S%res(t)%cap) then     ! CheckMoleculeIndex aborts the reference here
+                    p%kind = STEP_ABORT
+                else
+                    p%kind = MGPU_CREATION
+                    call random_number(trial)
+                    p%com = S%box%lo + matmul(S%box%matrix, trial)
+                    if (S%has_reservoir) then
+                        call random_number(u)
+                        p%pick = int(u * S%rsv(t)%count) + 1
+                        p%off = S%rsv(t)%off(:, 1:n1, p%pick)
+                    else
+                        p%off = S%res(t)%off(:, 1:n1, 1)
+                        if (n1 /= 1) then
+                            theta = rand_uniform() * TWOPI
+                            axis = int(rand_uniform() * three) + 1
+                            rot = axis_rotation(axis, theta)
+                            p%off = matmul(rot, p%off)
+                        end if
+                    end if
+                    p%u = rand_uniform()
+                end if
+            else
+                if (S%res(t)%count /= 0) then                            ! DeleteMolecule returns for an empty type
+                    p%mtype = TYPE_DELETION
+                    p%kind = MGPU_DELETION
+                    p%com = S%res(t)%com(:, m)
+                    p%off = S%res(t)%off(:, 1:n1, m)
+                    p%u = rand_uniform()
+                end if
+            end if
+        end if
+        call random_seed(size=nseed)
+        allocate(p%rng(nseed))
+        call random_seed(get=p%rng)
+    end subroutine propose_step
+
+    ! Walk one evaluated step: o / w = the engine's old / new rows of its candidate (w2: the second row of an as-written
+    ! deletion).  Mirrors the part of Translation / Rotation / CreateMolecule / DeleteMolecule that follows the energy
+    ! evaluation; `restore` = the generator must be put back to this step's state before anything else is drawn.
+    subroutine resolve_step(p, o, w, w2, n_cand, restore, accepted)
+        type(proposal), intent(in) :: p
+        real(real64), intent(in) :: o(5), w(5), w2(5)
+        integer, intent(in) :: n_cand
+        logical, intent(in) :: restore
+        logical, intent(out) :: accepted
+        real(real64) :: old(6), new(6), prob, trial(3)
+        real(real64), allocatable :: off_last(:, :), sites_last(:, :)
+        integer :: t, m, n1, last, stat
+        t = p%t
+        m = p%m
+        n1 = S%res(t)%n1
+        old = zero
+        new = zero
+        accepted = .false.
+        select case (p%mtype)
+        case (TYPE_TRANSLATION, TYPE_ROTATION)
+            if (p%mtype == TYPE_TRANSLATION) then
+                S%counter(C_TRIAL_T) = S%counter(C_TRIAL_T) + 1
+            else
+                S%counter(C_TRIAL_R) = S%counter(C_TRIAL_R) + 1
+            end if
+            old(1:3) = o(1:3)
+            new(1:3) = w(1:3)
+            old(IE_TOTAL) = old(IE_NONC) + old(IE_COUL) + old(IE_RECIP)
+            new(IE_TOTAL) = new(IE_NONC) + new(IE_COUL) + new(IE_RECIP)
+            prob = acceptance_probability(old, new, t, p%mtype)
+            if (p%u <= prob) then
+                accepted = .true.
+                if (restore) call random_seed(put=p%rng)
+                if (p%mtype == TYPE_TRANSLATION) then
+                    S%res(t)%com(:, m) = p%com
+                else
+                    S%res(t)%off(:, 1:n1, m) = p%off
+                end if
+                S%energy(IE_RECIP) = S%energy(IE_RECIP) + new(IE_RECIP) - old(IE_RECIP)
+                S%energy(IE_NONC) = S%energy(IE_NONC) + new(IE_NONC) - old(IE_NONC)
+                S%energy(IE_COUL) = S%energy(IE_COUL) + new(IE_COUL) - old(IE_COUL)
+                S%energy(IE_TOTAL) = S%energy(IE_TOTAL) + new(IE_TOTAL) - old(IE_TOTAL)
+                if (p%mtype == TYPE_TRANSLATION) then
+                    S%counter(C_T) = S%counter(C_T) + 1
+                else
+                    S%counter(C_R) = S%counter(C_R) + 1
+                end if
+                call window_commit(p, n_cand)
+            end if
+        case (TYPE_CREATION)
+            S%counter(C_TRIAL_C) = S%counter(C_TRIAL_C) + 1
+            old(IE_RECIP) = S%energy(IE_RECIP)
+            new(1:5) = w
+            old(IE_TOTAL) = old(IE_NONC) + old(IE_COUL) + old(IE_RECIP) + old(IE_SELF) + old(IE_INTRA)
+            new(IE_TOTAL) = new(IE_NONC) + new(IE_COUL) + new(IE_RECIP) + new(IE_SELF) + new(IE_INTRA)
+            S%res(t)%count = S%res(t)%count + 1
+            S%box%num_atoms = S%box%num_atoms + n1
+            prob = acceptance_probability(old, new, t, TYPE_CREATION)
+            if (p%u <= prob) then
+                accepted = .true.
+                if (restore) call random_seed(put=p%rng)
+                S%res(t)%com(:, m) = p%com
+                S%res(t)%off(:, 1:n1, m) = p%off
+                S%energy(IE_RECIP) = new(IE_RECIP)
+                S%energy(IE_NONC) = S%energy(IE_NONC) + new(IE_NONC) - old(IE_NONC)
+                S%energy(IE_COUL) = S%energy(IE_COUL) + new(IE_COUL) - old(IE_COUL)
+                S%energy(IE_SELF) = S%energy(IE_SELF) + new(IE_SELF) - old(IE_SELF)
+                S%energy(IE_INTRA) = S%energy(IE_INTRA) + new(IE_INTRA) - old(IE_INTRA)
+                S%energy(IE_TOTAL) = S%energy(IE_TOTAL) + new(IE_TOTAL) - old(IE_TOTAL)
+                S%counter(C_C) = S%counter(C_C) + 1
+                call window_commit(p, n_cand)
+                if (S%has_reservoir) then
+                    last = S%rsv(t)%count
+                    S%rsv(t)%com(:, p%pick) = S%rsv(t)%com(:, last)
+                    S%rsv(t)%off(:, 1:n1, p%pick) = S%rsv(t)%off(:, 1:n1, last)
+                    S%rsv(t)%count = S%rsv(t)%count - 1
+                    S%rbox%num_atoms = S%rbox%num_atoms - n1
+                end if
+            else
+                S%box%num_atoms = S%box%num_atoms - n1
+                S%res(t)%count = S%res(t)%count - 1
+            end if
+        case (TYPE_DELETION)
+            S%counter(C_TRIAL_D) = S%counter(C_TRIAL_D) + 1
+            old(1:5) = o
+            old(IE_RECIP) = S%energy(IE_RECIP)
+            new(IE_RECIP) = w(IE_RECIP)
+            if (as_written) new(IE_RECIP) = w2(IE_RECIP)                  ! creation-kind energy of the swapped-in molecule (F3)
+            old(IE_TOTAL) = old(IE_NONC) + old(IE_COUL) + old(IE_RECIP) + old(IE_SELF) + old(IE_INTRA)
+            new(IE_TOTAL) = new(IE_NONC) + new(IE_COUL) + new(IE_RECIP) + new(IE_SELF) + new(IE_INTRA)
+            last = S%res(t)%count
+            S%res(t)%count = S%res(t)%count - 1
+            S%box%num_atoms = S%box%num_atoms - n1
+            prob = acceptance_probability(old, new, t, TYPE_DELETION)
+            if (p%u <= prob) then
+                accepted = .true.
+                if (restore) call random_seed(put=p%rng)
+                off_last = S%res(t)%off(:, :, last)
+                S%res(t)%com(:, m) = S%res(t)%com(:, last)                ! RemoveMolecule: slot m <- the last slot
+                S%res(t)%off(:, :, m) = S%res(t)%off(:, :, last)
+                S%energy(IE_RECIP) = new(IE_RECIP)
+                S%energy(IE_NONC) = S%energy(IE_NONC) + new(IE_NONC) - old(IE_NONC)
+                S%energy(IE_COUL) = S%energy(IE_COUL) + new(IE_COUL) - old(IE_COUL)
+                S%energy(IE_SELF) = S%energy(IE_SELF) + new(IE_SELF) - old(IE_SELF)
+                S%energy(IE_INTRA) = S%energy(IE_INTRA) + new(IE_INTRA) - old(IE_INTRA)
+                S%energy(IE_TOTAL) = S%energy(IE_TOTAL) + new(IE_TOTAL) - old(IE_TOTAL)
+                S%counter(C_D) = S%counter(C_D) + 1
+                if (as_written) then
+                    allocate(sites_last(3, n1))
+                    call MoleculeSites(S%res(t)%com(:, m), S%res(t)%off(:, 1:n1, m), n1, sites_last)
+                    stat = mgpu_replica_replace_molecule(S%engine, 0_c_int, int(t - 1, c_int), int(m - 1, c_int), int(last - 1, c_int))
+                    call note(stat)
+                    stat = mgpu_replica_set_num_molecules(S%engine, 0_c_int, int(t - 1, c_int), int(last - 1, c_int))
+                    call note(stat)
+                    stat = mgpu_structure_factor_add(S%engine, 0_c_int, int(t - 1, c_int), sites_last)
+                    call note(stat)
+                    deallocate(sites_last)
+                else
+                    call window_commit(p, n_cand)
+                end if
+                if (S%has_reservoir) then
+                    call random_number(trial)
+                    trial = trial - half
+                    associate (r => S%rsv(t))
+                        if (r%count + 1 <= r%cap) then
+                            r%com(:, r%count + 1) = trial(1) * S%rbox%matrix(:, 1) + trial(2) * S%rbox%matrix(:, 2) + &
+                                                    trial(3) * S%rbox%matrix(:, 3)
+                            r%off(:, 1:n1, r%count + 1) = off_last(:, 1:n1)
+                            r%count = r%count + 1
+                            S%rbox%num_atoms = S%rbox%num_atoms + n1
+                        else
+                            call note(4)
+                        end if
+                    end associate
+                end if
+            else
+                S%res(t)%count = S%res(t)%count + 1
+                S%box%num_atoms = S%box%num_atoms + n1
+            end if
+        end select
+    end subroutine resolve_step
+
+    ! apply candidate p%cand of the window's batch from the rows still resident on the lane
+    subroutine window_commit(p, n_cand)
+        type(proposal), intent(in) :: p
+        integer, intent(in) :: n_cand
+        integer(c_int) :: rc
+        w_acc(1:n_cand) = 0
+        w_acc(p%cand) = 1
+        rc = mgpu_commit_submit(S%engine, 0_c_int, int(n_cand, c_int), w_rep, w_t, w_m, w_kind, c_null_ptr, &
+                                int(w_stride, c_int), w_acc)
+        call note(int(rc))
+    end subroutine window_commit
+
+    ! Propose up to kwin steps, evaluate them in one batched call, walk them; returns the number of steps consumed.
+    function run_window(kwin) result(done)
+        integer, intent(in) :: kwin
+        integer :: done
+        type(proposal), allocatable :: P(:)
+        real(real64), allocatable :: sites(:, :, :), o(:, :), w(:, :)
+        real(real64) :: none5(5)
+        integer :: j, n_prop, n_cand, t, n1, c, last, mx
+        integer(c_int) :: rc
+        logical :: accepted
+        mx = 1
+        do t = 1, S%n_res
+            mx = max(mx, S%res(t)%n1)
+        end do
+        allocate(P(kwin))
+        if (.not. allocated(w_rep)) then
+            allocate(w_rep(128), w_t(128), w_m(128), w_kind(128), w_acc(128))
+        end if
+        allocate(sites(3, mx, 2 * kwin), o(5, 2 * kwin), w(5, 2 * kwin))
+        sites = zero
+        w_stride = mx
+        n_prop = 0
+        n_cand = 0
+        do j = 1, kwin
+            call propose_step(P(j))
+            n_prop = j
+            if (P(j)%kind == STEP_ABORT) exit
+            if (P(j)%kind == STEP_NOOP) cycle
+            t = P(j)%t
+            n1 = S%res(t)%n1
+            n_cand = n_cand + 1
+            P(j)%cand = n_cand
+            w_rep(n_cand) = 0
+            w_t(n_cand) = t - 1
+            w_m(n_cand) = P(j)%m - 1
+            if (P(j)%kind == MGPU_CREATION) w_m(n_cand) = -1
+            w_kind(n_cand) = P(j)%kind
+            call MoleculeSites(P(j)%com, P(j)%off, n1, sites(:, 1:n1, n_cand))
+            if (P(j)%kind == MGPU_DELETION .and. as_written) then
+                ! F3: the reciprocal update runs with is_creation on the molecule RemoveMolecule moves into slot m
+                last = S%res(t)%count
+                n_cand = n_cand + 1
+                P(j)%cand2 = n_cand
+                w_rep(n_cand) = 0
+                w_t(n_cand) = t - 1
+                w_m(n_cand) = -1
+                w_kind(n_cand) = MGPU_CREATION
+                call MoleculeSites(S%res(t)%com(:, last), S%res(t)%off(:, 1:n1, last), n1, sites(:, 1:n1, n_cand))
+            end if
+        end do
+        if (n_cand > 0) then
+            rc = mgpu_gcmc_trial_submit(S%engine, 0_c_int, int(n_cand, c_int), w_rep, w_t, w_m, w_kind, sites, int(mx, c_int))
+            if (rc == MGPU_OK) rc = mgpu_gcmc_trial_wait(S%engine, 0_c_int, o, w)
+            call note(int(rc))
+        end if
+        none5 = zero
+        done = n_prop
+        do j = 1, n_prop
+            if (status /= 0) then
+                done = j - 1
+                exit
+            end if
+            if (P(j)%kind == STEP_ABORT) then
+                call note(4)
+                done = j
+                exit
+            end if
+            if (P(j)%kind == STEP_NOOP) cycle
+            c = P(j)%cand
+            if (P(j)%cand2 > 0) then
+                call resolve_step(P(j), o(:, c), w(:, c), w(:, P(j)%cand2), n_cand, j < n_prop, accepted)
+            else
+                call resolve_step(P(j), o(:, c), w(:, c), none5, n_cand, j < n_prop, accepted)
+            end if
+            if (accepted) then
+                done = j
+                exit
+            end if
+        end do
+        done = max(done, 1)
+    end function run_window
+
     ! AdjustMoveStepSizes, as written -- including the second branches that compare against +TOL and the
     ! rotation step that is multiplied by 1.95 and clamped from above by MIN_ROTATION_ANGLE
     subroutine adjust_move_step_sizes()
@@ -773,7 +1116,14 @@ contains
         call update_files(S, .false.)
         do while (S%current_block < nb_block .and. status == 0)
             S%current_block = S%current_block + 1
-            do step = 1, nb_step
+            step = 1
+            do while (step <= nb_step)
+                if (fused .and. spec_k > 1) then
+                    ! a window never crosses the end of a block (AdjustMoveStepSizes and the files come there)
+                    step = step + run_window(min(spec_k, nb_step - step + 1))
+                    if (status /= 0) exit
+                    cycle
+                end if
                 t = pick_residue_type()
                 m = pick_molecule_index(S%res(t)%count)
                 draw = rand_uniform()
@@ -790,6 +1140,7 @@ contains
                     end if
                 end if
                 if (status /= 0) exit
+                step = step + 1
             end do
             call adjust_move_step_sizes()
             call log_status(S)

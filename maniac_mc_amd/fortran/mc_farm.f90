@@ -67,7 +67,10 @@ module mc_farm
         integer(c_int), allocatable :: rep(:), t(:), m(:), kind(:), accept(:)
         integer, allocatable :: ia(:), move(:), cidx(:)    ! active-type index, move code, chain index
         integer, allocatable :: sel_ia(:), sel_mv(:), sel_slot(:)   ! per chain: the selection (slot 0 = no-op)
-        real(real64), allocatable :: sites(:, :, :)        ! (3, max_n1, n)
+        ! (3, max_n1, n) candidate rows: built straight in the engine's pinned staging block of the lane
+        ! (mgpu_lane_site_buffer), or in sites_own where that is not available
+        real(real64), pointer :: sites(:, :, :) => null()
+        real(real64), allocatable :: sites_own(:, :, :)
         real(real64), allocatable :: new_com(:, :), new_off(:, :, :)
         real(real64), allocatable :: old_e(:), new_e(:)    ! (ne * nc) rows packed by the engine
         real(real64), allocatable :: u(:, :)
@@ -284,7 +287,7 @@ contains
             F%lane(g)%first = min(g * per, n_replicas)
             F%lane(g)%n = max(0, min(per, n_replicas - g * per))
             F%lane(g)%nc = 0
-            call alloc_lane(F%lane(g), max(1, F%lane(g)%n), max_n1)
+            call alloc_lane(F%lane(g), max(1, F%lane(g)%n), int(max_n1), g)
         end do
         F%ready = .true.
     end function mfarm_create
@@ -329,13 +332,22 @@ contains
         F%gcmc = .true.
     end function mfarm_set_gcmc
 
-    subroutine alloc_lane(L, n, max_n1)
-        type(lane_buffers), intent(inout) :: L
-        integer, intent(in) :: n, max_n1
+    subroutine alloc_lane(L, n, max_n1, g)
+        type(lane_buffers), intent(inout), target :: L
+        integer, intent(in) :: n, max_n1, g
+        type(c_ptr) :: staged
+        integer(c_int) :: rc
         allocate(L%rep(n), L%t(n), L%m(n), L%kind(n), L%accept(n), L%ia(n), L%move(n), L%cidx(n))
         allocate(L%sel_ia(n), L%sel_mv(n), L%sel_slot(n))
-        allocate(L%sites(3, max_n1, n), L%new_com(3, n), L%new_off(3, max_n1, n))
+        allocate(L%new_com(3, n), L%new_off(3, max_n1, n))
         allocate(L%old_e(5 * n), L%new_e(5 * n), L%u(NRAND, n))
+        rc = mgpu_lane_site_buffer(F%engine, int(g, c_int), int(n, c_int), int(max_n1, c_int), staged)
+        if (rc == MGPU_OK .and. c_associated(staged)) then
+            call c_f_pointer(staged, L%sites, [3, max_n1, n])
+        else
+            allocate(L%sites_own(3, max_n1, n))
+            L%sites => L%sites_own
+        end if
         L%sites = 0.0_real64
         L%kind = MGPU_MOVE
     end subroutine alloc_lane
@@ -354,8 +366,10 @@ contains
             if (allocated(F%lane(g)%rep)) then
                 deallocate(F%lane(g)%rep, F%lane(g)%t, F%lane(g)%m, F%lane(g)%kind, F%lane(g)%accept, &
                            F%lane(g)%ia, F%lane(g)%move, F%lane(g)%cidx, F%lane(g)%sel_ia, F%lane(g)%sel_mv, &
-                           F%lane(g)%sel_slot, F%lane(g)%sites, F%lane(g)%new_com, &
+                           F%lane(g)%sel_slot, F%lane(g)%new_com, &
                            F%lane(g)%new_off, F%lane(g)%old_e, F%lane(g)%new_e, F%lane(g)%u)
+                if (allocated(F%lane(g)%sites_own)) deallocate(F%lane(g)%sites_own)
+                nullify(F%lane(g)%sites)
             end if
         end do
         F%ready = .false.

@@ -67,7 +67,7 @@ def header_text(inp, dat, maniac_path, data_path, inc_path, eng_or_ewald, reserv
 
 
 def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoir_path=None, device=0,
-                   mol_capacity=None, nb_block=None, nb_step=None, seams=False, as_written=False):
+                   mol_capacity=None, nb_block=None, nb_step=None, seams=False, as_written=False, speculate=8):
     """Run the chain; returns a dict with the final energies (K), counters, molecule counts, step sizes.
 
     ``seed``: None -> the input file's ``seed`` if present, else the generator is left unseeded
@@ -78,6 +78,10 @@ def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoi
     ``as_written``: True -> the reference's deletion update exactly as written (A(k) gains the swapped-in
     molecule's terms, monte_carlo_utils.f90:308), composed in the host loop from neutral engine primitives; for
     charged grand-canonical runs this reproduces the reference's files but not the intended physics (default False).
+    ``speculate``: K > 1 (default 8; batched mode only) -> the next K steps are drawn in the reference's random-number
+    order assuming every one is rejected and evaluated in ONE engine call; the first accepted one is applied, the
+    generator is put back to its state after that step and the rest is redrawn.  Same states, same files, up to
+    1 / acceptance fewer round trips.  1 -> one step per engine call.
     """
     system, inp, dat = io_maniac.load_system(maniac_path, data_path, inc_path, with_data=True)
     rdat = io_maniac.read_lammps_data(reservoir_path, inp) if reservoir_path else None
@@ -116,6 +120,7 @@ def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoi
         H.mchain_set_tables(masses.ctypes.data_as(_dp), ntypes.ctypes.data_as(_ip))
         H.mchain_set_mode(C.c_int(1 if seams else 0))
         H.mchain_set_as_written(C.c_int(1 if as_written else 0))
+        H.mchain_set_speculation(C.c_int(1 if seams else max(1, int(speculate))))
         header = header_text(inp, dat, maniac_path, data_path, inc_path, eng, reservoir_path, rdat)
         H.mchain_set_log_header(header, C.c_int(len(header)))
         H.mchain_set_moves(C.c_double(inp.translation_step), C.c_double(inp.rotation_step_angle),
@@ -136,8 +141,11 @@ def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoi
             seed = inp.seed if inp.has_seed else 0
         outdir = os.path.join(outdir, "")
         os.makedirs(outdir, exist_ok=True)
+        import time
+        t_loop = time.perf_counter()
         rc = H.mchain_run(C.c_int(inp.nb_block if nb_block is None else nb_block),
                           C.c_int(inp.nb_step if nb_step is None else nb_step), C.c_int(int(seed)), outdir.encode())
+        t_loop = time.perf_counter() - t_loop       # initial energy + Monte Carlo loop + files
         _lib.check(rc)
         e = np.zeros(6); cnt = np.zeros(8, dtype=np.int32); nm = np.zeros(n_res, dtype=np.int32); st = np.zeros(2)
         H.mchain_get_energy(e.ctypes.data_as(_dp))
@@ -148,7 +156,7 @@ def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoi
     finally:
         eng.close()
     keys = ("non_coulomb", "coulomb", "recip_coulomb", "ewald_self", "intra_coulomb", "total")
-    return dict(energy=dict(zip(keys, e)), recomputed_energy=e_final, counters=cnt, n_mol=nm,
+    return dict(energy=dict(zip(keys, e)), recomputed_energy=e_final, counters=cnt, n_mol=nm, loop_seconds=t_loop,
                 translation_step=st[0], rotation_step=st[1])
 
 
@@ -166,6 +174,8 @@ def main(argv=None):
     ap.add_argument("-o", dest="out", default="outputs/", help="output directory")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--speculate", type=int, default=8,
+                    help="speculative window: steps evaluated per engine call (same states and files; 1: one step per call)")
     ap.add_argument("--as-written", action="store_true",
                     help="the reference's deletion update exactly as written (SURVEY F3) instead of the intended physics")
     a = ap.parse_args(argv)
@@ -174,7 +184,7 @@ def main(argv=None):
             print(f"{what} file not found: {path}", file=sys.stderr)
             return 1
     res = run_simulation(a.maniac, a.data, a.inc, a.out, seed=a.seed, reservoir_path=a.reservoir, device=a.device,
-                         as_written=a.as_written)
+                         as_written=a.as_written, speculate=a.speculate)
     e = res["energy"]
     print(f"final energy (K): total {e['total']:.6f}  non_coulomb {e['non_coulomb']:.6f}  coulomb {e['coulomb']:.6f}  "
           f"recip {e['recip_coulomb']:.6f};  molecules {res['n_mol'].tolist()};  output in {os.path.join(a.out, '')}")

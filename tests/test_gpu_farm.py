@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from maniac_mc_amd import synth
-from tests.util import TOL_K
+from tests.util import TOL_K, farm_tol
 
 pytestmark = pytest.mark.gpu
 
@@ -102,7 +102,7 @@ def test_gcmc_farm_consistency_and_ideal_gas_limit():
         e = eng.system_energy(r)
         run = farm.energy(r)
         ref = np.array([e[k] for k in ("non_coulomb", "coulomb", "recip_coulomb", "ewald_self", "intra_coulomb")])
-        assert np.max(np.abs(run - ref)) < 2e-5 * max(1.0, np.max(np.abs(ref)) * 1e-6), (r, run - ref)
+        assert np.max(np.abs(run - ref)) < farm_tol(ref, 600 + 40 * 40), (r, run - ref)
         A = eng.structure_factor(r)
         eng.init_structure_factor(r, True)
         assert np.max(np.abs(A - eng.structure_factor(r))) < 1e-9
@@ -137,7 +137,7 @@ def test_gcmc_farm_in_a_triclinic_box():
         e = eng.system_energy(r)
         run = farm.energy(r)
         ref = np.array([e[k] for k in ("non_coulomb", "coulomb", "recip_coulomb", "ewald_self", "intra_coulomb")])
-        assert np.max(np.abs(run - ref)) < 2e-5 * max(1.0, np.max(np.abs(ref)) * 1e-6), (r, run - ref)
+        assert np.max(np.abs(run - ref)) < farm_tol(ref, 300), (r, run - ref)
         for ia in range(2):
             assert eng.num_molecules(r, ia) == counts[r, ia]
             dev = eng.get_molecules(r, ia)
@@ -195,7 +195,7 @@ def test_gcmc_farm_framework_water_at_stated_size():
         e = eng.system_energy(r)
         run = farm.energy(r)
         ref = np.array([e[k] for k in ("non_coulomb", "coulomb", "recip_coulomb", "ewald_self", "intra_coulomb")])
-        assert np.max(np.abs(run - ref)) < 2e-5 * max(1.0, np.max(np.abs(ref)) * 1e-6), (r, run - ref)
+        assert np.max(np.abs(run - ref)) < farm_tol(ref, 400), (r, run - ref)
         A = eng.structure_factor(r)
         eng.init_structure_factor(r, True)
         assert np.max(np.abs(A - eng.structure_factor(r))) < 1e-9
@@ -223,3 +223,26 @@ def test_farm_options_keep_the_invariants(env):
                         "test_farm_at_benchmark_size_three_lanes"],
                        capture_output=True, text=True, env=dict(os.environ, **env), cwd=root, timeout=900)
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("gcmc", [False, True], ids=["spce_nvt", "co2_gcmc"])
+def test_long_run_drift(gcmc):
+    """tools/long_run_check.py as a test: ~1 M trials at the benchmark size (SPC/E NVT: 256 chains x 4000 steps on four
+    lanes; CO2 GCMC: 512 chains x 2000 steps), after which every sampled chain's running energies must equal a
+    from-scratch evaluation to the random-walk tolerance of tests/util.py::farm_tol and A(k) a fresh S(k) to 1e-9
+    (round 2 measured 9e-9 K / 5e-13 after 3 M trials)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    steps = 2000 if gcmc else 4000
+    cmd = [sys.executable, os.path.join(root, "tools", "long_run_check.py"), "--steps", str(steps), "--lanes", "4",
+           "--replicas", "512" if gcmc else "256"] + (["--gcmc"] if gcmc else [])
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=root, timeout=1200)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    m = re.search(r"energy\| = ([0-9.e+-]+) K, max \|A - S\(k\)\| = ([0-9.e+-]+), largest \|E\| = ([0-9.e+-]+)", p.stdout)
+    assert m, p.stdout
+    worst_e, worst_a, big = (float(m.group(i)) for i in (1, 2, 3))
+    assert worst_e < farm_tol([big], steps) and worst_a < 1e-9, p.stdout

@@ -591,3 +591,64 @@ def test_fast_fold_is_bitwise_the_exact_fold():
     assert np.array_equal(of, oe) and np.array_equal(nf, ne)
     for e in engines:
         e.close()
+
+
+@pytest.mark.parametrize("make", [lambda: synth.co2_box(40, seed=5), lambda: synth.framework_water_box(n_water=24),
+                                  lambda: synth.mixture_box(seed=6), lambda: synth.five_site_water_box(),
+                                  lambda: synth.spce_box(6, seed=2)],
+                         ids=["co2", "framework_water", "mixture", "water5", "spce216"])
+def test_flat_and_plane_by_plane_sweeps_agree(make, refcpu_mod):
+    """The register-site pair sweep exists twice: pair_flat_kernel (one software-pipelined loop over all units of a work
+    unit; chosen for topologies with short planes or a frozen framework) and pair_sweep_kernel (plane by plane; the
+    10 125-atom box).  Both must give the oracle's energies; here the same grand-canonical batch (moves, insertions,
+    deletions of every active type) is evaluated by two engines created with MGPU_PAIR_FLAT=1 and =0, compared with
+    each other to the parity bar and, for the moves, with the C restatement."""
+    import os
+    s = make()
+    act = [t for t in range(s.topo.n_res) if s.topo.is_active[t]]
+    engines = []
+    for flat in ("1", "0"):
+        os.environ["MGPU_PAIR_FLAT"] = flat
+        try:
+            e = Engine.from_system(s, n_replicas=2)
+        finally:
+            os.environ.pop("MGPU_PAIR_FLAT", None)
+        for r in range(2):
+            e.init_structure_factor(r, True)
+        engines.append(e)
+    rng = np.random.default_rng(3)
+    L = np.diag(s.box_matrix)
+    for t in act:
+        n = int(s.n_mol[t])
+        n1 = int(s.topo.atoms_in_res[t])
+        k = min(12, n)
+        m = rng.choice(n, k, replace=False).astype(np.int32)
+        base = s.all_sites(t)
+        cand = base[m] + rng.uniform(-0.4, 0.4, (k, 1, 3))
+        kinds = np.array([MGPU_MOVE, MGPU_CREATION, MGPU_DELETION] * 4, dtype=np.int32)[:k]
+        cr = kinds == MGPU_CREATION
+        cand[cr] = base[m[cr]] - base[m[cr]].mean(axis=1, keepdims=True) + (s.bounds_lo + L * rng.uniform(0.1, 0.9, (int(cr.sum()), 3)))[:, None, :]
+        rep = (np.arange(k) % 2).astype(np.int32)
+        tt = np.full(k, t, np.int32)
+        res = [e.gcmc_trial(rep, tt, m, kinds, cand) for e in engines]
+        for a, b in zip(res[0], res[1]):
+            fin = np.isfinite(a) & np.isfinite(b)
+            assert np.array_equal(np.isfinite(a), np.isfinite(b))
+            assert np.all(np.abs(a[fin] - b[fin]) <= np.maximum(TOL_K, 16 * np.finfo(float).eps * np.abs(a[fin]))), (t, np.max(np.abs(a[fin] - b[fin])))
+        # the moves against the C restatement
+        P = refcpu_mod.RefCPU(s)
+        P.system_energy()
+        P.init_amplitude(True)
+        for c in np.flatnonzero(kinds == MGPU_MOVE):
+            com, off = P.get_molecule(t, int(m[c]))
+            P.save_fourier(t, int(m[c]))
+            eo = P.old_energy(t, int(m[c]), 0)[:3]
+            P.set_molecule(t, int(m[c]), cand[c, 0], cand[c] - cand[c, 0][None, :])
+            en = P.new_energy(t, int(m[c]), 0)[:3]
+            P.set_molecule(t, int(m[c]), com, off)
+            P.restore_fourier(t, int(m[c]))
+            for e_res in res:
+                close(e_res[0][c, :3], eo, "old")
+                close(e_res[1][c, :3], en, "new")
+    for e in engines:
+        e.close()

@@ -24,9 +24,12 @@ SUMMARY = json.load(open(os.path.join(RUNS, "summary.json")))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seams", [False, True], ids=["fused", "seams"])
+@pytest.mark.parametrize("mode", ["speculate8", "fused", "seams"])
 @pytest.mark.parametrize("case", sorted(SUMMARY))
-def test_run_writes_the_reference_files(case, seams, tmp_path):
+def test_run_writes_the_reference_files(case, mode, tmp_path):
+    """mode: speculate8 = windows of 8 steps per engine call (the default of run.py); fused = one batched call per
+    step; seams = one call per reference seam.  All three must write the reference's files."""
+    seams = mode == "seams"
     from maniac_mc_amd import run
     inputs = os.path.join(RUNS, case, "inputs")
     expected = os.path.join(RUNS, case, "expected")
@@ -37,7 +40,8 @@ def test_run_writes_the_reference_files(case, seams, tmp_path):
     os.chdir(inputs)                    # the log echoes the file names as given: the fixtures used relative ones
     try:
         res = run.run_simulation("system.maniac", "system.data", "system.inc", out, seed=SUMMARY[case]["seed"],
-                                 reservoir_path=reservoir, seams=seams, as_written=as_written)
+                                 reservoir_path=reservoir, seams=seams, as_written=as_written,
+                                 speculate=8 if mode == "speculate8" else 1)
     finally:
         os.chdir(cwd)
     # running energies of the chain == a full recomputation of the final configuration (as written, A(k) carries

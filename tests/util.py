@@ -20,6 +20,14 @@ def tol_for(*values):
     return max(TOL_K, 16 * np.finfo(np.float64).eps * big)
 
 
+def farm_tol(ref, steps):
+    """Absolute tolerance in K for a chain's RUNNING energy components against a from-scratch evaluation after
+    `steps` Metropolis steps: the stated 1e-10 kcal/mol plus a random-walk allowance of 64 ulp of the largest component
+    per accepted move (every accepted move adds new - old, each carrying a rounding of that size)."""
+    big = float(np.max(np.abs(np.asarray(ref, dtype=np.float64)))) if np.size(ref) else 0.0
+    return TOL_K + 64 * np.finfo(np.float64).eps * big * np.sqrt(max(1, steps))
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 

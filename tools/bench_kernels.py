@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--n-side", type=int, default=15)
     ap.add_argument("--json", default=None, help="also write the figures to this file")
+    ap.add_argument("--kinds", choices=["workload", "moves", "insertions", "deletions"], default="workload",
+                    help="override the workload's mix of trial kinds (diagnostics)")
     args = ap.parse_args()
     R = args.replicas
     s, eng, ta = build(args.workload, R, args.n_side)
@@ -95,6 +97,8 @@ def main():
         else:
             u = rng.random(R)
             kind = np.where(u < 0.5, _lib.MGPU_MOVE, np.where(u < 0.75, _lib.MGPU_CREATION, _lib.MGPU_DELETION)).astype(np.int32)
+        if args.kinds != "workload":
+            kind = np.full(R, {"moves": _lib.MGPU_MOVE, "insertions": _lib.MGPU_CREATION, "deletions": _lib.MGPU_DELETION}[args.kinds], np.int32)
         nm = np.array([eng.num_molecules(r, ta) for r in range(R)]) if args.workload != "spce" else np.full(R, n0)
         m = (rng.random(R) * np.maximum(nm, 1)).astype(np.int32)
         m = np.minimum(m, np.minimum(nm, n0) - 1)          # a slot whose coordinates this script knows (never a grown one)

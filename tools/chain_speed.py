@@ -1,11 +1,59 @@
-import sys, time, os, tempfile
-sys.path.insert(0, os.getcwd())
-from maniac_mc_amd import synth, io_maniac, run
-s = synth.spce_box(15)
-d = tempfile.mkdtemp()
-files = io_maniac.write_input_files(s, d + "/in", nb_block=2, nb_step=15000, translation_step=0.3, rotation_step_angle=0.3,
-                                    translation_proba=0.5, rotation_proba=0.5, masses=[15.9994, 1.008], atom_names=["OW", "HW"])
-t0 = time.perf_counter()
-res = run.run_simulation(*files, d + "/out/", seed=5)
-el = time.perf_counter() - t0
-print("chain: 30000 moves in %.2f s total (incl. setup, file output) -> %.0f moves/s; accepted %d" % (el, 30000 / el, res["counters"][1] + res["counters"][3]))
+#!/usr/bin/env python3
+"""Speed of the single-chain drop-in (mc_chain.f90 through run.run_simulation) with and without speculative windows.
+
+    python tools/chain_speed.py [--blocks 4] [--steps 2000]
+Cases: the two charged grand-canonical whole-run fixtures (tests/golden/runs/co2_gcmc = BASELINE.json configs[2],
+framework_water_gcmc = configs[3] in miniature; their own inputs and seeds, more steps) in the as-written mode the
+fixtures were made in, and the 10 125-atom SPC/E box (NVT).  For every case the loop is run with K = 1 (one engine call
+per step), 4, 8 and 16; the output files of all K must be identical (checked here), only the time differs.
+"""
+import argparse
+import filecmp
+import json
+import os
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from maniac_mc_amd import io_maniac, run, synth  # noqa: E402
+
+RUNS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "runs")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--blocks", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--ks", default="1,4,8,16")
+    a = ap.parse_args()
+    ks = [int(k) for k in a.ks.split(",")]
+    summary = json.load(open(os.path.join(RUNS, "summary.json")))
+    tmp = tempfile.mkdtemp()
+    cases = []
+    for name in ("co2_gcmc", "framework_water_gcmc"):
+        inp = os.path.join(RUNS, name, "inputs")
+        cases.append((name, [os.path.join(inp, f) for f in ("system.maniac", "system.data", "system.inc")],
+                      dict(seed=summary[name]["seed"], as_written=bool(summary[name].get("as_written")))))
+    s = synth.spce_box(15)
+    files = io_maniac.write_input_files(s, tmp + "/spce_in", nb_block=2, nb_step=100, translation_step=0.3, rotation_step_angle=0.3,
+                                        translation_proba=0.5, rotation_proba=0.5, masses=[15.9994, 1.008], atom_names=["OW", "HW"])
+    cases.append(("spce_10125_nvt", list(files), dict(seed=5)))
+    for name, files, kw in cases:
+        base = None
+        for k in ks:
+            out = os.path.join(tmp, f"{name}_k{k}") + "/"
+            res = run.run_simulation(*files, out, nb_block=a.blocks, nb_step=a.steps, speculate=k, **kw)
+            n = a.blocks * a.steps
+            c = res["counters"]
+            acc = int(c[1] + c[3] + c[5] + c[7])
+            same = ""
+            if base is None:
+                base = (out, res["loop_seconds"])
+            else:
+                diff = [f for f in sorted(os.listdir(out)) if f != "log.maniac" and not filecmp.cmp(os.path.join(out, f), os.path.join(base[0], f), shallow=False)]
+                same = f"  files identical to K={ks[0]}: {not diff}{' ' + str(diff) if diff else ''}  speed-up {base[1] / res['loop_seconds']:.2f}x"
+            print(f"{name:24s} K={k:2d}: {n} steps in {res['loop_seconds']:.2f} s -> {n / res['loop_seconds']:.0f} steps/s, acceptance {acc / n:.2f}{same}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
