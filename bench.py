@@ -240,10 +240,12 @@ def spawn_ranks(n_gpus, argv):
     return subprocess.call(cmd, env=env)
 
 
-def plan_host_threads(n_threads_req, local_world):
+def plan_host_threads(n_threads_req, local_world, want=6):
     cores = usable_cores()
     if n_threads_req > 0:
         return n_threads_req
+    if want != 6:
+        return max(1, min(want, cores // max(1, local_world)))
     # six threads per GPU: measured round 3 on the 16-CPU boxes (SPC/E: 4 / 6 / 8 threads 7.40 / 7.40 / 7.35 M accepted moves/s,
     # GPU-bound; CO2 GCMC 8192 x 4 lanes: 2 / 4 / 6 / 8 / 12 / 16 threads 7.8 / 9.3 / 10.5 / 6.6 / 7.3 / 6.7 M -- beyond six the
     # regions' fork / join and the threads' spinning cost more than the extra threads bring)
@@ -327,13 +329,14 @@ def cpu_baseline_gcmc(system, t_act, p_move, translation_step, rotation_step, fu
 
 WORKLOADS = {
     # name: default chains per GPU, lanes, what BASELINE.json calls it
-    "spce": dict(replicas=8192, lanes=4, config="metric workload: 10 125-atom SPC/E box (configs[1] recipe at 15^3)"),
+    "spce": dict(replicas=8192, lanes=4, drivers=1, threads=6, config="metric workload: 10 125-atom SPC/E box (configs[1] recipe at 15^3)"),
     # the grand-canonical boxes are small (a few hundred atoms): per lane step the fixed host costs (OpenMP regions, HIP calls)
-    # weigh as much as the kernels, so they run MANY chains on TWO lanes (measured round 3, co2_gcmc: 2048 x 2 5.4 M,
-    # 8192 x 4 6.6 M, 8192 x 2 11.2 M, 16384 x 2 13.7 M accepted moves/s)
-    "co2_gcmc": dict(replicas=16384, lanes=2, config="configs[2]: GCMC of CO2 in a 50 A box, insertion / deletion at one fugacity"),
-    "framework_water": dict(replicas=8192, lanes=2, config="configs[3] stand-in: 2208-atom framework + 4-site water, full move set"),
-    "co2_isotherm": dict(replicas=16384, lanes=2, config="configs[4]: 8 fugacity points dealt over the ranks"),
+    # weigh as much as the kernels, so they run MANY chains (measured round 3, co2_gcmc, one driver thread: 2048 x 2 lanes
+    # 5.4 M, 8192 x 4 6.6 M, 8192 x 2 11.2 M, 16384 x 2 13.7 M accepted moves/s) and TWO host driver threads sharing four
+    # lanes (16384 x 4 lanes, 8 threads: 19.8 M; the SPC/E box is GPU-bound and gains nothing from a second driver)
+    "co2_gcmc": dict(replicas=16384, lanes=4, drivers=2, threads=8, config="configs[2]: GCMC of CO2 in a 50 A box, insertion / deletion at one fugacity"),
+    "framework_water": dict(replicas=8192, lanes=4, drivers=2, threads=8, config="configs[3] stand-in: 2208-atom framework + 4-site water, full move set"),
+    "co2_isotherm": dict(replicas=16384, lanes=4, drivers=2, threads=8, config="configs[4]: 8 fugacity points dealt over the ranks"),
 }
 
 
@@ -352,7 +355,10 @@ def main():
     ap.add_argument("--no-pin", action="store_true", help="do not bind the host threads to the GPU's NUMA node")
     ap.add_argument("--lanes", type=int, default=None,
                     help="submission lanes (chain groups in flight) of the Fortran driver: the host prepares / resolves one "
-                         "group while the GPU evaluates the others; default 4 (SPC/E) or 2 (grand-canonical workloads)")
+                         "group while the GPU evaluates the others; default 4")
+    ap.add_argument("--drivers", type=int, default=None,
+                    help="host driver threads of the Fortran farm that share the lanes, each with a team of host-threads / drivers "
+                         "(default 1 for SPC/E, 2 for the grand-canonical workloads)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -391,7 +397,11 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if world != max(1, args.gpus):
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
-    args.host_threads = plan_host_threads(args.host_threads, local_world)
+    args.host_threads = plan_host_threads(args.host_threads, local_world, WORKLOADS[wl]["threads"])
+    if args.drivers is None:
+        args.drivers = WORKLOADS[wl]["drivers"]
+    if args.host_threads < 2 * args.drivers:
+        args.drivers = 1
     device = local_rank if args.device is None else args.device
 
     if args.dry_run:
@@ -434,7 +444,7 @@ def main():
         from maniac_mc_amd.farm import ReplicaFarm as Farm
     if wl != "spce" and args.host != "fortran":
         sys.exit("bench.py: the grand-canonical workloads run on the Fortran farm")
-    kw = dict(n_threads=args.host_threads, n_lanes=args.lanes) if args.host == "fortran" else {}
+    kw = dict(n_threads=args.host_threads, n_lanes=args.lanes, n_drivers=args.drivers) if args.host == "fortran" else {}
     R = args.replicas
     iso_pts, fug_grid, point_of_chain = None, None, None
     t_act, p_move, fug_one = 0, 1.0, None        # active residue type, share of translation + rotation, the fugacity
@@ -670,7 +680,7 @@ def main():
                                     "co2_isotherm": f"co2_isotherm_{ISOTHERM_POINTS}fugacities_50A_box_Nk{Nk}"}[wl],
                        "baseline_config": WORKLOADS[wl]["config"],
                        "replicas_per_gpu": R, "host_driver": args.host, "host_threads": args.host_threads if args.host == "fortran" else 1,
-                       "lanes": n_lanes, "host_cores": pinned, "moves": moves,
+                       "lanes": n_lanes, "host_drivers": args.drivers, "host_cores": pinned, "moves": moves,
                        "trials_per_step": R * world, "parallelism": f"replicas x{world}"},
             "trial_moves_per_s": tot_trials / elapsed,
             "acceptance": tot_acc / max(1.0, tot_trials),

@@ -45,14 +45,24 @@ extern "C" {
  *   MGPU_PAIR_NO_FUSE=1         trial moves as two single-state sweeps instead of one fused old + new sweep
  *   MGPU_RECIP_PER_K=1          per-k reciprocal kernel even where the row form's LDS tables fit
  *   MGPU_PAIR_EXACT_FOLD=1      always the multiply / round / fma minimum-image fold in the pair sweep (default: the
- *                               two-instruction fold min(|d|, L - |d|) whenever every atom of the replicas in a launch
- *                               lies within one box length of the cell centre, which the engine tracks on the host)
+ *                               two-instruction fold min(|d|, L - |d|) whenever every resident atom of the replicas in
+ *                               a launch and every candidate site of it lies within 0.745 box lengths of the cell
+ *                               centre, which the engine tracks on the host; both folds see the same raw separation
+ *                               and return the same bits)
+ *   MGPU_PAIR_FLAT=0 / 1        plane-by-plane (pair_sweep_kernel) / flat (pair_flat_kernel) register-site pair sweep
+ *                               (default: flat for topologies with short planes -- every plane-major residue type has
+ *                               at most 1024 molecule slots -- or a frozen framework, orthorhombic boxes)
+ *   MGPU_NO_FROZEN=1            inactive residues of >= 64 atoms stay site-major in the caller's site order (default:
+ *                               "frozen" layout, sites sorted by atom type, swept by pair_flat_kernel)
+ *   MGPU_PAIR_FUSE_MAX=<n>      largest molecule whose trial moves sweep old + new state in one pass (default 3; 4 and
+ *                               5 select kernels of up to 256 VGPRs at half the occupancy: measured slower)
  *   MGPU_DEFER_COMMIT=1         a commit from a lane's resident rows is not launched but folded into the lane's
  *                               next trial (one kernel applies it and sweeps k for the new candidates); bitwise the
  *                               same results, measured no faster than the two launches
  * Threading rule: one host thread drives an engine at a time; lanes must hold disjoint replicas while their
- * trials / commits are in flight; every synchronous entry point that reads or rewrites replica state drains all
- * lanes first. */
+ * trials / commits are in flight; every synchronous entry point that reads or rewrites replica state -- the
+ * mgpu_replica_* / structure-factor / system-energy calls and the synchronous candidate calls
+ * (mgpu_pair / recip / intra / trial_energy_candidates, mgpu_commit_candidates) -- drains all lanes first. */
 
 /* candidate kinds for the reciprocal-space update, ewald_energy.f90:241-256 */
 #define MGPU_MOVE 0      /* A += sum q (phi_new - phi_old)   translation / rotation */

@@ -164,11 +164,10 @@ struct mgpu_engine {
     double *d_res_q = nullptr;
     int *d_res_atype = nullptr;
     // frozen residues (inactive, n1 >= 64): site_perm[t][a] = position of the caller's site a in the engine's
-    // atom-type-sorted order (identity for every other residue type); d_grp_tab = their group records
+    // atom-type-sorted order (identity for every other residue type)
     std::vector<std::vector<int>> site_perm;
     std::vector<char> frozen;        // [n_res]
     bool any_frozen = false;
-    int4 *d_grp_tab = nullptr;
     int *d_atom_ty = nullptr;        // [Ncap] 0-based atom type of every slot (pair_flat_kernel fetches it per lane)
     // Register-site sweeps of this engine go through pair_flat_kernel (one software-pipelined loop over all units of
     // a work unit) instead of the plane-by-plane pair_sweep_kernel: chosen at creation for topologies with short planes
@@ -391,17 +390,12 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
     // fast_fold: every atom of the replicas involved lies within one box length of the cell centre (tracked on the
     // host), so the register-site kernels may fold separations with two instructions per axis (image_r2_fast)
     const bool ff = fast_fold && !ordered && !e->bx.triclinic && e->pair_fast_fold;
-    // fz: the topology has a frozen residue (inactive framework, sites sorted by atom type): the register-site kernels
-    // built with the per-lane-charge plane sweep
-    const bool fz = e->any_frozen;
-#define MGPU_PAIR_FF_FZ(NS, FU)                                                                   \
+#define MGPU_PAIR_FF(NS, FU)                                                                      \
     do {                                                                                          \
-        if (ff && fz) MGPU_LAUNCH_PAIR(NS, false, false, FU, true, true);                         \
-        else if (ff) MGPU_LAUNCH_PAIR(NS, false, false, FU, true, false);                         \
-        else if (fz) MGPU_LAUNCH_PAIR(NS, false, false, FU, false, true);                         \
-        else MGPU_LAUNCH_PAIR(NS, false, false, FU, false, false);                                \
+        if (ff) MGPU_LAUNCH_PAIR(NS, false, false, FU, true);                                     \
+        else MGPU_LAUNCH_PAIR(NS, false, false, FU, false);                                       \
     } while (0)
-    // the flat kernels are latency-bound: as many workgroups per CU as their registers and the LDS table allow
+    // flat kernels: as many workgroups per CU as their registers and the LDS tables allow
 #define MGPU_LAUNCH_FLAT_1(NS, FU, FW)                                                                                  \
     do {                                                                                                               \
         const int nb = resident_blocks<&pair_flat_kernel<NS, FU, FW>>(e->coul_bytes);                                  \
@@ -434,11 +428,11 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
         }
     } else if (fused) {
         switch (common_n1) {
-            case 1: MGPU_PAIR_FF_FZ(1, true); break;
-            case 2: MGPU_PAIR_FF_FZ(2, true); break;
-            case 3: MGPU_PAIR_FF_FZ(3, true); break;
-            case 4: MGPU_PAIR_FF_FZ(4, true); break;   // wide instantiations: 2 waves per SIMD, one workgroup per CU
-            default: MGPU_PAIR_FF_FZ(5, true); break;
+            case 1: MGPU_PAIR_FF(1, true); break;
+            case 2: MGPU_PAIR_FF(2, true); break;
+            case 3: MGPU_PAIR_FF(3, true); break;
+            case 4: MGPU_PAIR_FF(4, true); break;   // wide instantiations: 2 waves per SIMD, one workgroup per CU
+            default: MGPU_PAIR_FF(5, true); break;
         }
     } else if (e->bx.triclinic) {
         if (ordered) MGPU_LAUNCH_PAIR(0, true, true);
@@ -447,15 +441,15 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
         MGPU_LAUNCH_PAIR(0, true, false);
     } else {
         switch (common_n1) {
-            case 1: MGPU_PAIR_FF_FZ(1, false); break;
-            case 2: MGPU_PAIR_FF_FZ(2, false); break;
-            case 3: MGPU_PAIR_FF_FZ(3, false); break;
-            case 4: MGPU_PAIR_FF_FZ(4, false); break;
-            case 5: MGPU_PAIR_FF_FZ(5, false); break;
+            case 1: MGPU_PAIR_FF(1, false); break;
+            case 2: MGPU_PAIR_FF(2, false); break;
+            case 3: MGPU_PAIR_FF(3, false); break;
+            case 4: MGPU_PAIR_FF(4, false); break;
+            case 5: MGPU_PAIR_FF(5, false); break;
             default: MGPU_LAUNCH_PAIR(0, false, false); break;
         }
     }
-#undef MGPU_PAIR_FF_FZ
+#undef MGPU_PAIR_FF
 #undef MGPU_LAUNCH_FLAT
 #undef MGPU_LAUNCH_FLAT_1
 #undef MGPU_LAUNCH_PAIR
@@ -702,57 +696,71 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
         tp.n1[t] = atoms_in_res[t];
         tp.cap[t] = mol_capacity[t];
         tp.seg_off[t] = off;
-        tp.site_major[t] = atoms_in_res[t] >= 64 ? (is_active[t] == 0 && std::getenv("MGPU_NO_FROZEN") == nullptr ? 2 : 1) : 0;
+        tp.site_major[t] = atoms_in_res[t] >= 64 ? 1 : 0;
         off += atoms_in_res[t] * mol_capacity[t];
     }
     tp.n_cap_atoms = off;
-    // frozen residues: stable sort of the sites by atom type -> one group per type present
+    // Layout of the big inactive residues and the register-site pair kernel go together: "frozen" (sites sorted by
+    // atom type, one group per type present) + pair_flat_kernel, or site-major + pair_sweep_kernel.  Default: flat
+    // wherever a framework (inactive, >= 64 atoms) is present -- measured round 3, 2208-atom framework + 4-site water,
+    // 1532 evaluations per launch: flat 44.7 us, site-major plane-by-plane 46.8 us, type-sorted plane-by-plane 53.8 us;
+    // CO2 box without a framework: flat 12.3 us, plane-by-plane 11.3 us, so plain boxes keep pair_sweep_kernel.
+    // MGPU_PAIR_FLAT=1 forces the flat kernel wherever it is eligible, =0 never; MGPU_NO_FROZEN=1 keeps site-major.
     std::vector<int4> grp_tab;
-    e->site_perm.resize(n_res);
-    e->frozen.assign(n_res, 0);
-    for (int t = 0; t < n_res; ++t) {
-        std::vector<int> &perm = e->site_perm[t];
-        perm.resize(tp.n1[t]);
-        tp.n_grp[t] = 0;
-        tp.grp_off[t] = (int)grp_tab.size();
-        if (tp.site_major[t] != 2) {
-            for (int a = 0; a < tp.n1[t]; ++a) perm[a] = a;
-            continue;
-        }
-        e->frozen[t] = 1;
-        e->any_frozen = true;
-        std::vector<int> order(tp.n1[t]);
-        for (int a = 0; a < tp.n1[t]; ++a) order[a] = a;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-            return atom_types[(size_t)t * max_atom + a] < atom_types[(size_t)t * max_atom + b];
-        });
-        int cur_ty = -1;
-        for (int pos = 0; pos < tp.n1[t]; ++pos) {
-            const int a = order[pos], ty = atom_types[(size_t)t * max_atom + a] - 1;
-            perm[a] = pos;
-            if (ty != cur_ty) {
-                grp_tab.push_back(make_int4(pos, 0, ty, 0));
-                tp.n_grp[t] += 1;
-                cur_ty = ty;
+    auto build_layout = [&](bool use_frozen) {
+        grp_tab.clear();
+        e->site_perm.assign(n_res, std::vector<int>());
+        e->frozen.assign(n_res, 0);
+        e->any_frozen = false;
+        for (int t = 0; t < n_res; ++t) {
+            std::vector<int> &perm = e->site_perm[t];
+            perm.resize(tp.n1[t]);
+            tp.n_grp[t] = 0;
+            tp.grp_off[t] = (int)grp_tab.size();
+            tp.site_major[t] = tp.n1[t] >= 64 ? ((use_frozen && is_active[t] == 0) ? 2 : 1) : 0;
+            if (tp.site_major[t] != 2) {
+                for (int a = 0; a < tp.n1[t]; ++a) perm[a] = a;
+                continue;
             }
-            grp_tab.back().y += 1;
+            e->frozen[t] = 1;
+            e->any_frozen = true;
+            std::vector<int> order(tp.n1[t]);
+            for (int a = 0; a < tp.n1[t]; ++a) order[a] = a;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+                return atom_types[(size_t)t * max_atom + a] < atom_types[(size_t)t * max_atom + b];
+            });
+            int cur_ty = -1;
+            for (int pos = 0; pos < tp.n1[t]; ++pos) {
+                const int a = order[pos], ty = atom_types[(size_t)t * max_atom + a] - 1;
+                perm[a] = pos;
+                if (ty != cur_ty) {
+                    grp_tab.push_back(make_int4(pos, 0, ty, 0));
+                    tp.n_grp[t] += 1;
+                    cur_ty = ty;
+                }
+                grp_tab.back().y += 1;
+            }
         }
-    }
+    };
     {
-        constexpr int kFlatMaxCap = 1024;       // <= 16 units per plane
-        bool short_planes = true, ok = true;
+        bool framework = false;
+        for (int t = 0; t < n_res; ++t) framework = framework || (tp.n1[t] >= 64 && is_active[t] == 0);
+        bool want_flat = framework;
+        if (const char *ov = std::getenv("MGPU_PAIR_FLAT")) want_flat = std::atoi(ov) != 0;
+        build_layout(want_flat && std::getenv("MGPU_NO_FROZEN") == nullptr);
+        bool ok = e->box_type != 3 && (int)grp_tab.size() <= kMaxGrp;
+        int planes = 0;                        // one lane of a wave builds one plane's record
         for (int t = 0; t < n_res; ++t) {
             if (tp.site_major[t] == 1) ok = false;
-            if (tp.site_major[t] == 0 && tp.cap[t] > kFlatMaxCap) short_planes = false;
+            planes += tp.site_major[t] == 2 ? tp.cap[t] * tp.n_grp[t] : tp.n1[t];
         }
-        if ((int)grp_tab.size() > kMaxGrp) ok = false;
-        int planes = 0;                        // one lane of the wave builds one plane's record
-        for (int t = 0; t < n_res; ++t) planes += tp.site_major[t] == 2 ? tp.cap[t] * tp.n_grp[t] : tp.n1[t];
         if (planes > kFlatMaxPlanes) ok = false;
-        e->pair_flat = ok && (short_planes || e->any_frozen);
-        if (const char *ov = std::getenv("MGPU_PAIR_FLAT")) e->pair_flat = ok && std::atoi(ov) != 0;
-        for (size_t g = 0; g < grp_tab.size() && g < (size_t)kMaxGrp; ++g) {
-            tp.grp_start[g] = grp_tab[g].x; tp.grp_cnt[g] = grp_tab[g].y; tp.grp_ty[g] = grp_tab[g].z;
+        e->pair_flat = want_flat && ok;
+        if (!e->pair_flat && e->any_frozen) build_layout(false);
+        for (size_t g = 0; g < (size_t)kMaxGrp; ++g) {
+            tp.grp_start[g] = g < grp_tab.size() ? grp_tab[g].x : 0;
+            tp.grp_cnt[g] = g < grp_tab.size() ? grp_tab[g].y : 0;
+            tp.grp_ty[g] = g < grp_tab.size() ? grp_tab[g].z : 0;
         }
     }
     e->pair_fuse = std::getenv("MGPU_PAIR_NO_FUSE") == nullptr;
@@ -912,13 +920,8 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     HIP_TRY_E(hipMemcpy(e->d_kw, kw.data(), e->nk * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY_E(hipMemcpy(e->d_pair_tab, ptab.data(), ptab.size() * sizeof(double2), hipMemcpyHostToDevice));
     HIP_TRY_E(hipMemcpy(e->d_res_q, q_dev.data(), q_dev.size() * sizeof(double), hipMemcpyHostToDevice));
-    if (!grp_tab.empty()) {
-        HIP_TRY_E(hipMalloc(&e->d_grp_tab, grp_tab.size() * sizeof(int4)));
-        HIP_TRY_E(hipMemcpy(e->d_grp_tab, grp_tab.data(), grp_tab.size() * sizeof(int4), hipMemcpyHostToDevice));
-    }
     HIP_TRY_E(hipMalloc(&e->d_atom_ty, ncap * sizeof(int)));
     HIP_TRY_E(hipMemcpy(e->d_atom_ty, a_ty.data(), ncap * sizeof(int), hipMemcpyHostToDevice));
-    tp.grp_tab = e->d_grp_tab;
     tp.slot_q = e->d_atom_q;
     tp.slot_ty = e->d_atom_ty;
     HIP_TRY_E(hipMemcpy(e->d_res_atype, atype0.data(), atype0.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -939,7 +942,7 @@ int mgpu_engine_destroy(mgpu_engine *e) {
     for (void *p : {(void *)e->d_pos, (void *)e->d_nmol, (void *)e->d_A, (void *)e->d_kpack, (void *)e->d_kw,
                     (void *)e->d_pair_tab, (void *)e->d_coul_tab, (void *)e->d_res_q, (void *)e->d_res_atype, (void *)e->d_atom_res,
                     (void *)e->d_atom_mol, (void *)e->d_atom_q, (void *)e->d_phase_tab, (void *)e->d_S, (void *)e->d_trj,
-                    (void *)e->d_tw, (void *)e->d_kslot, (void *)e->d_rrows, (void *)e->d_grp_tab, (void *)e->d_atom_ty})
+                    (void *)e->d_tw, (void *)e->d_kslot, (void *)e->d_rrows, (void *)e->d_atom_ty})
         if (p) (void)hipFree(p);
     e->h_stage.release();
     for (auto &ln : e->lanes) {

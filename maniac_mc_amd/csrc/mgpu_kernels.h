@@ -61,18 +61,16 @@ struct Topo {
     int cap[kMaxRes];             // molecule slots
     int seg_off[kMaxRes];         // first atom slot of the residue type
     int site_major[kMaxRes];      // 0 plane-major, 1 site-major, 2 frozen: site-major with the sites sorted by atom type
-    // frozen residues (inactive, n1 >= 64: frameworks): the residue's sites are renumbered so that sites of one atom
-    // type are contiguous; grp_tab[grp_off[t] + g] = {first sorted site, count, 0-based atom type, 0} for its n_grp[t]
-    // groups.  A wave then sweeps 64 consecutive sites of ONE atom type: the (4 epsilon, sigma^2) of every
-    // (candidate site, group) pair is wave-uniform and the scalar LJ / Coulomb skips of the plane-major sweep apply;
-    // only the charge is per lane (frameworks carry per-atom charges).
+    // frozen residues (inactive, n1 >= 64: frameworks; swept by pair_flat_kernel): the residue's sites are renumbered
+    // so that sites of one atom type are contiguous; group g of residue t (g < n_grp[t]) is record grp_off[t] + g of
+    // grp_start / grp_cnt / grp_ty = {first sorted site, count, 0-based atom type}.  A wave then sweeps 64 consecutive
+    // sites of ONE atom type: the (4 epsilon, sigma^2) of every (candidate site, unit) pair is wave-uniform and the LJ
+    // half is skipped by a scalar branch where epsilon = 0; only the charge is per lane (per-atom framework charges).
     int n_grp[kMaxRes];
     int grp_off[kMaxRes];
-    const int4 *grp_tab;
+    int grp_start[kMaxGrp], grp_cnt[kMaxGrp], grp_ty[kMaxGrp];
     const double *slot_q;         // [n_cap_atoms] charge of every atom slot (same for all replicas)
     const int *slot_ty;           // [n_cap_atoms] 0-based atom type of every atom slot
-    // the same group records by value (read through the scalar cache by pair_flat_kernel's unit generator)
-    int grp_start[kMaxGrp], grp_cnt[kMaxGrp], grp_ty[kMaxGrp];
 };
 
 struct BoxDev {
@@ -252,10 +250,7 @@ __device__ __forceinline__ void pair_term(double dx, double dy, double dz, const
 // ComputeOldEnergy and ComputeNewEnergy (monte_carlo_utils.f90:380-395 / :275-330); each state's sums are
 // formed exactly as the unfused sweep forms them, and the work unit writes two partials {old, new}.
 // ------------------------------------------------------------------------------------------
-// FROZ: the topology has frozen residues (inactive frameworks stored sorted by atom type, per-lane charges): only then
-// is the per-lane-charge variant of the hot path compiled in, so the kernels of every other topology keep their
-// register budget.
-template <int NS, bool ORDERED, bool TRI, bool FUSED = false, bool FASTW = false, bool FROZ = false>
+template <int NS, bool ORDERED, bool TRI, bool FUSED = false, bool FASTW = false>
 __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MGPU_PAIR_MINWAVES) void pair_sweep_kernel(
     Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
@@ -349,15 +344,13 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                 const int nm = nm_r[t2], n2 = tp.n1[t2];
                 if (nm == 0) continue;
                 const bool same_t = (t2 == it.t) && (it.m >= 0);
-                // ---- hot path of the register-site sweeps: one "plane" = a run of `nm` atoms that share their atom
-                //      type (plane-major: site a2 of every molecule, charge uniform too; frozen: one atom-type group of
-                //      one molecule, charge per lane), swept in units of 64, branch-free per unit, NS independent
+                // ---- hot path of the register-site sweeps: one plane = site a2 of every molecule of a plane-major type
+                //      (charge and atom type uniform), swept in units of 64 molecules, branch-free per unit, NS independent
                 //      dependency chains, next unit's coordinates prefetched while this one computes ----
-                [[maybe_unused]] auto plane_sweep = [&](auto plq_tag, const double *pxp, const double *pyp, const double *pzp,
-                                                        const double *pqp, int nm, bool excl, int dummy_m, double qj, int tyj, int key) {
-                    constexpr bool PLQ = decltype(plq_tag)::value;      // per-lane charge (frozen groups)
+                [[maybe_unused]] auto plane_sweep = [&](const double *pxp, const double *pyp, const double *pzp,
+                                                        int nm, bool excl, int dummy_m, double qj, int tyj, int key) {
                     const int cpp = (nm + 63) >> 6;
-                    const bool qj_on = PLQ || fabs(qj) >= kErrorTol;
+                    const bool qj_on = fabs(qj) >= kErrorTol;
                     double e4[NTY], sg2[NTY], qq[NTY];
                     bool lj[NTY], c_on[NTY];
                     bool any_c = false, all_c = true, any_lj = false;
@@ -367,7 +360,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                         e4[s] = pt.x; sg2[s] = pt.y;
                         lj[s] = pt.x != 0.0;                               // epsilon = 0 contributes 0
                         c_on[s] = qj_on && (fabs(rq[s]) >= kErrorTol);      // energy_utils.f90:430
-                        qq[s] = c_on[s] ? (PLQ ? rq[s] : rq[s] * qj) : 0.0;
+                        qq[s] = c_on[s] ? rq[s] * qj : 0.0;
                         any_c = any_c || c_on[s]; all_c = all_c && c_on[s]; any_lj = any_lj || lj[s];
                     }
                     if (!(any_c || any_lj)) return;
@@ -380,10 +373,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                     auto is_special = [&](int cc) {
                         return ORDERED || (cc == cpp - 1 && (nm & 63) != 0) || (excl && cc == (it.m >> 6));
                     };
-                    // wq: the lane's weight in the Coulomb sums -- 1 / 0 (valid / masked off) where the charge is
-                    // uniform, the lane's own charge (0 where masked off or below CoulombEnergy's 1e-10 threshold) for
-                    // a frozen group
-                    auto fetch = [&](int cc, bool special, double &x, double &y, double &z, double &wq, bool &ok) {
+                    auto fetch = [&](int cc, bool special, double &x, double &y, double &z, bool &ok) {
                         int m2 = cc * 64 + lane;
                         ok = true;
                         if (special) {
@@ -392,12 +382,6 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                             m2 = ok ? m2 : dummy_m;
                         }
                         x = pxp[m2]; y = pyp[m2]; z = pzp[m2];
-                        if constexpr (PLQ) {
-                            const double q = pqp[m2];
-                            wq = (ok && fabs(q) >= kErrorTol) ? q : 0.0;
-                        } else {
-                            wq = ok ? 1.0 : 0.0;
-                        }
                     };
                     double acc[NREG];
 #pragma unroll
@@ -440,20 +424,18 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                                 }
                             }
                         };
-                        double xj, yj, zj, wj;
+                        double xj, yj, zj;
                         bool valid, special = is_special(c);
-                        fetch(c, special, xj, yj, zj, wj, valid);
+                        fetch(c, special, xj, yj, zj, valid);
                         for (; c < cpp; c += nsplit) {
-                            double xn = xj, yn = yj, zn = zj, wn = wj;
+                            double xn = xj, yn = yj, zn = zj;
                             bool vn = true;
                             const bool special_n = is_special(c + nsplit);
-                            if (c + nsplit < cpp) fetch(c + nsplit, special_n, xn, yn, zn, wn, vn);
+                            if (c + nsplit < cpp) fetch(c + nsplit, special_n, xn, yn, zn, vn);
                             // (a mask-free copy of the unit for ordinary chunks was measured slower:
                             //  the duplicated body costs more registers than the masks cost cycles)
-                            // uniform charge: the weight is rebuilt from the mask (no second prefetch register pair)
-                            unit(xj, yj, zj, PLQ ? wj : (valid ? 1.0 : 0.0), valid);
+                            unit(xj, yj, zj, valid ? 1.0 : 0.0, valid);          // masked-off lanes carry weight 0
                             xj = xn; yj = yn; zj = zn; valid = vn; special = special_n;
-                            if constexpr (PLQ) wj = wn;
                         }
                     };
                     if (all_c) sweep_plane(std::true_type{});
@@ -461,22 +443,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
 #pragma unroll
                     for (int s = 0; s < NREG; ++s) ec[s / NTY] = fma(qq[s % NTY], acc[s], ec[s / NTY]);
                 };
-                if (NS > 0 && FROZ && tp.site_major[t2] == 2) {
-                    // frozen residue: one plane per (molecule, atom-type group); the candidate is never one of its molecules
-                    // unless an inactive molecule itself is evaluated (then that whole molecule is skipped)
-                    if constexpr (NS > 0 && FROZ) {
-                        const int ng = tp.n_grp[t2], seg2 = tp.seg_off[t2];
-                        for (int m2 = 0; m2 < nm; ++m2) {
-                            if (same_t && (ORDERED ? (m2 <= it.m) : (m2 == it.m))) continue;
-                            for (int g = 0; g < ng; ++g) {
-                                const int4 gr = tp.grp_tab[tp.grp_off[t2] + g];        // scalar load
-                                const int base = seg2 + m2 * n2 + gr.x;
-                                plane_sweep(std::true_type{}, px + base, py + base, pz + base, tp.slot_q + base, gr.y, false, 0,
-                                            0.0, gr.z, plane_base + m2 * ng + g);
-                            }
-                        }
-                    }
-                } else if (!tp.site_major[t2]) {
+                if (!tp.site_major[t2]) {
                     // plane-major: unit = (site index a2, 64 consecutive molecules); q / type uniform
                     if constexpr (NS > 0) {
                         const int cap2 = tp.cap[t2], seg2 = tp.seg_off[t2];
@@ -488,8 +455,8 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                         for (int a2 = 0; a2 < n2; ++a2) {
                             const double qj = res_q[t2 * tp.max_atom + a2];
                             const int tyj = res_atype[t2 * tp.max_atom + a2];
-                            plane_sweep(std::false_type{}, px + seg2 + a2 * cap2, py + seg2 + a2 * cap2, pz + seg2 + a2 * cap2,
-                                        nullptr, nm, same_t, dummy_m, qj, tyj, plane_base + a2);
+                            plane_sweep(px + seg2 + a2 * cap2, py + seg2 + a2 * cap2, pz + seg2 + a2 * cap2, nm, same_t, dummy_m, qj, tyj,
+                                        plane_base + a2);
                         }
                     } else {
                         const int cpp = (nm + 63) >> 6, units = n2 * cpp;
@@ -1038,9 +1005,6 @@ struct AcceptBits {
 #ifndef MGPU_RECIP_MINWAVES
 #define MGPU_RECIP_MINWAVES 4   // <= 128 VGPRs: four 4-wave workgroups per CU, 1024 items resident at once
 #endif
-#ifndef MGPU_RECIP_PREFETCH
-#define MGPU_RECIP_PREFETCH 0   // bit 0 (k sweep) / bit 1 (commit): touch A(k) ahead of the phase tables (see recip_rows_kernel)
-#endif
 #ifndef MGPU_RECIP_EARLY_LOAD
 #define MGPU_RECIP_EARLY_LOAD 0   // bit 0 (k sweep) / bit 1 (commit): request the first chunk of A(k) before the phase tables (see below)
 #endif
@@ -1065,7 +1029,12 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
             else it.aux = nm - 1;                                 // swap-with-last target
         }
     }
-    const int n1 = tp.n1[it.t], nss = 2 * n1;
+    // site-states: the new sites and the old sites of a move (2 n1); an insertion, a deletion or A += S(sites) carries
+    // ONE set (n1) -- half the table entries, XY products and inner-loop terms
+    const bool use_new = (it.kind == 0 /*MOVE*/ || it.kind == 1 /*CREATION*/ || it.kind == 4 /*FOURIER_ADD*/);
+    const bool use_old = (it.kind == 0 /*MOVE*/ || it.kind == 2 /*DELETION*/);
+    const bool two_sets = use_new && use_old;
+    const int n1 = tp.n1[it.t], nss = two_sets ? 2 * n1 : n1;
     const int kofs[3] = {0, bx.kmax[0] + 1, bx.kmax[0] + bx.kmax[1] + 2};
     const int ktot = bx.kmax[0] + bx.kmax[1] + bx.kmax[2] + 3;
     double2 *s_xy = s_tab + nss * ktot;
@@ -1073,8 +1042,6 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
     RecipRow *s_rows = reinterpret_cast<RecipRow *>(s_q + n1);
     double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
     double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
-    const bool use_new = (it.kind == 0 /*MOVE*/ || it.kind == 1 /*CREATION*/ || it.kind == 4 /*FOURIER_ADD*/);
-    const bool use_old = (it.kind == 0 /*MOVE*/ || it.kind == 2 /*DELETION*/);
     double2 *A = A_base + (size_t)it.replica * bx.n_slots;
 
     for (int r = threadIdx.x; r < n_rows; r += kBlock) s_rows[r] = rows[r];
@@ -1084,7 +1051,13 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
     // (MGPU_RECIP_EARLY_LOAD = 1 requests the first chunk -- all of a thread's tasks at the bench size -- HERE, before
     // the phase tables are built, so that the memory round trip would run under the sincos / XY phases.  Measured on
     // MI355X, 2048 items: k sweep 27.3 -> 35.0 us, commit 25.2 -> 27.5 us: holding 65 VGPRs of loaded data across the
-    // sincos phase spills 37 dwords under the 128-VGPR cap that keeps every item's workgroup resident.)
+    // sincos phase spills 37 dwords under the 128-VGPR cap that keeps every item's workgroup resident.
+    // Round 3, same idea without the registers and without the lock step, all measured slower or equal and removed again:
+    // touching one dword per 128-byte line of A(k) right after the coordinate loads so that HBM fills L2 / Infinity Cache
+    // under the table phases (k sweep 27.0 -> 32.8 us at the SPC/E box, 32.0 -> 41.3 us at the CO2 box; commit 27.4 ->
+    // 31.3 / 33.9 -> 37.4 us: loads return in order, so the touches delay everything behind them); starting the four
+    // workgroups that share a CU 0.5 / 1.2 / 3 us apart (s_sleep) so that they sit in different phases (27.2 -> 27.5 /
+    // 29.8 / 35.4 us); sincospi phase tables (a third of the table phase's instructions: 27.4 vs 27.3 us).)
     int rj[kRecipTaskChunk];
     double2 Ap[kRecipTaskChunk], Am[kRecipTaskChunk], w[kRecipTaskChunk];
     auto load_chunk = [&](int t0) {
@@ -1100,29 +1073,15 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
     };
     constexpr bool kEarly = ((MGPU_RECIP_EARLY_LOAD) >> (COMMIT ? 1 : 0)) & 1;
     if constexpr (kEarly) load_chunk(threadIdx.x);
-    // MGPU_RECIP_PREFETCH (bit 0: k sweep, bit 1: commit): touch one dword of every 128-byte line of this replica's A(k)
-    // right after the site coordinates have been requested, so that HBM delivers A into L2 / Infinity Cache while the
-    // phase tables are built; the values are only consumed at the very end (two live VGPRs), and loads return in
-    // order, so nothing in between waits for them.
-    constexpr bool kPrefetch = ((MGPU_RECIP_PREFETCH) >> (COMMIT ? 1 : 0)) & 1;
-    unsigned pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;
-    [[maybe_unused]] auto prefetch_A = [&]() {
-        const volatile unsigned *line = reinterpret_cast<const volatile unsigned *>(A);
-        const int n_lines = (bx.n_slots * 16 + 127) >> 7;
-        const int l0 = threadIdx.x;
-        if (l0 < n_lines) pf0 = line[l0 * 32];
-        if (l0 + kBlock < n_lines) pf1 = line[(l0 + kBlock) * 32];
-        if (l0 + 2 * kBlock < n_lines) pf2 = line[(l0 + 2 * kBlock) * 32];
-        if (l0 + 3 * kBlock < n_lines) pf3 = line[(l0 + 3 * kBlock) * 32];
-    };
 
-    // phase 1: entry (s = set * n1 + a, axis, k >= 0) at s_tab[s * ktot + kofs[axis] + k]
+    // phase 1: entry (s, axis, k >= 0) at s_tab[s * ktot + kofs[axis] + k]; s = set * n1 + a with both sets, s = a with one
+    // (set 0 = the new sites, set 1 = the old ones)
     for (int e = threadIdx.x; e < nss * ktot; e += kBlock) {
         const int s = e / ktot, kk = e - s * ktot;
-        const int set = s >= n1 ? 1 : 0, a = s - set * n1;
+        const int set = two_sets ? (s >= n1 ? 1 : 0) : (use_old ? 1 : 0), a = s - (s >= n1 ? n1 : 0);
         const int axis = (kk >= kofs[2]) ? 2 : (kk >= kofs[1] ? 1 : 0);
-        // an unused site set still gets finite entries: phase 3 multiplies them by XY = 0
-        const bool used = !((set == 0 && !use_new) || (set == 1 && !use_old));
+        // with no set at all (MGPU_NONE: the energy of A as it is) the entries are zero and phase 3 adds nothing
+        const bool used = use_new || use_old;
         double x = 0.0, y = 0.0, z = 0.0;
         if (used) {
             if (set == 0) {
@@ -1133,19 +1092,17 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
                 x = px[j]; y = py[j]; z = pz[j];
             }
         }
-        if constexpr (kPrefetch) { if (e == (int)threadIdx.x) prefetch_A(); }
         s_tab[e] = used ? phase_entry(atom_phase(bx, axis, x, y, z), kk - kofs[axis]) : make_double2(0.0, 0.0);
     }
-    if constexpr (kPrefetch) { if ((int)threadIdx.x >= nss * ktot) prefetch_A(); }
     for (int a = threadIdx.x; a < n1; a += kBlock) s_q[a] = res_q[it.t * tp.max_atom + a];
     __syncthreads();
 
     // phase 2: XY[row][s] = (+q for the new sites, -q for the old ones) * X[kx] * Y[ky]   (ewald_energy.f90:241-256)
     for (int e = threadIdx.x; e < n_rows * nss; e += kBlock) {
         const int row = e / nss, s = e - row * nss;
-        const int set = s >= n1 ? 1 : 0, a = s - set * n1;
+        const int set = two_sets ? (s >= n1 ? 1 : 0) : (use_old ? 1 : 0), a = s - (s >= n1 ? n1 : 0);
         double2 v = make_double2(0.0, 0.0);
-        if (set == 0 ? use_new : use_old) {
+        if (use_new || use_old) {
             const RecipRow r = s_rows[row];
             const double2 *t = s_tab + s * ktot;
             const int aky = r.ky < 0 ? -r.ky : r.ky;
@@ -1191,10 +1148,6 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
         }
     }
 
-    if constexpr (kPrefetch) {
-        // keep the prefetch registers alive up to here: an empty statement that reads them
-        asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3));
-    }
     if (!COMMIT) {
         acc = wave_sum(acc);
         if (BOTH) acc0 = wave_sum(acc0);

@@ -47,7 +47,7 @@ module mc_farm
     private
     public :: mfarm_create, mfarm_run, mfarm_destroy, mfarm_get_energy, mfarm_get_molecule, mfarm_recalibrate
     public :: mfarm_get_timers, mfarm_set_gcmc, mfarm_get_counts, mfarm_get_counters, mfarm_set_triclinic
-    public :: mfarm_rng_sample
+    public :: mfarm_rng_sample, mfarm_set_drivers
 
     real(real64), parameter :: PI = 3.14159265358979323846_real64
     real(real64), parameter :: TWOPI = 2.0_real64 * PI
@@ -102,7 +102,8 @@ module mc_farm
         integer(int64) :: ticks(7) = 0                     ! generate, submit, wait, resolve, commit, rng, gather
         integer :: rng_kind = 1, n_threads = 1, n_lanes = 2
         integer :: team = 1                                ! OpenMP threads of one lane's loops
-        logical :: lane_threads = .false.                  ! one host thread (plus its team) per lane
+        logical :: lane_threads = .false.                  ! several driver threads (each with its team) share the lanes
+        integer :: n_drivers = 1                           ! driver threads asked for (mfarm_set_drivers; MFARM_LANE_THREADS overrides)
         integer(int64), allocatable :: cxs(:, :)           ! (4, R) xoshiro256+ state of every chain
     end type farm_state
 
@@ -282,6 +283,7 @@ contains
         F%trials = 0; F%accepted = 0; F%counters = 0; F%skipped = 0; F%ticks = 0
         F%rng_kind = rng_kind
         F%n_threads = max(1, int(n_threads))
+        F%n_drivers = 1
         call seed_farm_rng(int(seed), int(n_replicas))
         do g = 0, F%n_lanes - 1
             F%lane(g)%first = min(g * per, n_replicas)
@@ -710,7 +712,7 @@ contains
         integer(c_int), value :: n_steps
         real(c_double), intent(out) :: out(3)
         integer(c_int) :: rc
-        integer :: step, g, lu, ios, nlen
+        integer :: step, g, lu, ios, nlen, n_drv, d
         integer(c_int) :: rc_lane(0:MGPU_LANES - 1)
         integer :: elen, eios
         character(len=16) :: envval
@@ -733,23 +735,35 @@ contains
         ! profiling slots).  Measured on MI355X at the default bench size: the host stops being the limit (it waits
         ! 60 % of the time) but the free-running lanes' pair sweeps share the device and stretch (100 -> 104-112 us),
         ! 5.3 M against 5.9 M accepted moves/s in lock step -- kept as an option for hosts too slow to keep up.
+        ! MFARM_LANE_THREADS=<d>: d driver threads (1 = as many as lanes, the round-2 meaning), each running the lock-step
+        ! loop over ITS lanes (d, d + n_drv, ...) with a team of n_threads / n_drv -- a driver thread with two lanes
+        ! overlaps its own host work on one lane with the GPU's work on the other, and the driver threads overlap
+        ! each other's host work (the grand-canonical boxes are host-bound with one driver)
         F%lane_threads = .false.
+        n_drv = F%n_drivers
         call get_environment_variable("MFARM_LANE_THREADS", envval, elen, eios)
         if (eios == 0 .and. elen > 0) then
-            if (envval(1:1) == "1") F%lane_threads = F%n_lanes > 1 .and. F%rng_kind /= 0 .and. .not. allocated(slog) &
-                                                     .and. F%n_threads >= 2 * F%n_lanes
+            read(envval(1:elen), *, iostat=eios) n_drv
+            if (eios /= 0) n_drv = 1
+            if (n_drv == 1) n_drv = F%n_lanes
         end if
+        n_drv = max(1, min(n_drv, F%n_lanes))
+        F%lane_threads = n_drv > 1 .and. F%rng_kind /= 0 .and. .not. allocated(slog) .and. F%n_threads >= 2 * n_drv
         if (n_steps > 0 .and. F%lane_threads) then
-            F%team = max(1, F%n_threads / F%n_lanes)
+            F%team = max(1, F%n_threads / n_drv)
             call omp_set_max_active_levels(2)
             rc_lane = MGPU_OK
-            !$omp parallel num_threads(F%n_lanes) private(g, step) proc_bind(spread)
-            g = omp_get_thread_num()
-            rc_lane(g) = generate_and_submit(g)
+            !$omp parallel num_threads(n_drv) private(d, g, step) proc_bind(spread)
+            d = omp_get_thread_num()
+            do g = d, F%n_lanes - 1, n_drv
+                rc_lane(g) = generate_and_submit(g)
+            end do
             do step = 1, n_steps
-                if (rc_lane(g) /= MGPU_OK) exit
-                rc_lane(g) = resolve_and_commit(g)
-                if (rc_lane(g) == MGPU_OK .and. step < n_steps) rc_lane(g) = generate_and_submit(g)
+                do g = d, F%n_lanes - 1, n_drv
+                    if (rc_lane(g) /= MGPU_OK) cycle
+                    rc_lane(g) = resolve_and_commit(g)
+                    if (rc_lane(g) == MGPU_OK .and. step < n_steps) rc_lane(g) = generate_and_submit(g)
+                end do
             end do
             !$omp end parallel
             do g = 0, F%n_lanes - 1
@@ -811,6 +825,15 @@ contains
             t = t + F%lane(g)%ticks
         end do
     end subroutine lane_ticks
+
+    ! Driver threads of mfarm_run (1: the calling thread drives all lanes in lock step; d > 1: d threads, each driving
+    ! lanes d0, d0 + d, ... with a team of n_threads / d).  Measured on MI355X (round 3): two drivers on four lanes lift the
+    ! host-bound grand-canonical farms (CO2 box 14.2 -> 19.8 M, framework + water 4.6 -> 5.3 M accepted moves/s) and
+    ! change nothing for the GPU-bound 10 125-atom box (7.16 M either way).
+    subroutine mfarm_set_drivers(n) bind(C, name="mfarm_set_drivers")
+        integer(c_int), value :: n
+        F%n_drivers = max(1, int(n))
+    end subroutine mfarm_set_drivers
 
     ! trial / accepted counts: translations, rotations, creations, deletions (counter_type,
     ! src/simulation_state.f90:19-31)

@@ -74,7 +74,7 @@ class FortranFarm:
     def __init__(self, system: System, n_replicas: int, device: int = 0, seed: int = 1,
                  translation_step: float = 0.3, rotation_step: float = 0.3, p_translation: float = 0.5,
                  rng_kind: int = 1, n_threads: int = 8, mol_capacity=None, gcmc=None,
-                 n_lanes: int = 2):
+                 n_lanes: int = 2, n_drivers: int = 1):
         self.H = lib()
         # mc_farm.f90 keeps ONE farm in module state (as the reference keeps one simulation): a second live
         # instance would silently take it over
@@ -125,6 +125,8 @@ class FortranFarm:
             mat = np.asfortranarray(system.box_matrix, dtype=np.float64)
             rcp = np.asfortranarray(reciprocal, dtype=np.float64)
             self.H.mfarm_set_triclinic(mat.ctypes.data_as(_dp), rcp.ctypes.data_as(_dp), C.c_double(volume))
+        self.H.mfarm_set_drivers(C.c_int(max(1, int(n_drivers))))     # host threads that share the lanes (mc_farm.f90)
+        self.n_drivers = max(1, int(n_drivers))
         self.max_n1 = max_n1
         self.n_lanes = max(1, min(int(n_lanes) if n_lanes > 0 else 2, 4, self.R))
         self.n_active = len(active)
