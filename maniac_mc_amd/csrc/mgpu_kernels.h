@@ -1005,12 +1005,29 @@ struct AcceptBits {
 #ifndef MGPU_RECIP_MINWAVES
 #define MGPU_RECIP_MINWAVES 4   // <= 128 VGPRs: four 4-wave workgroups per CU, 1024 items resident at once
 #endif
+#ifndef MGPU_COMMIT_MINWAVES
+#define MGPU_COMMIT_MINWAVES 5  // the commit needs 76 VGPRs: five workgroups per CU (measured 26.8 -> 24.7 us at the SPC/E box, 17.2 -> 16.0 us
+                                // at the framework box; the k sweep at five: 25.8 -> 28.8 us, it spills below 125 VGPRs)
+#endif
 #ifndef MGPU_RECIP_EARLY_LOAD
 #define MGPU_RECIP_EARLY_LOAD 0   // bit 0 (k sweep) / bit 1 (commit): request the first chunk of A(k) before the phase tables (see below)
 #endif
-constexpr int kRecipTaskChunk = 5;
+// Phase 3 of recip_rows_kernel: a thread's tasks are taken in chunks; with MGPU_RECIP_PIPELINE two chunks are in flight
+// (the next chunk's A(k), weights and task words are requested before the current chunk's arithmetic).  Measured on
+// MI355X, round 3 (k sweep, us per launch: SPC/E box 2048 items / CO2 box 4096 / framework box 2048):
+//   one chunk of 5 (round 2)      25.8 / 47.0 / 21.7      one chunk of 3     26.1 / 42.3 / 17.7
+//   one chunk of 4                28.7 / 44.0 / 19.8      pipelined, 2 + 2   25.7 / 40.8 / 18.2   <- default
+//   pipelined, 3 + 3 (spills)     38.4 / 67.6 / 20.9
+// A thread visits its tasks in ascending order whatever the chunking, so the sums are the same bits.
+#ifndef MGPU_RECIP_PIPELINE
+#define MGPU_RECIP_PIPELINE 1
+#endif
+#ifndef MGPU_RECIP_TASK_CHUNK
+#define MGPU_RECIP_TASK_CHUNK 2
+#endif
+constexpr int kRecipTaskChunk = MGPU_RECIP_TASK_CHUNK;   // tasks a thread requests ahead of their use
 template <bool COMMIT, bool BOTH>
-__global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel(
+__global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_MINWAVES) void recip_rows_kernel(
     Topo tp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
     const int *__restrict__ trj, const double2 *__restrict__ tw, int n_tasks, const RecipRow *__restrict__ rows, int n_rows,
     double2 *__restrict__ A_base, const RecipItem *__restrict__ items,
@@ -1058,21 +1075,24 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
     // 31.3 / 33.9 -> 37.4 us: loads return in order, so the touches delay everything behind them); starting the four
     // workgroups that share a CU 0.5 / 1.2 / 3 us apart (s_sleep) so that they sit in different phases (27.2 -> 27.5 /
     // 29.8 / 35.4 us); sincospi phase tables (a third of the table phase's instructions: 27.4 vs 27.3 us).)
-    int rj[kRecipTaskChunk];
-    double2 Ap[kRecipTaskChunk], Am[kRecipTaskChunk], w[kRecipTaskChunk];
-    auto load_chunk = [&](int t0) {
+    struct Chunk {
+        int rj[kRecipTaskChunk];
+        double2 Ap[kRecipTaskChunk], Am[kRecipTaskChunk], w[kRecipTaskChunk];
+    };
+    Chunk ch0;
+    auto load_chunk = [&](Chunk &ch, int t0) {
 #pragma unroll
         for (int c = 0; c < kRecipTaskChunk; ++c) {
             const int t = t0 + c * kBlock;
             const bool in = t < n_tasks;
-            rj[c] = in ? trj[t] : 0;                                   // filler: row 0, j 0, nothing present
-            Ap[c] = in ? A[2 * t] : make_double2(0.0, 0.0);
-            Am[c] = in ? A[2 * t + 1] : make_double2(0.0, 0.0);
-            w[c] = (in && !COMMIT) ? tw[t] : make_double2(0.0, 0.0);
+            ch.rj[c] = in ? trj[t] : 0;                                // filler: row 0, j 0, nothing present
+            ch.Ap[c] = in ? A[2 * t] : make_double2(0.0, 0.0);
+            ch.Am[c] = in ? A[2 * t + 1] : make_double2(0.0, 0.0);
+            ch.w[c] = (in && !COMMIT) ? tw[t] : make_double2(0.0, 0.0);
         }
     };
     constexpr bool kEarly = ((MGPU_RECIP_EARLY_LOAD) >> (COMMIT ? 1 : 0)) & 1;
-    if constexpr (kEarly) load_chunk(threadIdx.x);
+    if constexpr (kEarly) load_chunk(ch0, threadIdx.x);
 
     // phase 1: entry (s, axis, k >= 0) at s_tab[s * ktot + kofs[axis] + k]; s = set * n1 + a with both sets, s = a with one
     // (set 0 = the new sites, set 1 = the old ones)
@@ -1118,12 +1138,13 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
 
     const double2 *zt = s_tab + kofs[2];
     double acc = 0.0, acc0 = 0.0;
-    for (int t0 = threadIdx.x; t0 < n_tasks; t0 += kBlock * kRecipTaskChunk) {
-        if (!kEarly || t0 != (int)threadIdx.x) load_chunk(t0);
+    // the tasks of one chunk: a thread's tasks are visited in ascending order whatever the chunk size, so the sums do
+    // not depend on it
+    auto compute_chunk = [&](const Chunk &ch, int t0) {
 #pragma unroll
         for (int c = 0; c < kRecipTaskChunk; ++c) {
-            const double2 *xy = s_xy + ((rj[c] >> 8) & 0xfffff) * nss;
-            const double2 *z = zt + (rj[c] & 0xff);
+            const double2 *xy = s_xy + ((ch.rj[c] >> 8) & 0xfffff) * nss;
+            const double2 *z = zt + (ch.rj[c] & 0xff);
             double sac = 0.0, sbd = 0.0, sad = 0.0, sbc = 0.0;
             for (int s = 0; s < nss; ++s) {
                 const double2 p = xy[s], q = z[s * ktot];
@@ -1132,21 +1153,45 @@ __global__ __launch_bounds__(kBlock, MGPU_RECIP_MINWAVES) void recip_rows_kernel
                 sad = fma(p.x, q.y, sad);
                 sbc = fma(p.y, q.x, sbc);
             }
-            const double wp = w[c].x, wm = w[c].y;
-            if (BOTH) acc0 += wp * fma(Ap[c].x, Ap[c].x, Ap[c].y * Ap[c].y) + wm * fma(Am[c].x, Am[c].x, Am[c].y * Am[c].y);
-            const double npx = Ap[c].x + (sac - sbd), npy = Ap[c].y + (sad + sbc);
-            const double nmx = Am[c].x + (sac + sbd), nmy = Am[c].y + (sbc - sad);
+            const double wp = ch.w[c].x, wm = ch.w[c].y;
+            if (BOTH) acc0 += wp * fma(ch.Ap[c].x, ch.Ap[c].x, ch.Ap[c].y * ch.Ap[c].y) + wm * fma(ch.Am[c].x, ch.Am[c].x, ch.Am[c].y * ch.Am[c].y);
+            const double npx = ch.Ap[c].x + (sac - sbd), npy = ch.Ap[c].y + (sad + sbc);
+            const double nmx = ch.Am[c].x + (sac + sbd), nmy = ch.Am[c].y + (sbc - sad);
             if (COMMIT) {
                 const int t = t0 + c * kBlock;
                 if (t < n_tasks) {        // absent members stay zero
-                    A[2 * t] = (rj[c] & kTaskHasP) ? make_double2(npx, npy) : make_double2(0.0, 0.0);
-                    A[2 * t + 1] = (rj[c] & kTaskHasM) ? make_double2(nmx, nmy) : make_double2(0.0, 0.0);
+                    A[2 * t] = (ch.rj[c] & kTaskHasP) ? make_double2(npx, npy) : make_double2(0.0, 0.0);
+                    A[2 * t + 1] = (ch.rj[c] & kTaskHasM) ? make_double2(nmx, nmy) : make_double2(0.0, 0.0);
                 }
             } else {
                 acc += wp * fma(npx, npx, npy * npy) + wm * fma(nmx, nmx, nmy * nmy);   // ewald_energy.f90:259-266
             }
         }
+    };
+    constexpr int kStride = kBlock * kRecipTaskChunk;
+#if MGPU_RECIP_PIPELINE
+    // two chunks in flight: the next chunk's A(k) is requested before the current one is consumed
+    {
+        Chunk ch1;
+        int t0 = threadIdx.x;
+        if (!kEarly && t0 < n_tasks) load_chunk(ch0, t0);
+        while (t0 < n_tasks) {
+            const int t1 = t0 + kStride;
+            if (t1 < n_tasks) load_chunk(ch1, t1);
+            compute_chunk(ch0, t0);
+            if (t1 >= n_tasks) break;
+            const int t2 = t1 + kStride;
+            if (t2 < n_tasks) load_chunk(ch0, t2);
+            compute_chunk(ch1, t1);
+            t0 = t2;
+        }
     }
+#else
+    for (int t0 = threadIdx.x; t0 < n_tasks; t0 += kStride) {
+        if (!kEarly || t0 != (int)threadIdx.x) load_chunk(ch0, t0);
+        compute_chunk(ch0, t0);
+    }
+#endif
 
     if (!COMMIT) {
         acc = wave_sum(acc);

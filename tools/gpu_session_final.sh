@@ -1,0 +1,23 @@
+#!/bin/bash
+# round-3 measurement session on the final build: PMC passes (sha-tied), rocprofv3 kernel stats, bench lines
+set -e -o pipefail
+out=gpurun_out/r3final
+mkdir -p $out
+export TMPDIR=/tmp
+sha256sum maniac_mc_amd/libmaniac_hip.so > $out/lib_sha256.txt
+bash tools/pmc_passes.sh $out/pmc r03 2048 2 spce > $out/pmc_spce.log 2>&1
+bash tools/pmc_passes.sh $out/pmc r03 4096 1 co2_gcmc > $out/pmc_co2.log 2>&1
+bash tools/pmc_passes.sh $out/pmc r03 2048 2 framework_water > $out/pmc_fw.log 2>&1
+for wl in spce co2_gcmc framework_water; do
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$out/prof_$wl -o p -- python3 /root/repo/bench.py --workload $wl --no-cpu-baseline --steps 300 > /root/repo/$out/bench_${wl}_under_rocprof.json 2> /root/repo/$out/bench_${wl}_under_rocprof.err)
+done
+python bench.py --steps 20 --warmup 5 > $out/bench_driver_format.json 2> $out/bench_driver_format.err
+python bench.py > $out/bench_spce.json 2> $out/bench_spce.err
+python bench.py --workload co2_gcmc > $out/bench_co2_gcmc.json 2> $out/bench_co2_gcmc.err
+python bench.py --workload framework_water > $out/bench_framework_water.json 2> $out/bench_framework_water.err
+python bench.py --workload co2_isotherm > $out/bench_co2_isotherm.json 2> $out/bench_co2_isotherm.err
+python bench.py --host-threads 2 --no-cpu-baseline > $out/bench_spce_T2.json 2> $out/bench_spce_T2.err
+python tools/chain_speed.py --blocks 2 --steps 1500 > $out/chain_speed.txt 2>&1
+for wl in spce co2_gcmc framework_water; do python tools/bench_kernels.py --replicas 2048 --reps 5 --workload $wl > $out/k_${wl}_R2048.json; done
+python tools/bench_kernels.py --replicas 4096 --reps 5 --workload co2_gcmc > $out/k_co2_gcmc_R4096.json
+echo done
