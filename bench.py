@@ -608,13 +608,14 @@ def main():
         if pair_dominant:
             # Pair sweep: bound by fp64 vector issue, not by HBM (measured HBM-side traffic is a fraction of the
             # algorithmic bytes).  achieved = ALGORITHMIC flops (64 per site-atom pair term) over time.
-            pmc = pmc_summary(wl, "pair_sweep_kernel")
+            pmc = pmc_summary(wl, "::pair_")
             fresh = bool(pmc) and not pmc["stale"] and pmc.get("valu_instr_per_eval") is not None
             job_tflops = evals_rank * flop_eval / elapsed / 1e12
             launch_tflops = evals_rank * flop_eval / (ms_pair * 1e-3) / 1e12 if ms_pair else None
             roof = {"bound": "valu", "bound_note": "fp64 vector issue (the contract's hbm / mfma do not apply: measured HBM-side "
                                                    "traffic is a fraction of the algorithmic bytes and there is no MFMA-shaped work; SURVEY 8(d))",
-                    "kernel": "pair_sweep_kernel (trial moves: old + new state in one sweep; insertions / deletions: one state)",
+                    "kernel": "pair_flat_kernel<4,...> (framework box: one software-pipelined loop over all units, single-state items)" if wl == "framework_water"
+                              else "pair_sweep_kernel<3,false,false,true,true> (old + new state of a trial move in one sweep, two-instruction fold)",
                     "achieved": job_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": job_tflops / FP64_VECTOR_PEAK_TFLOPS,
                     "achieved_basis": f"ALGORITHMIC flops: {FLOP_PER_PAIR:g} per site-atom pair term x {n1} sites x (N - {n1}) atoms = "

@@ -296,7 +296,11 @@ int engine_nsplit(const mgpu_engine *e) {
     }
     int cap_split = 16;
     if (e->n_replicas >= 256) {
-        const int want = std::max(1, e->n_cu * 64 / e->n_replicas);
+        int want = std::max(1, e->n_cu * 64 / e->n_replicas);
+        // Short work units (the grand-canonical boxes: a few dozen units per item, and a launch carries 1.5 items per
+        // candidate) are dominated by their tail: twice the waves per item fill the last round (round 3, framework box,
+        // 3064 items per launch on 4096 resident waves: nsplit 2 = 1.5 rounds of 19 units, nsplit 4 = 3 rounds of 10)
+        if (units <= 128) want *= 2;
         cap_split = 1;
         while (cap_split * 2 <= std::min(want, 4)) cap_split *= 2;
     }

@@ -5,11 +5,16 @@ out=gpurun_out/r3final
 mkdir -p $out
 export TMPDIR=/tmp
 sha256sum maniac_mc_amd/libmaniac_hip.so > $out/lib_sha256.txt
+python -m pytest tests -m gpu -x -q > $out/pytest.log 2>&1 || { tail -80 $out/pytest.log; exit 1; }
+tail -3 $out/pytest.log
 bash tools/pmc_passes.sh $out/pmc r03 2048 2 spce > $out/pmc_spce.log 2>&1
-bash tools/pmc_passes.sh $out/pmc r03 4096 1 co2_gcmc > $out/pmc_co2.log 2>&1
-bash tools/pmc_passes.sh $out/pmc r03 2048 2 framework_water > $out/pmc_fw.log 2>&1
+bash tools/pmc_passes.sh $out/pmc r03 4096 2 co2_gcmc > $out/pmc_co2.log 2>&1
+bash tools/pmc_passes.sh $out/pmc r03 2048 4 framework_water > $out/pmc_fw.log 2>&1
+mkdir -p profiles/r03
+for wl in spce co2_gcmc framework_water; do cp $out/pmc/pmc_${wl}_r03.json profiles/r03/pmc_${wl}.json; done
 for wl in spce co2_gcmc framework_water; do
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$out/prof_$wl -o p -- python3 /root/repo/bench.py --workload $wl --no-cpu-baseline --steps 300 > /root/repo/$out/bench_${wl}_under_rocprof.json 2> /root/repo/$out/bench_${wl}_under_rocprof.err)
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$out/prof_$wl -o p -- python3 /root/repo/bench.py --workload $wl --no-cpu-baseline --steps 200 --settle-s 0 --sustained-steps 0 > /root/repo/$out/bench_${wl}_under_rocprof.json 2> /root/repo/$out/bench_${wl}_under_rocprof.err)
+  rm -f $out/prof_$wl/*kernel_trace.csv
 done
 python bench.py --steps 20 --warmup 5 > $out/bench_driver_format.json 2> $out/bench_driver_format.err
 python bench.py > $out/bench_spce.json 2> $out/bench_spce.err
@@ -20,4 +25,6 @@ python bench.py --host-threads 2 --no-cpu-baseline > $out/bench_spce_T2.json 2> 
 python tools/chain_speed.py --blocks 2 --steps 1500 > $out/chain_speed.txt 2>&1
 for wl in spce co2_gcmc framework_water; do python tools/bench_kernels.py --replicas 2048 --reps 5 --workload $wl > $out/k_${wl}_R2048.json; done
 python tools/bench_kernels.py --replicas 4096 --reps 5 --workload co2_gcmc > $out/k_co2_gcmc_R4096.json
+rm -rf $out/pmc/*/*/*kernel_trace.csv
+du -sh $out
 echo done
