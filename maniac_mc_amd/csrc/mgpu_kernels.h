@@ -1154,7 +1154,9 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
                 sbc = fma(p.y, q.x, sbc);
             }
             const double wp = ch.w[c].x, wm = ch.w[c].y;
-            if (BOTH) acc0 += wp * fma(ch.Ap[c].x, ch.Ap[c].x, ch.Ap[c].y * ch.Ap[c].y) + wm * fma(ch.Am[c].x, ch.Am[c].x, ch.Am[c].y * ch.Am[c].y);
+            // explicit fma forms: the deferred-commit kernel must produce the same bits, and a contraction left to the
+            // compiler may pick a different product to fuse in a different kernel
+            if (BOTH) acc0 += fma(wp, fma(ch.Ap[c].x, ch.Ap[c].x, ch.Ap[c].y * ch.Ap[c].y), wm * fma(ch.Am[c].x, ch.Am[c].x, ch.Am[c].y * ch.Am[c].y));
             const double npx = ch.Ap[c].x + (sac - sbd), npy = ch.Ap[c].y + (sad + sbc);
             const double nmx = ch.Am[c].x + (sac + sbd), nmy = ch.Am[c].y + (sbc - sad);
             if (COMMIT) {
@@ -1164,7 +1166,7 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
                     A[2 * t + 1] = (ch.rj[c] & kTaskHasM) ? make_double2(nmx, nmy) : make_double2(0.0, 0.0);
                 }
             } else {
-                acc += wp * fma(npx, npx, npy * npy) + wm * fma(nmx, nmx, nmy * nmy);   // ewald_energy.f90:259-266
+                acc += fma(wp, fma(npx, npx, npy * npy), wm * fma(nmx, nmx, nmy * nmy));   // ewald_energy.f90:259-266
             }
         }
     };
@@ -1419,10 +1421,10 @@ __global__ __launch_bounds__(kBlock, 2) void trial_k_kernel(
         double sac, sbd, sad, sbc;
         task_sums(rj[c], 0, n1c, sac, sbd, sad, sbc);
         const double wp = w[c].x, wm = w[c].y;
-        acc0 += wp * fma(Ap[c].x, Ap[c].x, Ap[c].y * Ap[c].y) + wm * fma(Am[c].x, Am[c].x, Am[c].y * Am[c].y);
+        acc0 += fma(wp, fma(Ap[c].x, Ap[c].x, Ap[c].y * Ap[c].y), wm * fma(Am[c].x, Am[c].x, Am[c].y * Am[c].y));
         const double npx = Ap[c].x + (sac - sbd), npy = Ap[c].y + (sad + sbc);
         const double nmx = Am[c].x + (sac + sbd), nmy = Am[c].y + (sbc - sad);
-        acc += wp * fma(npx, npx, npy * npy) + wm * fma(nmx, nmx, nmy * nmy);   // ewald_energy.f90:259-266
+        acc += fma(wp, fma(npx, npx, npy * npy), wm * fma(nmx, nmx, nmy * nmy));   // ewald_energy.f90:259-266
     }
     acc = wave_sum(acc);
     acc0 = wave_sum(acc0);
