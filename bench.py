@@ -329,14 +329,17 @@ def cpu_baseline_gcmc(system, t_act, p_move, translation_step, rotation_step, fu
 
 WORKLOADS = {
     # name: default chains per GPU, lanes, what BASELINE.json calls it
-    "spce": dict(replicas=8192, lanes=4, drivers=1, threads=6, config="metric workload: 10 125-atom SPC/E box (configs[1] recipe at 15^3)"),
+    # device_build: the engine keeps the molecules' frames and builds the trial geometry itself (no host mirror, no candidate
+    # rows staged; measured round 3, SPC/E: 1 / 2 / 6 host threads 5.25 / 7.02 / 7.41 M host-built, 7.24 / 7.31 / 7.32 M
+    # device-built -- one host thread per GPU then keeps the GPU busy)
+    "spce": dict(replicas=8192, lanes=4, drivers=1, threads=6, device_build=1, config="metric workload: 10 125-atom SPC/E box (configs[1] recipe at 15^3)"),
     # the grand-canonical boxes are small (a few hundred atoms): per lane step the fixed host costs (OpenMP regions, HIP calls)
     # weigh as much as the kernels, so they run MANY chains (measured round 3, co2_gcmc, one driver thread: 2048 x 2 lanes
     # 5.4 M, 8192 x 4 6.6 M, 8192 x 2 11.2 M, 16384 x 2 13.7 M accepted moves/s) and TWO host driver threads sharing four
     # lanes (16384 x 4 lanes, 8 threads: 19.8 M; the SPC/E box is GPU-bound and gains nothing from a second driver)
-    "co2_gcmc": dict(replicas=16384, lanes=4, drivers=2, threads=8, config="configs[2]: GCMC of CO2 in a 50 A box, insertion / deletion at one fugacity"),
-    "framework_water": dict(replicas=8192, lanes=4, drivers=2, threads=8, config="configs[3] stand-in: 2208-atom framework + 4-site water, full move set"),
-    "co2_isotherm": dict(replicas=16384, lanes=4, drivers=2, threads=8, config="configs[4]: 8 fugacity points dealt over the ranks"),
+    "co2_gcmc": dict(replicas=16384, lanes=4, drivers=2, threads=8, device_build=1, config="configs[2]: GCMC of CO2 in a 50 A box, insertion / deletion at one fugacity"),
+    "framework_water": dict(replicas=8192, lanes=4, drivers=2, threads=8, device_build=1, config="configs[3] stand-in: 2208-atom framework + 4-site water, full move set"),
+    "co2_isotherm": dict(replicas=16384, lanes=4, drivers=2, threads=8, device_build=1, config="configs[4]: 8 fugacity points dealt over the ranks"),
 }
 
 
@@ -359,6 +362,9 @@ def main():
     ap.add_argument("--drivers", type=int, default=None,
                     help="host driver threads of the Fortran farm that share the lanes, each with a team of host-threads / drivers "
                          "(default 1 for SPC/E, 2 for the grand-canonical workloads)")
+    ap.add_argument("--device-build", type=int, default=None, choices=[0, 1],
+                    help="1: the engine keeps the molecules' frames and builds the trial moves on the device (no host mirror, no "
+                         "candidate rows staged); 0: the Fortran driver builds them from its mirror (default: see WORKLOADS)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -444,7 +450,10 @@ def main():
         from maniac_mc_amd.farm import ReplicaFarm as Farm
     if wl != "spce" and args.host != "fortran":
         sys.exit("bench.py: the grand-canonical workloads run on the Fortran farm")
-    kw = dict(n_threads=args.host_threads, n_lanes=args.lanes, n_drivers=args.drivers) if args.host == "fortran" else {}
+    if args.device_build is None:
+        args.device_build = WORKLOADS[wl].get("device_build", 0)
+    kw = dict(n_threads=args.host_threads, n_lanes=args.lanes, n_drivers=args.drivers,
+              device_build=bool(args.device_build)) if args.host == "fortran" else {}
     R = args.replicas
     iso_pts, fug_grid, point_of_chain = None, None, None
     t_act, p_move, fug_one = 0, 1.0, None        # active residue type, share of translation + rotation, the fugacity
@@ -681,7 +690,8 @@ def main():
                                     "co2_isotherm": f"co2_isotherm_{ISOTHERM_POINTS}fugacities_50A_box_Nk{Nk}"}[wl],
                        "baseline_config": WORKLOADS[wl]["config"],
                        "replicas_per_gpu": R, "host_driver": args.host, "host_threads": args.host_threads if args.host == "fortran" else 1,
-                       "lanes": n_lanes, "host_drivers": args.drivers, "host_cores": pinned, "moves": moves,
+                       "lanes": n_lanes, "host_drivers": args.drivers, "trial_geometry": "device-built" if args.device_build else "host-built",
+                       "host_cores": pinned, "moves": moves,
                        "trials_per_step": R * world, "parallelism": f"replicas x{world}"},
             "trial_moves_per_s": tot_trials / elapsed,
             "acceptance": tot_acc / max(1.0, tot_trials),

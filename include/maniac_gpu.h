@@ -266,6 +266,25 @@ int mgpu_commit_candidates(mgpu_engine *e, int n_candidates, const int *replica,
  * mgpu_commit_submit accepts sites = NULL when it commits the candidates of the lane's last
  * mgpu_trial_submit (same n_candidates, order and site_stride): their rows are still on the device. */
 #define MGPU_LANES 4
+/* Molecule frames -- what the reference keeps per molecule: com[n_mol][3] = primary%mol_com and off[n_mol][n1][3] =
+ * primary%site_offset (src/simulation_state.f90:115-116).  mgpu_replica_set_frames uploads them together with the sites
+ * com + off (formed as src/geometry_utils.f90:379-382 forms them before every use) and keeps them resident, so that trial
+ * moves can be BUILT on the device: a host then needs neither a mirror of the coordinates nor to stage candidate rows.
+ * mgpu_replica_set_molecules (sites only) drops a residue type's frames again. */
+int mgpu_replica_set_frames(mgpu_engine *e, int replica, int t, int n_mol, const double *com, const double *off);
+int mgpu_replica_get_frames(mgpu_engine *e, int replica, int t, int *n_mol, double *com, double *off);
+/* One trial per candidate, its geometry built on the device from the resident frames (orthorhombic boxes):
+ *   move[c] = 1  Translation      com <- ApplyPBC(com + (u[c][0..2] - 1/2) translation_step)      src/translation.f90:93-112
+ *           = 2  Rotation         offsets rotated by (u[c][3] - 1/2) rotation_step about Cartesian axis int(3 u[c][4]) + 1
+ *                                                                                                src/monte_carlo_utils.f90:30-92
+ *           = 3  CreateMolecule   com <- lo + L u[c][0..2]; offsets of molecule 1 of the type rotated by 2 pi u[c][3]
+ *                                 about that axis; m ignored                                       src/create_molecule.f90:166-207
+ *           = 4  DeleteMolecule   the resident molecule m as it is
+ * u = n x 5 uniform numbers in [0, 1) drawn by the host (the random stream stays on the host, as the acceptance does).
+ * Energies come back through mgpu_gcmc_trial_wait; mgpu_commit_submit(sites = NULL) on the same lane applies the accepted
+ * candidates from the rows the device built, sites and frames. */
+int mgpu_move_trial_submit(mgpu_engine *e, int lane, int n_candidates, const int *replica, const int *t, const int *m,
+                           const int *move, const double *u, double translation_step, double rotation_step);
 /* Pinned staging of a lane's NEXT trial, sized for n_max candidates of site_stride sites: a host that builds its
  * candidate rows directly in *sites and then passes that same pointer as `sites` to mgpu_trial_submit /
  * mgpu_gcmc_trial_submit on this lane (with at most n_max candidates and the same site_stride) saves the engine's copy

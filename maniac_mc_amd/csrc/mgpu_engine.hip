@@ -82,6 +82,8 @@ struct Lane {
     int n_submitted = 0;          // candidates of the trial in flight (0 = none)
     bool dirty = false;           // something was queued on the stream since its last synchronise (asynchronous entry points)
     int last_trial_n = 0, last_trial_stride = 0;   // shape of the site rows still resident in d_sites
+    bool last_trial_built = false;                 // ... built on the device (rows carry the candidates' frames)
+    int last_trial_frame = 0;                      // site index of the frame inside such a row
     int n_pair_items = 0, n_split = 1;   // reduced pair-energy entries of the trial in flight (2 per fused item + 1 per single)
     int n_fused = 0;                      // of which the first 2 * n_fused belong to fused (old + new) items
     const RecipItem *d_trial_items = nullptr;   // RecipItems of the last trial, resident while last_trial_n != 0
@@ -90,6 +92,7 @@ struct Lane {
     std::vector<int> pair_old, pair_new, intra_idx, kinds;   // per-candidate rows of the trial in flight
     std::vector<double> self_of;                              // per-candidate Ewald self term (host constant)
     std::vector<char> cand_ok;                                // per candidate: its sites are within the fast fold's range
+    std::vector<int> build_kind;                              // candidate kinds of a device-built trial
     std::vector<double> h_lj, h_cc;                           // pair energies of the trial being collected
     // A commit of the lane's last trial that has been accepted by the host but not launched: the lane's next
     // trial_submit folds it into its k sweep (trial_k_kernel); anything else that needs the engine's state flushes it
@@ -169,6 +172,11 @@ struct mgpu_engine {
     std::vector<char> frozen;        // [n_res]
     bool any_frozen = false;
     int *d_atom_ty = nullptr;        // [Ncap] 0-based atom type of every slot (pair_flat_kernel fetches it per lane)
+    // molecule frames (mgpu_replica_set_frames): com [R][3][n_mol_slots], off [R][3][Ncap]; allocated on first use
+    double *d_com = nullptr, *d_off = nullptr;
+    std::vector<char> frames_ok;     // [R][n_res]: the frames of (replica, type) mirror its sites
+    std::vector<char> frames_tight;  // [R][n_res]: every molecule's centre lies in the cell and its offsets within 0.24 L:
+                                     // any device-built candidate then lies within the fast fold's range
     // Register-site sweeps of this engine go through pair_flat_kernel (one software-pipelined loop over all units of
     // a work unit) instead of the plane-by-plane pair_sweep_kernel: chosen at creation for topologies with short planes
     // (every plane-major residue type has at most kFlatMaxCap molecule slots) or a frozen residue; MGPU_PAIR_FLAT=0 / 1
@@ -704,6 +712,12 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
         off += atoms_in_res[t] * mol_capacity[t];
     }
     tp.n_cap_atoms = off;
+    tp.com = nullptr;
+    tp.off = nullptr;
+    tp.n_mol_slots = 0;
+    for (int t = 0; t < n_res; ++t) { tp.mol_off[t] = tp.n_mol_slots; tp.n_mol_slots += mol_capacity[t]; }
+    e->frames_ok.assign((size_t)n_replicas * n_res, 0);
+    e->frames_tight.assign((size_t)n_replicas * n_res, 0);
     // Layout of the big inactive residues and the register-site pair kernel go together: "frozen" (sites sorted by
     // atom type, one group per type present) + pair_flat_kernel, or site-major + pair_sweep_kernel.  Default: flat
     // wherever a framework (inactive, >= 64 atoms) is present -- measured round 3, 2208-atom framework + 4-site water,
@@ -777,6 +791,7 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     for (int d = 0; d < 3; ++d) {
         bx.L[d] = box_matrix[d * 3 + d]; bx.invL[d] = 1.0 / bx.L[d]; bx.kmax[d] = e->kmax[d];
         bx.ctr[d] = bounds_lo[d] + 0.5 * bx.L[d];
+        bx.lo[d] = bounds_lo[d];
     }
     std::memcpy(bx.rcp, e->reciprocal, sizeof(double) * 9);
     std::memcpy(bx.m, box_matrix, sizeof(double) * 9);
@@ -946,7 +961,7 @@ int mgpu_engine_destroy(mgpu_engine *e) {
     for (void *p : {(void *)e->d_pos, (void *)e->d_nmol, (void *)e->d_A, (void *)e->d_kpack, (void *)e->d_kw,
                     (void *)e->d_pair_tab, (void *)e->d_coul_tab, (void *)e->d_res_q, (void *)e->d_res_atype, (void *)e->d_atom_res,
                     (void *)e->d_atom_mol, (void *)e->d_atom_q, (void *)e->d_phase_tab, (void *)e->d_S, (void *)e->d_trj,
-                    (void *)e->d_tw, (void *)e->d_kslot, (void *)e->d_rrows, (void *)e->d_atom_ty})
+                    (void *)e->d_tw, (void *)e->d_kslot, (void *)e->d_rrows, (void *)e->d_atom_ty, (void *)e->d_com, (void *)e->d_off})
         if (p) (void)hipFree(p);
     e->h_stage.release();
     for (auto &ln : e->lanes) {
@@ -1017,6 +1032,7 @@ int mgpu_replica_set_molecules(mgpu_engine *e, int replica, int t, int n_mol, co
         HIP_TRY(hipMemcpy(e->d_pos + ((size_t)replica * 3 + d) * tp.n_cap_atoms + tp.seg_off[t], st + d * seg,
                           seg * sizeof(double), hipMemcpyHostToDevice));
     e->h_nmol[replica * tp.n_res + t] = n_mol;
+    e->frames_ok[(size_t)replica * tp.n_res + t] = 0;       // sites given without com / offsets (set_frames sets it again)
     e->in_range[(size_t)replica * tp.n_res + t] = sites_in_range(e, sites, n_mol * n1) ? 1 : 0;
     HIP_TRY(hipMemcpy(e->d_nmol + replica * tp.n_res + t, &n_mol, sizeof(int), hipMemcpyHostToDevice));
     return MGPU_OK;
@@ -1044,6 +1060,93 @@ int mgpu_replica_get_molecules(mgpu_engine *e, int replica, int t, int *n_mol, d
             const size_t j = tp.site_major[t] ? (size_t)m * n1 + perm[a] : (size_t)a * cap + m;
             for (int d = 0; d < 3; ++d) sites[((size_t)m * n1 + a) * 3 + d] = st[d * seg + j];
         }
+    return MGPU_OK;
+}
+
+// Molecule frames of one residue type as the reference keeps them: com[n_mol][3] = primary%mol_com, off[n_mol][n1][3] =
+// primary%site_offset (simulation_state.f90:115-116).  The sites com + off are formed here exactly as the reference forms
+// them before every use (geometry_utils.f90:379-382) and uploaded as mgpu_replica_set_molecules does.
+int mgpu_replica_set_frames(mgpu_engine *e, int replica, int t, int n_mol, const double *com, const double *off) {
+    int rc = check_replica_t(e, replica, t);
+    if (rc) return rc;
+    if (n_mol < 0 || n_mol > e->tp.cap[t]) return set_error(MGPU_ERR_CAPACITY, "n_mol exceeds the residue type's mol_capacity");
+    if (n_mol > 0 && (!com || !off)) return set_error(MGPU_ERR_INVALID_ARG, "set_frames: null argument");
+    if (e->frozen[t]) return set_error(MGPU_ERR_INVALID_ARG, "set_frames: frozen (inactive framework) residue types carry no frames");
+    if ((rc = use_device(e))) return rc;
+    const Topo &tp = e->tp;
+    const int n1 = tp.n1[t], cap = tp.cap[t];
+    std::vector<double> sites((size_t)n_mol * n1 * 3);
+    bool tight = true;
+    for (int m = 0; m < n_mol; ++m) {
+        for (int d = 0; d < 3; ++d)
+            tight = tight && std::fabs(com[(size_t)m * 3 + d] - e->bx.ctr[d]) <= 0.5 * e->bx.L[d];
+        for (int a = 0; a < n1; ++a)
+            for (int d = 0; d < 3; ++d) {
+                const double o = off[((size_t)m * n1 + a) * 3 + d];
+                sites[((size_t)m * n1 + a) * 3 + d] = com[(size_t)m * 3 + d] + o;
+                tight = tight && std::fabs(o) <= 0.24 * e->bx.L[d];
+            }
+    }
+    if ((rc = mgpu_replica_set_molecules(e, replica, t, n_mol, sites.data()))) return rc;
+    if (!e->d_com) {
+        const size_t R = e->n_replicas;
+        HIP_TRY(hipMalloc(&e->d_com, R * 3 * tp.n_mol_slots * sizeof(double)));
+        HIP_TRY(hipMemset(e->d_com, 0, R * 3 * tp.n_mol_slots * sizeof(double)));
+        HIP_TRY(hipMalloc(&e->d_off, R * 3 * tp.n_cap_atoms * sizeof(double)));
+        HIP_TRY(hipMemset(e->d_off, 0, R * 3 * tp.n_cap_atoms * sizeof(double)));
+        e->tp.com = e->d_com;
+        e->tp.off = e->d_off;
+    }
+    const size_t seg = (size_t)n1 * cap;
+    if ((rc = e->h_stage.reserve(3 * (seg + cap) * sizeof(double)))) return rc;
+    double *st = (double *)e->h_stage.p, *sc = st + 3 * seg;
+    std::memset(st, 0, 3 * (seg + cap) * sizeof(double));
+    for (int m = 0; m < n_mol; ++m) {
+        for (int d = 0; d < 3; ++d) sc[(size_t)d * cap + m] = com[(size_t)m * 3 + d];
+        for (int a = 0; a < n1; ++a) {
+            const size_t j = tp.site_major[t] ? (size_t)m * n1 + a : (size_t)a * cap + m;
+            for (int d = 0; d < 3; ++d) st[d * seg + j] = off[((size_t)m * n1 + a) * 3 + d];
+        }
+    }
+    for (int d = 0; d < 3; ++d) {
+        HIP_TRY(hipMemcpy(e->d_off + ((size_t)replica * 3 + d) * tp.n_cap_atoms + tp.seg_off[t], st + d * seg, seg * sizeof(double),
+                          hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->d_com + ((size_t)replica * 3 + d) * tp.n_mol_slots + tp.mol_off[t], sc + (size_t)d * cap, cap * sizeof(double),
+                          hipMemcpyHostToDevice));
+    }
+    e->frames_ok[(size_t)replica * tp.n_res + t] = 1;
+    e->frames_tight[(size_t)replica * tp.n_res + t] = tight ? 1 : 0;
+    return MGPU_OK;
+}
+
+int mgpu_replica_get_frames(mgpu_engine *e, int replica, int t, int *n_mol, double *com, double *off) {
+    int rc = check_replica_t(e, replica, t);
+    if (rc) return rc;
+    if ((rc = use_device(e))) return rc;
+    const Topo &tp = e->tp;
+    const int n1 = tp.n1[t], cap = tp.cap[t], nm = e->h_nmol[replica * tp.n_res + t];
+    if (n_mol) *n_mol = nm;
+    if ((!com && !off) || nm == 0) return MGPU_OK;
+    if (!e->d_com || !e->frames_ok[(size_t)replica * tp.n_res + t])
+        return set_error(MGPU_ERR_STATE, "get_frames: the engine holds no frames for this replica / residue type");
+    const size_t seg = (size_t)n1 * cap;
+    if ((rc = e->h_stage.reserve(3 * (seg + cap) * sizeof(double)))) return rc;
+    double *st = (double *)e->h_stage.p, *sc = st + 3 * seg;
+    if ((rc = sync_all_lanes(e))) return rc;
+    for (int d = 0; d < 3; ++d) {
+        HIP_TRY(hipMemcpy(st + d * seg, e->d_off + ((size_t)replica * 3 + d) * tp.n_cap_atoms + tp.seg_off[t], seg * sizeof(double),
+                          hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(sc + (size_t)d * cap, e->d_com + ((size_t)replica * 3 + d) * tp.n_mol_slots + tp.mol_off[t], cap * sizeof(double),
+                          hipMemcpyDeviceToHost));
+    }
+    for (int m = 0; m < nm; ++m) {
+        if (com) for (int d = 0; d < 3; ++d) com[(size_t)m * 3 + d] = sc[(size_t)d * cap + m];
+        if (off)
+            for (int a = 0; a < n1; ++a) {
+                const size_t j = tp.site_major[t] ? (size_t)m * n1 + a : (size_t)a * cap + m;
+                for (int d = 0; d < 3; ++d) off[((size_t)m * n1 + a) * 3 + d] = st[d * seg + j];
+            }
+    }
     return MGPU_OK;
 }
 
@@ -1082,9 +1185,17 @@ int mgpu_replica_copy(mgpu_engine *e, int dst, int src) {
                            hipMemcpyDeviceToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->d_A + (size_t)dst * e->n_slots, e->d_A + (size_t)src * e->n_slots, e->n_slots * sizeof(double2),
                            hipMemcpyDeviceToDevice, e->stream));
+    if (e->d_com) {
+        HIP_TRY(hipMemcpyAsync(e->d_com + (size_t)dst * 3 * tp.n_mol_slots, e->d_com + (size_t)src * 3 * tp.n_mol_slots,
+                               (size_t)3 * tp.n_mol_slots * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->d_off + (size_t)dst * 3 * tp.n_cap_atoms, e->d_off + (size_t)src * 3 * tp.n_cap_atoms,
+                               (size_t)3 * tp.n_cap_atoms * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    }
     for (int t = 0; t < tp.n_res; ++t) {
         e->h_nmol[dst * tp.n_res + t] = e->h_nmol[src * tp.n_res + t];
         e->in_range[(size_t)dst * tp.n_res + t] = e->in_range[(size_t)src * tp.n_res + t];
+        e->frames_ok[(size_t)dst * tp.n_res + t] = e->frames_ok[(size_t)src * tp.n_res + t];
+        e->frames_tight[(size_t)dst * tp.n_res + t] = e->frames_tight[(size_t)src * tp.n_res + t];
     }
     return sync_stream(e);
 }
@@ -1098,6 +1209,7 @@ int mgpu_replica_replace_molecule(mgpu_engine *e, int replica, int t, int m_dst,
     if (m_dst == m_src) return MGPU_OK;
     if ((rc = use_device(e))) return rc;
     if ((rc = sync_all_lanes(e))) return rc;
+    e->frames_ok[(size_t)replica * tp.n_res + t] = 0;       // a slot copy of the sites only
     const int n1 = tp.n1[t];
     for (int d = 0; d < 3; ++d) {
         double *base = e->d_pos + ((size_t)replica * 3 + d) * tp.n_cap_atoms + tp.seg_off[t];
@@ -1301,11 +1413,30 @@ int mgpu_intra_energy_candidates(mgpu_engine *e, int n, const int *replica, cons
 // One pass over k per candidate yields both reciprocal energies.  Device output rows (doubles):
 //   lj[n_pair] c[n_pair] u_old[n] u_new[n] intra[n]; the lane remembers where each candidate's
 //   pair items are.
+// build != nullptr: the candidate rows are built on the device (trial_build_kernel) from the molecule frames, the move
+// codes (1 translation, 2 rotation, 3 creation, 4 deletion) and five uniform numbers per candidate; `sites` is null and
+// site_stride is ignored (a row is [sites (n1_max) | com | offsets (n1_max)])
+struct TrialBuild {
+    const int *move;
+    const double *u;              // [n][5]
+    double t_step, r_step;
+};
 static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica, const int *t, const int *m,
-                             const int *kind, const double *sites, int site_stride) {
+                             const int *kind, const double *sites, int site_stride, const TrialBuild *build = nullptr) {
     if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "trial_submit: the lane still holds an un-waited trial");
     int rc;
     ln.dirty = true;
+    ln.last_trial_built = false;
+    int frame_at = 0;
+    if (build) {
+        int n1_all = 1;
+        for (int c = 0; c < n; ++c) {
+            if (t[c] < 0 || t[c] >= e->tp.n_res) return set_error(MGPU_ERR_INVALID_ARG, "trial_submit: residue type out of range");
+            n1_all = std::max(n1_all, e->tp.n1[t[c]]);
+        }
+        frame_at = n1_all;
+        site_stride = 2 * n1_all + 1;
+    }
     // from here on the rows of the lane's previous trial are gone (the staging block below may be regrown and is
     // overwritten): a failed submit must not leave them committable "from the lane's resident rows"
     ln.last_trial_n = 0;
@@ -1314,9 +1445,13 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     const size_t site_bytes = (size_t)n * site_stride * 3 * sizeof(double);
     const size_t pit_cap = 2 * (size_t)n * sizeof(PairItem), rit_bytes = (size_t)n * sizeof(RecipItem);
     const size_t iit_cap = (size_t)n * sizeof(PairItem) + (size_t)n * sizeof(int);       // intra items | pend_idx
-    if (sites == ln.h_in.p && site_bytes + pit_cap + rit_bytes + iit_cap > ln.h_in.bytes)
+    // device-built trials append [move codes (n ints) | uniforms (5 n doubles)] behind everything else, 8-byte aligned
+    const size_t build_at = (site_bytes + pit_cap + rit_bytes + iit_cap + 7) & ~(size_t)7;
+    const size_t build_mv = ((size_t)n * sizeof(int) + 7) & ~(size_t)7;
+    const size_t build_bytes = build ? build_mv + (size_t)5 * n * sizeof(double) : 0;
+    if (sites && sites == ln.h_in.p && site_bytes + pit_cap + rit_bytes + iit_cap > ln.h_in.bytes)
         return set_error(MGPU_ERR_INVALID_ARG, "trial_submit: more candidates than the lane's site buffer was sized for");
-    if ((rc = ln.h_in.reserve(site_bytes + pit_cap + rit_bytes + iit_cap))) return rc;
+    if ((rc = ln.h_in.reserve(build_at + build_bytes))) return rc;
     double *h_sites = (double *)ln.h_in.p;
     PairItem *pit = (PairItem *)((char *)ln.h_in.p + site_bytes);
     RecipItem *rit = (RecipItem *)((char *)ln.h_in.p + site_bytes + pit_cap);
@@ -1353,7 +1488,18 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
         n1_max = std::max(n1_max, n1);
         ln.kinds[c] = k;
         fast = fast && replica_in_range(e, replica[c]);
-        if (k != MGPU_DELETION) {
+        if (build) {
+            const size_t idx = (size_t)replica[c] * e->tp.n_res + t[c];
+            if (!e->d_com || !e->frames_ok[idx])
+                return set_error(MGPU_ERR_STATE, "move_trial_submit: no molecule frames for candidate " + std::to_string(c) +
+                                                     " (mgpu_replica_set_frames)");
+            const int mv = build->move[c];
+            if (mv < 1 || mv > 4 || (k == MGPU_MOVE) != (mv <= 2) || (k == MGPU_CREATION) != (mv == 3))
+                return set_error(MGPU_ERR_INVALID_ARG, "move_trial_submit: move code does not match the candidate kind");
+            // a built candidate's centre lies in the cell (ApplyPBC / uniform insertion); with tight frames its sites are
+            // within the fast fold's range
+            if (k != MGPU_DELETION) { ln.cand_ok[c] = e->frames_tight[idx]; fast = fast && ln.cand_ok[c]; }
+        } else if (k != MGPU_DELETION) {
             ln.cand_ok[c] = sites_in_range(e, sites + (size_t)c * site_stride * 3, n1) ? 1 : 0;
             fast = fast && ln.cand_ok[c];          // the candidate's own sites are swept in this launch
         }
@@ -1365,13 +1511,18 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
             if (k != MGPU_CREATION) { ln.pair_old[c] = 2 * n_fused + i_single; pit_single[i_single++] = PairItem{replica[c], t[c], mc, -1, 0}; }
             if (k != MGPU_DELETION) { ln.pair_new[c] = 2 * n_fused + i_single; pit_single[i_single++] = PairItem{replica[c], t[c], mc, c, 0}; }
         }
-        rit[c] = RecipItem{replica[c], t[c], mc, k, k == MGPU_DELETION ? -1 : c, 0};   // one k sweep: old and new
+        rit[c] = RecipItem{replica[c], t[c], mc, k, k == MGPU_DELETION ? -1 : c, 0, frame_at};   // one k sweep: old and new
         if (k == MGPU_CREATION) { ln.intra_idx[c] = n_intra; iit[n_intra++] = PairItem{replica[c], t[c], -1, c, 0}; }
         if (k == MGPU_DELETION) { ln.intra_idx[c] = n_intra; iit[n_intra++] = PairItem{replica[c], t[c], mc, -1, 0}; }
     }
     const int n_single = i_single, n_pair = 2 * n_fused + n_single;     // reduced pair-energy entries
-    if (sites != h_sites) std::memcpy(h_sites, sites, site_bytes);        // rows built in place (mgpu_lane_site_buffer): no copy
-    if (any_frozen(e, n, t)) permute_frozen_rows(e, h_sites, n, site_stride, t);
+    if (build) {
+        std::memcpy((char *)ln.h_in.p + build_at, build->move, (size_t)n * sizeof(int));
+        std::memcpy((char *)ln.h_in.p + build_at + build_mv, build->u, (size_t)5 * n * sizeof(double));
+    } else {
+        if (sites != h_sites) std::memcpy(h_sites, sites, site_bytes);    // rows built in place (mgpu_lane_site_buffer): no copy
+        if (any_frozen(e, n, t)) permute_frozen_rows(e, h_sites, n, site_stride, t);
+    }
     const size_t iit_bytes = (size_t)n_intra * sizeof(PairItem);
     // results in device memory, copied out once: [split partials of the pair sweep (n_pair * nsplit complex-sized
     // records, reduced on the host in trial_wait) | u_old | u_new | intra]
@@ -1417,10 +1568,21 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     }
     // one staging block [sites | pair items (2n slots) | recip items | intra items | pend_idx] -> one H2D copy
     const size_t in_bytes = site_bytes + pit_cap + rit_bytes + iit_bytes + (fused_k ? pend_bytes : 0);
-    if ((rc = ln.d_sites.reserve(site_bytes + pit_cap + rit_bytes + iit_cap))) return rc;
+    if ((rc = ln.d_sites.reserve(build_at + build_bytes))) return rc;
     if ((rc = ln.d_out.reserve(out_doubles * sizeof(double)))) return rc;
     if ((rc = ln.h_out.reserve(out_doubles * sizeof(double)))) return rc;
-    HIP_TRY(hipMemcpyAsync(ln.d_sites.p, ln.h_in.p, in_bytes, hipMemcpyHostToDevice, ln.stream));
+    if (build) {
+        // the rows are written by the device: only [items | move codes | uniforms] travel
+        HIP_TRY(hipMemcpyAsync((char *)ln.d_sites.p + site_bytes, (char *)ln.h_in.p + site_bytes, build_at + build_bytes - site_bytes,
+                               hipMemcpyHostToDevice, ln.stream));
+        hipLaunchKernelGGL(trial_build_kernel, dim3((n + 127) / 128), dim3(128), 0, ln.stream, e->tp, e->bx,
+                           (const RecipItem *)((char *)ln.d_sites.p + site_bytes + pit_cap), (const int *)((char *)ln.d_sites.p + build_at),
+                           (const double *)((char *)ln.d_sites.p + build_at + build_mv), build->t_step, build->r_step,
+                           (double *)ln.d_sites.p, site_stride, frame_at, n);
+        HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(hipMemcpyAsync(ln.d_sites.p, ln.h_in.p, in_bytes, hipMemcpyHostToDevice, ln.stream));
+    }
     const PairItem *d_pit = (const PairItem *)((char *)ln.d_sites.p + site_bytes);
     const RecipItem *d_rit = (const RecipItem *)((char *)ln.d_sites.p + site_bytes + pit_cap);
     const PairItem *d_iit = (const PairItem *)((char *)ln.d_sites.p + site_bytes + pit_cap + rit_bytes);
@@ -1458,6 +1620,8 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     ln.n_split = nsplit;
     ln.last_trial_n = n;
     ln.last_trial_stride = site_stride;
+    ln.last_trial_built = build != nullptr;
+    ln.last_trial_frame = frame_at;
     ln.d_trial_items = d_rit;
     ln.h_trial_items = rit;
     ln.trial_n1_max = n1_max;
@@ -1518,6 +1682,9 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
     if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "commit_submit: wait for the lane's trial first");
     ln.dirty = true;
     if ((rc = flush_deferred(e, ln))) return rc;
+    // committing a device-built trial from its resident rows: the rows carry the candidates' frames
+    const bool built = !sites && reuse_sites && ln.last_trial_built && n == ln.last_trial_n;
+    if (built) site_stride = ln.last_trial_stride;
     // the pinned staging block may still feed the H2D copy of the lane's previous commit
     if (ln.commit_staged) {
         HIP_TRY(hipEventSynchronize(ln.commit_staged_ev));
@@ -1551,6 +1718,12 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
         if (kind[c] != MGPU_DELETION) {
             any_sites = true;
             it.src = c;
+            it.frame = built ? ln.last_trial_frame : 0;
+            // where the engine keeps molecule frames they must stay the mirror of the sites: a move / insertion given as
+            // bare sites cannot update them
+            if (!built && e->d_com && e->frames_ok[idx])
+                return set_error(MGPU_ERR_STATE, "commit: this replica holds molecule frames (mgpu_replica_set_frames): commit "
+                                                 "device-built trials from the lane's resident rows, or set the molecules again");
             // the accepted sites become resident atoms: keep the replica's range flag honest
             const bool ok = sites ? sites_in_range(e, sites + (size_t)c * site_stride * 3, e->tp.n1[t[c]])
                                   : (c < (int)ln.cand_ok.size() && ln.cand_ok[c]);
@@ -1577,7 +1750,7 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
             bits.w[c >> 5] |= 1u << (c & 31);
         }
         if (!same) return set_error(MGPU_ERR_INVALID_ARG, "commit_submit: candidates differ from the lane's last trial");
-        if (e->defer_commits) {
+        if (e->defer_commits && !built) {
             // not launched: the lane's next trial_submit applies it inside its k sweep (any other call flushes it)
             Lane::Deferred &d = ln.deferred;
             d.active = true;
@@ -1659,6 +1832,23 @@ int mgpu_gcmc_trial_submit(mgpu_engine *e, int lane, int n, const int *replica, 
     return trial_submit_impl(e, e->lanes[lane], n, replica, t, m, kind, sites, site_stride);
 }
 
+int mgpu_move_trial_submit(mgpu_engine *e, int lane, int n, const int *replica, const int *t, const int *m, const int *move,
+                           const double *u, double translation_step, double rotation_step) {
+    int rc = check_lane(e, lane);
+    if (rc) return rc;
+    if (n <= 0 || !replica || !t || !m || !move || !u) return set_error(MGPU_ERR_INVALID_ARG, "move_trial_submit: bad argument");
+    if (e->bx.triclinic) return set_error(MGPU_ERR_STATE, "move_trial_submit: orthorhombic boxes only");
+    if ((rc = use_device(e))) return rc;
+    Lane &ln = e->lanes[lane];
+    ln.build_kind.resize(n);
+    for (int c = 0; c < n; ++c) {
+        if (move[c] < 1 || move[c] > 4) return set_error(MGPU_ERR_INVALID_ARG, "move_trial_submit: unknown move code");
+        ln.build_kind[c] = move[c] <= 2 ? MGPU_MOVE : (move[c] == 3 ? MGPU_CREATION : MGPU_DELETION);
+    }
+    const TrialBuild build{move, u, translation_step, rotation_step};
+    return trial_submit_impl(e, ln, n, replica, t, m, ln.build_kind.data(), nullptr, 0, &build);
+}
+
 int mgpu_gcmc_trial_wait(mgpu_engine *e, int lane, double *old_energy, double *new_energy) {
     int rc = check_lane(e, lane);
     if (rc) return rc;
@@ -1683,7 +1873,7 @@ int mgpu_commit_submit(mgpu_engine *e, int lane, int n, const int *replica, cons
     if (n < 0 || !replica || !t || !m || !kind || !accept) return set_error(MGPU_ERR_INVALID_ARG, "commit_submit: bad argument");
     if ((rc = use_device(e))) return rc;
     Lane &ln = e->lanes[lane];
-    const bool reuse = (sites == nullptr) && ln.last_trial_n == n && ln.last_trial_stride == site_stride;
+    const bool reuse = (sites == nullptr) && ln.last_trial_n == n && (ln.last_trial_stride == site_stride || ln.last_trial_built);
     return commit_submit_impl(e, ln, n, replica, t, m, kind, sites, site_stride, accept, reuse);
 }
 

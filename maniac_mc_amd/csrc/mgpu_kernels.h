@@ -71,11 +71,20 @@ struct Topo {
     int grp_start[kMaxGrp], grp_cnt[kMaxGrp], grp_ty[kMaxGrp];
     const double *slot_q;         // [n_cap_atoms] charge of every atom slot (same for all replicas)
     const int *slot_ty;           // [n_cap_atoms] 0-based atom type of every atom slot
+    // Molecule frames (only once mgpu_replica_set_frames has been used, else null): what the reference keeps per
+    // molecule -- com [R][3][n_mol_slots] = primary%mol_com (molecule slot mol_off[t] + m) and off [R][3][n_cap_atoms] =
+    // primary%site_offset in the slot layout of pos -- so that trial moves can be built on the device
+    // (trial_build_kernel); pos stays the rounded sum com + off, which is what the reference forms before every use.
+    double *com;
+    double *off;
+    int mol_off[kMaxRes];
+    int n_mol_slots;
 };
 
 struct BoxDev {
     double L[3], invL[3];         // orthorhombic edge lengths box%matrix(d,d)
     double ctr[3];                // centre of the primary cell (orthorhombic): bounds_lo + L / 2
+    double lo[3];                 // bounds_lo
     double rcp[9];                // box%reciprocal, row-major
     double m[9];                  // box%matrix, row-major (cell vectors are its columns)
     int triclinic;                // box%type == 3: 27-image search instead of the per-axis fold
@@ -99,6 +108,8 @@ struct RecipItem {
     int replica, t, m, kind;
     int src;                      // row of cand_sites holding the new sites (< 0: none)
     int aux;                      // commit: new molecule count of (replica, t) after the move
+    int frame;                    // > 0: row `src` carries the candidate's frame at site index `frame` (com) and frame + 1 ...
+                                  // (offsets): a device-built trial (trial_build_kernel); the commit writes it back
 };
 
 __device__ __forceinline__ int atom_slot(const Topo &tp, int t, int m, int a) {
@@ -962,6 +973,28 @@ __global__ __launch_bounds__(kBlock) void recip_kernel(
                 px[j] = px[jl]; py[j] = py[jl]; pz[j] = pz[jl];
             }
         }
+        // molecule frames, where the engine keeps them: a device-built move / insertion writes its com and offsets back,
+        // a deletion moves the last molecule's frame with its sites
+        if (tp.com) {
+            const size_t rep3 = (size_t)it.replica * 3;
+            double *fcom = tp.com + rep3 * tp.n_mol_slots + tp.mol_off[it.t];
+            double *foff = tp.off + rep3 * tp.n_cap_atoms;
+            if ((it.kind == 0 || it.kind == 1) && it.frame > 0) {
+                const double *fr = cand_sites + ((size_t)it.src * site_stride + it.frame) * 3;
+                if (threadIdx.x < 3) fcom[(size_t)threadIdx.x * tp.n_mol_slots + it.m] = fr[threadIdx.x];
+                if (threadIdx.x < n1) {
+                    const int j = atom_slot(tp, it.t, it.m, threadIdx.x);
+                    for (int d = 0; d < 3; ++d) foff[(size_t)d * tp.n_cap_atoms + j] = fr[(1 + threadIdx.x) * 3 + d];
+                }
+            } else if (it.kind == 2 && it.aux != it.m) {
+                const int last = it.aux;
+                if (threadIdx.x < 3) fcom[(size_t)threadIdx.x * tp.n_mol_slots + it.m] = fcom[(size_t)threadIdx.x * tp.n_mol_slots + last];
+                if (threadIdx.x < n1) {
+                    const int j = atom_slot(tp, it.t, it.m, threadIdx.x), jl = atom_slot(tp, it.t, last, threadIdx.x);
+                    for (int d = 0; d < 3; ++d) foff[(size_t)d * tp.n_cap_atoms + j] = foff[(size_t)d * tp.n_cap_atoms + jl];
+                }
+            }
+        }
         if (threadIdx.x == 0 && (it.kind == 1 || it.kind == 2)) nmol[it.replica * tp.n_res + it.t] = it.aux;
     }
 }
@@ -1221,6 +1254,28 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
                 px[j] = px[jl]; py[j] = py[jl]; pz[j] = pz[jl];
             }
         }
+        // molecule frames, where the engine keeps them: a device-built move / insertion writes its com and offsets back,
+        // a deletion moves the last molecule's frame with its sites
+        if (tp.com) {
+            const size_t rep3 = (size_t)it.replica * 3;
+            double *fcom = tp.com + rep3 * tp.n_mol_slots + tp.mol_off[it.t];
+            double *foff = tp.off + rep3 * tp.n_cap_atoms;
+            if ((it.kind == 0 || it.kind == 1) && it.frame > 0) {
+                const double *fr = cand_sites + ((size_t)it.src * site_stride + it.frame) * 3;
+                if (threadIdx.x < 3) fcom[(size_t)threadIdx.x * tp.n_mol_slots + it.m] = fr[threadIdx.x];
+                if (threadIdx.x < n1) {
+                    const int j = atom_slot(tp, it.t, it.m, threadIdx.x);
+                    for (int d = 0; d < 3; ++d) foff[(size_t)d * tp.n_cap_atoms + j] = fr[(1 + threadIdx.x) * 3 + d];
+                }
+            } else if (it.kind == 2 && it.aux != it.m) {
+                const int last = it.aux;
+                if (threadIdx.x < 3) fcom[(size_t)threadIdx.x * tp.n_mol_slots + it.m] = fcom[(size_t)threadIdx.x * tp.n_mol_slots + last];
+                if (threadIdx.x < n1) {
+                    const int j = atom_slot(tp, it.t, it.m, threadIdx.x), jl = atom_slot(tp, it.t, last, threadIdx.x);
+                    for (int d = 0; d < 3; ++d) foff[(size_t)d * tp.n_cap_atoms + j] = foff[(size_t)d * tp.n_cap_atoms + jl];
+                }
+            }
+        }
         if (threadIdx.x == 0 && (it.kind == 1 || it.kind == 2)) nmol[it.replica * tp.n_res + it.t] = it.aux;
     }
 }
@@ -1435,6 +1490,76 @@ __global__ __launch_bounds__(kBlock, 2) void trial_k_kernel(
         for (int wv = 0; wv < kWavesPerBlock; ++wv) { u += s_red[2 * wv]; u0 += s_red[2 * wv + 1]; }
         u_new[blockIdx.x] = u * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;   // ewald_energy.f90:272
         u_old[blockIdx.x] = u0 * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Trial geometry built on the device (the farm's moves: Translation / Rotation / CreateMolecule of the reference,
+// src/translation.f90:93-112, src/monte_carlo_utils.f90:30-92, src/create_molecule.f90:166-207) from the molecule
+// frames the engine keeps resident (com = primary%mol_com, off = primary%site_offset) and the host's uniform numbers:
+//   move 1  translation   com <- ApplyPBC(com + (u[0..2] - 1/2) * translation_step)          offsets unchanged
+//   move 2  rotation      offsets rotated by (u[3] - 1/2) * rotation_step about Cartesian axis int(3 u[4]) + 1
+//   move 3  creation      com <- lo + L * u[0..2]; offsets of molecule 1 of the type, rotated by 2 pi u[3] about that axis
+//   move 4  deletion      nothing to build
+// One thread per candidate.  Row c of `rows` (row_stride "sites" of three doubles) receives the candidate's sites
+// com + off at [0, n1), its frame at [frame_at] (com) and [frame_at + 1, frame_at + 1 + n1) (offsets): the sweeps read
+// the sites, the commit writes sites AND frame back.  Orthorhombic boxes.
+// ------------------------------------------------------------------------------------------
+__global__ void trial_build_kernel(Topo tp, BoxDev bx, const RecipItem *__restrict__ items, const int *__restrict__ move,
+                                   const double *__restrict__ uu, double t_step, double r_step, double *__restrict__ rows,
+                                   int row_stride, int frame_at, int n) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const RecipItem it = items[c];
+    const int mv = move[c];
+    if (mv == 4) return;
+    const double *u = uu + 5 * (size_t)c;
+    const int n1 = tp.n1[it.t];
+    const size_t rep3 = (size_t)it.replica * 3;
+    const int src_m = mv == 3 ? 0 : it.m;          // creation: the geometry of molecule 1 (create_molecule.f90:197-199)
+    double com[3];
+    for (int d = 0; d < 3; ++d) com[d] = tp.com[(rep3 + d) * tp.n_mol_slots + tp.mol_off[it.t] + src_m];
+    int p = 0, q = 0;
+    double cs = 1.0, sn = 0.0;
+    bool rot = false;
+    if (mv == 1) {
+        for (int d = 0; d < 3; ++d) {
+            // translation.f90:104-110, geometry_utils.f90:190: lo + modulo(pos - lo, L)
+            double x = (com[d] + (u[d] - 0.5) * t_step) - bx.lo[d];
+            if (x < 0.0 || x >= bx.L[d]) {
+                x = fmod(x, bx.L[d]);
+                if (x < 0.0) x += bx.L[d];
+            }
+            com[d] = bx.lo[d] + x;
+        }
+    } else if (mv == 2 || (mv == 3 && n1 > 1)) {
+        const int axis = (int)(u[4] * 3.0) + 1;                              // monte_carlo_utils.f90:54-64
+        const double theta = mv == 2 ? (u[3] - 0.5) * r_step : u[3] * kTwoPi;
+        sincos(theta, &sn, &cs);
+        p = axis % 3;                                                        // RotationMatrix: X -> (Y, Z), Y -> (Z, X), Z -> (X, Y)
+        q = (axis + 1) % 3;
+        rot = true;
+    }
+    if (mv == 3)
+        for (int d = 0; d < 3; ++d) com[d] = bx.lo[d] + bx.L[d] * u[d];       // create_molecule.f90:180-184
+    double *row = rows + (size_t)c * row_stride * 3;
+    for (int d = 0; d < 3; ++d) row[(size_t)frame_at * 3 + d] = com[d];
+    for (int a = 0; a < n1; ++a) {
+        const int j = atom_slot(tp, it.t, src_m, a);
+        double o[3];
+        for (int d = 0; d < 3; ++d) o[d] = tp.off[(rep3 + d) * tp.n_cap_atoms + j];
+        if (rot) {                                                           // (p, q) = (1, 2), (2, 0) or (0, 1)
+            const double x = p == 0 ? o[0] : (p == 1 ? o[1] : o[2]);
+            const double y = q == 0 ? o[0] : (q == 1 ? o[1] : o[2]);
+            const double xn = cs * x - sn * y, yn = sn * x + cs * y;
+            o[0] = p == 0 ? xn : (q == 0 ? yn : o[0]);
+            o[1] = p == 1 ? xn : (q == 1 ? yn : o[1]);
+            o[2] = p == 2 ? xn : (q == 2 ? yn : o[2]);
+        }
+        for (int d = 0; d < 3; ++d) {
+            row[(size_t)(frame_at + 1 + a) * 3 + d] = o[d];
+            row[(size_t)a * 3 + d] = com[d] + o[d];
+        }
     }
 }
 

@@ -142,6 +142,32 @@ class Engine:
         check(self.L.mgpu_replica_get_molecules(self.h, C.c_int(replica), C.c_int(t), C.byref(nm), _d(sites)))
         return sites
 
+    def set_frames(self, replica, t, com, off):
+        """mgpu_replica_set_frames: com (n, 3) and offsets (n, n1, 3) as the reference keeps them; the sites are com + off."""
+        n1 = int(self.topo.atoms_in_res[t])
+        com = np.ascontiguousarray(com, dtype=np.float64).reshape(-1, 3)
+        off = np.ascontiguousarray(np.asarray(off, dtype=np.float64)[:, :n1, :]).reshape(-1, n1, 3)
+        check(self.L.mgpu_replica_set_frames(self.h, C.c_int(replica), C.c_int(t), C.c_int(com.shape[0]), _d(com), _d(off)))
+
+    def get_frames(self, replica, t):
+        n = self.num_molecules(replica, t)
+        n1 = int(self.topo.atoms_in_res[t])
+        com = np.zeros((n, 3)); off = np.zeros((n, n1, 3)); nm = C.c_int()
+        check(self.L.mgpu_replica_get_frames(self.h, C.c_int(replica), C.c_int(t), C.byref(nm), _d(com), _d(off)))
+        return com, off
+
+    def move_trial(self, replica, t, m, move, u, translation_step, rotation_step, lane=0):
+        """Device-built trials (mgpu_move_trial_submit + wait): (old[n,5], new[n,5])."""
+        m = _ints(m); n = m.shape[0]
+        replica = _ints(replica, n); t = _ints(t, n); move = _ints(move, n)
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(n, 5)
+        old = np.zeros((n, 5)); new = np.zeros((n, 5))
+        self._last_stride = 0
+        check(self.L.mgpu_move_trial_submit(self.h, C.c_int(lane), C.c_int(n), _i(replica), _i(t), _i(m), _i(move), _d(u),
+                                            C.c_double(translation_step), C.c_double(rotation_step)))
+        check(self.L.mgpu_gcmc_trial_wait(self.h, C.c_int(lane), _d(old), _d(new)))
+        return old, new
+
     def num_molecules(self, replica, t):
         n = C.c_int()
         check(self.L.mgpu_replica_num_molecules(self.h, C.c_int(replica), C.c_int(t), C.byref(n)))

@@ -208,6 +208,25 @@ module maniac_gpu
             integer(c_int), intent(in) :: replica(*), t(*), m(*), kind(*), accept(*)
             integer(c_int) :: rc
         end function
+        ! molecule frames (com, offsets) resident on the device and trial moves built from them there
+        function mgpu_replica_get_frames(e, replica, t, n_mol, com, off) bind(C, name="mgpu_replica_get_frames") result(rc)
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: e
+            integer(c_int), value :: replica, t
+            integer(c_int), intent(out) :: n_mol
+            real(c_double), intent(out) :: com(*), off(*)
+            integer(c_int) :: rc
+        end function
+        function mgpu_move_trial_submit(e, lane, n, replica, t, m, move, u, translation_step, rotation_step) &
+                bind(C, name="mgpu_move_trial_submit") result(rc)
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: e
+            integer(c_int), value :: lane, n
+            integer(c_int), intent(in) :: replica(*), t(*), m(*), move(*)
+            real(c_double), intent(in) :: u(*)
+            real(c_double), value :: translation_step, rotation_step
+            integer(c_int) :: rc
+        end function
         ! pinned staging of a lane's next trial: candidate rows built in place are not copied again
         function mgpu_lane_site_buffer(e, lane, n_max, site_stride, sites) bind(C, name="mgpu_lane_site_buffer") result(rc)
             import :: c_ptr, c_int

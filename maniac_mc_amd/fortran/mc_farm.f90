@@ -47,7 +47,7 @@ module mc_farm
     private
     public :: mfarm_create, mfarm_run, mfarm_destroy, mfarm_get_energy, mfarm_get_molecule, mfarm_recalibrate
     public :: mfarm_get_timers, mfarm_set_gcmc, mfarm_get_counts, mfarm_get_counters, mfarm_set_triclinic
-    public :: mfarm_rng_sample, mfarm_set_drivers
+    public :: mfarm_rng_sample, mfarm_set_drivers, mfarm_configure
 
     real(real64), parameter :: PI = 3.14159265358979323846_real64
     real(real64), parameter :: TWOPI = 2.0_real64 * PI
@@ -72,6 +72,8 @@ module mc_farm
         real(real64), pointer :: sites(:, :, :) => null()
         real(real64), allocatable :: sites_own(:, :, :)
         real(real64), allocatable :: new_com(:, :), new_off(:, :, :)
+        integer(c_int), allocatable :: mvc(:)              ! device-built trials: move code per candidate
+        real(real64), allocatable :: u5(:, :)              ! ... and its five uniform numbers (5, n)
         real(real64), allocatable :: old_e(:), new_e(:)    ! (ne * nc) rows packed by the engine
         real(real64), allocatable :: u(:, :)
         ! per-lane accumulators (lanes may run on different host threads), folded into the farm's totals by mfarm_run
@@ -104,10 +106,15 @@ module mc_farm
         integer :: team = 1                                ! OpenMP threads of one lane's loops
         logical :: lane_threads = .false.                  ! several driver threads (each with its team) share the lanes
         integer :: n_drivers = 1                           ! driver threads asked for (mfarm_set_drivers; MFARM_LANE_THREADS overrides)
+        ! .true.: the engine holds the molecules' frames (mgpu_replica_set_frames) and BUILDS the trial geometry itself
+        ! (mgpu_move_trial_submit): the host keeps counts, energies and the random stream -- no mirror of the coordinates,
+        ! no gathers from it, no candidate rows to stage
+        logical :: device_build = .false.
         integer(int64), allocatable :: cxs(:, :)           ! (4, R) xoshiro256+ state of every chain
     end type farm_state
 
     type(farm_state), save, target :: F
+    logical, save :: want_device_build = .false.           ! consumed by the next mfarm_create (mfarm_configure)
 
     interface
         function c_posix_memalign(ptr, alignment, bytes) bind(C, name="posix_memalign") result(rc)
@@ -237,7 +244,8 @@ contains
             tot = tot + cap(ia)
         end do
         F%cap_total = tot
-        call alloc_mirror(3 + 3 * max_n1, tot, int(n_replicas))
+        F%device_build = want_device_build
+        if (.not. F%device_build) call alloc_mirror(3 + 3 * max_n1, tot, int(n_replicas))
         allocate(F%energy(5, n_replicas))
         F%n_threads = max(1, int(n_threads))
         ! n_lanes groups of replicas, one per engine lane (<= 0: the default of two)
@@ -253,13 +261,15 @@ contains
             !$omp parallel do num_threads(F%n_threads) schedule(static) private(r, ia, k, src)
             do i = 1, lane_n
                 r = lane_first + i
-                F%mol(:, :, r) = 0.0_real64
+                if (.not. F%device_build) F%mol(:, :, r) = 0.0_real64
                 src = 0
                 do ia = 1, n_active
-                    do k = 1, n_mol(ia)
-                        F%mol(1:3, F%first(ia) + k, r) = com(:, src + k)
-                        F%mol(4:, F%first(ia) + k, r) = reshape(off(:, :, src + k), [3 * max_n1])
-                    end do
+                    if (.not. F%device_build) then
+                        do k = 1, n_mol(ia)
+                            F%mol(1:3, F%first(ia) + k, r) = com(:, src + k)
+                            F%mol(4:, F%first(ia) + k, r) = reshape(off(:, :, src + k), [3 * max_n1])
+                        end do
+                    end if
                     F%cnt(ia, r) = n_mol(ia)
                     src = src + n_mol(ia)
                 end do
@@ -342,7 +352,7 @@ contains
         allocate(L%rep(n), L%t(n), L%m(n), L%kind(n), L%accept(n), L%ia(n), L%move(n), L%cidx(n))
         allocate(L%sel_ia(n), L%sel_mv(n), L%sel_slot(n))
         allocate(L%new_com(3, n), L%new_off(3, max_n1, n))
-        allocate(L%old_e(5 * n), L%new_e(5 * n), L%u(NRAND, n))
+        allocate(L%old_e(5 * n), L%new_e(5 * n), L%u(NRAND, n), L%mvc(n), L%u5(5, n))
         rc = mgpu_lane_site_buffer(F%engine, int(g, c_int), int(n, c_int), int(max_n1, c_int), staged)
         if (rc == MGPU_OK .and. c_associated(staged)) then
             call c_f_pointer(staged, L%sites, [3, max_n1, n])
@@ -369,7 +379,7 @@ contains
                 deallocate(F%lane(g)%rep, F%lane(g)%t, F%lane(g)%m, F%lane(g)%kind, F%lane(g)%accept, &
                            F%lane(g)%ia, F%lane(g)%move, F%lane(g)%cidx, F%lane(g)%sel_ia, F%lane(g)%sel_mv, &
                            F%lane(g)%sel_slot, F%lane(g)%new_com, &
-                           F%lane(g)%new_off, F%lane(g)%old_e, F%lane(g)%new_e, F%lane(g)%u)
+                           F%lane(g)%new_off, F%lane(g)%old_e, F%lane(g)%new_e, F%lane(g)%u, F%lane(g)%mvc, F%lane(g)%u5)
                 if (allocated(F%lane(g)%sites_own)) deallocate(F%lane(g)%sites_own)
                 nullify(F%lane(g)%sites)
             end if
@@ -474,7 +484,7 @@ contains
             L%sel_slot(i) = slot
             ! announce the mirror record phase 3 will gather: a prefetch does not stall this loop, so a thread has
             ! the DRAM misses of all its chains in flight instead of taking them one by one in phase 3
-            if (slot > 0) then
+            if (slot > 0 .and. .not. F%device_build) then
                 k = F%first(ia) + merge(1, slot, mv == MV_CREATION)
                 call mgpu_host_prefetch(c_loc(F%mol(1, k, r)), int(8 * (3 + 3 * F%n1(ia)), c_int))
             end if
@@ -512,6 +522,15 @@ contains
         !$omp do schedule(static)
         do j = 1, L%nc
             i = L%cidx(j)
+            if (F%device_build) then
+                ! the engine builds the geometry: hand over the move and the numbers its construction consumes
+                ! (u4..u6 displacement / position, u7 angle, u8 axis -- the same draws the host construction below uses)
+                L%mvc(j) = int(L%move(j), c_int)
+                do d = 1, 5
+                    L%u5(d, j) = L%u(3 + d, i)
+                end do
+                cycle
+            end if
             r = L%rep(j) + 1
             ia = L%ia(j)
             slot = L%m(j) + 1
@@ -583,7 +602,10 @@ contains
         !$omp end parallel
         call system_clock(c1)
         if (L%nc > 0) then
-            if (F%gcmc) then
+            if (F%device_build) then
+                rc = mgpu_move_trial_submit(F%engine, int(g, c_int), int(L%nc, c_int), L%rep, L%t, L%m, L%mvc, L%u5, &
+                                            F%translation_step, F%rotation_step)
+            else if (F%gcmc) then
                 rc = mgpu_gcmc_trial_submit(F%engine, int(g, c_int), int(L%nc, c_int), L%rep, L%t, L%m, L%kind, &
                                             L%sites, int(F%max_n1, c_int))
             else
@@ -615,7 +637,7 @@ contains
         rc = MGPU_OK
         if (L%nc == 0) return
         call system_clock(c0)
-        if (F%gcmc) then
+        if (F%gcmc .or. F%device_build) then
             ne = 5
             rc = mgpu_gcmc_trial_wait(F%engine, int(g, c_int), L%old_e, L%new_e)   ! rows of 5
         else
@@ -665,18 +687,20 @@ contains
                 slot = L%m(j) + 1
                 select case (L%move(j))
                 case (MV_CREATION)
-                    call store_molecule(F%mol(:, base + slot, r), L%new_com(:, j), L%new_off(:, :, j), n1)
+                    if (.not. F%device_build) call store_molecule(F%mol(:, base + slot, r), L%new_com(:, j), L%new_off(:, :, j), n1)
                     F%cnt(ia, r) = F%cnt(ia, r) + 1
                     k_c = k_c + 1
                 case (MV_DELETION)
                     last = F%cnt(ia, r)                                    ! RemoveMolecule, delete_molecule.f90:107-114
-                    do k = 1, 3 + 3 * n1
-                        F%mol(k, base + slot, r) = F%mol(k, base + last, r)
-                    end do
+                    if (.not. F%device_build) then
+                        do k = 1, 3 + 3 * n1
+                            F%mol(k, base + slot, r) = F%mol(k, base + last, r)
+                        end do
+                    end if
                     F%cnt(ia, r) = last - 1
                     k_d = k_d + 1
                 case default
-                    call store_molecule(F%mol(:, base + slot, r), L%new_com(:, j), L%new_off(:, :, j), n1)
+                    if (.not. F%device_build) call store_molecule(F%mol(:, base + slot, r), L%new_com(:, j), L%new_off(:, :, j), n1)
                     if (L%move(j) == MV_TRANSLATION) then
                         k_t = k_t + 1
                     else
@@ -826,6 +850,13 @@ contains
         end do
     end subroutine lane_ticks
 
+    ! device_build /= 0: the NEXT farm created builds its trial moves on the device from the frames the caller uploaded with
+    ! mgpu_replica_set_frames (orthorhombic boxes); 0: on the host from its mirror (the default)
+    subroutine mfarm_configure(device_build) bind(C, name="mfarm_configure")
+        integer(c_int), value :: device_build
+        want_device_build = device_build /= 0
+    end subroutine mfarm_configure
+
     ! Driver threads of mfarm_run (1: the calling thread drives all lanes in lock step; d > 1: d threads, each driving
     ! lanes d0, d0 + d, ... with a team of n_threads / d).  Measured on MI355X (round 3): two drivers on four lanes lift the
     ! host-bound grand-canonical farms (CO2 box 14.2 -> 19.8 M, framework + water 4.6 -> 5.3 M accepted moves/s) and
@@ -917,6 +948,16 @@ contains
     subroutine mfarm_get_molecule(replica, ia, slot, com, off) bind(C, name="mfarm_get_molecule")
         integer(c_int), value :: replica, ia, slot
         real(c_double), intent(out) :: com(3), off(3, F%max_n1)
+        real(c_double), allocatable :: c_all(:, :), o_all(:, :, :)
+        integer(c_int) :: nm, rc
+        if (F%device_build) then
+            allocate(c_all(3, F%cap(ia + 1)), o_all(3, F%n1(ia + 1), F%cap(ia + 1)))
+            rc = mgpu_replica_get_frames(F%engine, replica, int(F%res_type(ia + 1), c_int), nm, c_all, o_all)
+            com = c_all(:, slot + 1)
+            off = 0.0_real64
+            off(:, 1:F%n1(ia + 1)) = o_all(:, :, slot + 1)
+            return
+        end if
         com = F%mol(1:3, F%first(ia + 1) + slot + 1, replica + 1)
         off = reshape(F%mol(4:, F%first(ia + 1) + slot + 1, replica + 1), [3, F%max_n1])
     end subroutine mfarm_get_molecule

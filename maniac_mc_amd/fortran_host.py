@@ -74,7 +74,7 @@ class FortranFarm:
     def __init__(self, system: System, n_replicas: int, device: int = 0, seed: int = 1,
                  translation_step: float = 0.3, rotation_step: float = 0.3, p_translation: float = 0.5,
                  rng_kind: int = 1, n_threads: int = 8, mol_capacity=None, gcmc=None,
-                 n_lanes: int = 2, n_drivers: int = 1):
+                 n_lanes: int = 2, n_drivers: int = 1, device_build: bool = False):
         self.H = lib()
         # mc_farm.f90 keeps ONE farm in module state (as the reference keeps one simulation): a second live
         # instance would silently take it over
@@ -89,6 +89,13 @@ class FortranFarm:
         self.eng = Engine(topo, system.box_matrix, system.bounds_lo, system.real_space_cutoff,
                           system.ewald_tolerance, self.R, device, self.mol_capacity)
         self.eng.load_system(system, 0)
+        # device_build: the engine keeps the molecules' frames (com, offsets) and builds the trial moves itself; the
+        # Fortran driver then holds no mirror of the coordinates (orthorhombic boxes)
+        self.device_build = bool(device_build) and not system.is_triclinic()
+        if self.device_build:
+            for tt in range(topo.n_res):
+                if topo.is_active[tt]:
+                    self.eng.set_frames(0, tt, system.com[tt], system.offsets[tt])
         self.eng.init_structure_factor(0, True)
         for r in range(1, self.R):
             self.eng.replica_copy(r, 0)
@@ -111,6 +118,7 @@ class FortranFarm:
                             e0["intra_coulomb"]])
         lo = np.ascontiguousarray(system.bounds_lo)
         length = np.ascontiguousarray(np.diag(system.box_matrix))
+        self.H.mfarm_configure(C.c_int(1 if self.device_build else 0))
         rc = self.H.mfarm_create(self.eng.h, C.c_int(self.R), C.c_int(len(active)), self.active.ctypes.data_as(_ip),
                                  n1.ctypes.data_as(_ip), nmol.ctypes.data_as(_ip), cap.ctypes.data_as(_ip),
                                  C.c_int(max_n1), com.ctypes.data_as(_dp), off.ctypes.data_as(_dp),

@@ -14,10 +14,15 @@ pytestmark = pytest.mark.gpu
                                            (lambda: synth.mixture_box(seed=4), 5, 50),
                                            (lambda: synth.mixture_box(seed=4, tilt=(1.5, -0.8, 0.6)), 4, 50),
                                            (lambda: synth.rigid_adsorbate_box(), 3, 30)])
-def test_fortran_farm_consistency(maker, R, steps):
+@pytest.mark.parametrize("device_build", [False, True], ids=["host_built", "device_built"])
+def test_fortran_farm_consistency(maker, R, steps, device_build):
+    """device_built: the engine keeps the molecules' frames and builds the trial moves itself (mgpu_move_trial_submit);
+    the Fortran driver then has no mirror, and farm.molecule() reads the frames back from the device (the triclinic
+    case falls back to the host construction)."""
     from maniac_mc_amd.fortran_host import FortranFarm
     s = maker()
-    farm = FortranFarm(s, R, seed=11, translation_step=0.4, rotation_step=0.4)
+    farm = FortranFarm(s, R, seed=11, translation_step=0.4, rotation_step=0.4, device_build=device_build)
+    assert farm.device_build == (device_build and not s.is_triclinic())
     acc = farm.run(steps)
     assert farm.trials + farm.skipped == R * steps and 0 < acc <= farm.trials
     assert acc == farm.accepted
@@ -73,7 +78,8 @@ def test_fortran_farm_intrinsic_rng_and_single_replica():
     farm.close()
 
 
-def test_gcmc_farm_consistency_and_ideal_gas_limit():
+@pytest.mark.parametrize("device_build", [False, True], ids=["host_built", "device_built"])
+def test_gcmc_farm_consistency_and_ideal_gas_limit(device_build):
     """Grand-canonical chains (BASELINE.json configs[2]/[4] in miniature): insertion / deletion /
     translation / rotation of rigid CO2 in a 50 A box at several fugacities, one per replica group.
     (1) bookkeeping: counts, running 5-component energies, A(k) and host mirrors equal a from-scratch
@@ -84,7 +90,7 @@ def test_gcmc_farm_consistency_and_ideal_gas_limit():
     V = 50.0 ** 3
     targets = np.repeat([10.0, 20.0, 30.0], R // 3)               # phi V per replica
     farm = FortranFarm(s, R, seed=17, translation_step=1.0, rotation_step=0.6, n_threads=4, mol_capacity=[90],
-                       gcmc=dict(p_translation=0.2, p_rotation=0.2, fugacity=targets / V))
+                       gcmc=dict(p_translation=0.2, p_rotation=0.2, fugacity=targets / V), device_build=device_build)
     farm.run(600)                                                   # equilibrate
     samples = []
     for _ in range(40):
@@ -147,14 +153,15 @@ def test_gcmc_farm_in_a_triclinic_box():
     farm.close()
 
 
-def test_farm_at_benchmark_size_three_lanes():
+@pytest.mark.parametrize("device_build", [False, True], ids=["host_built", "device_built"])
+def test_farm_at_benchmark_size_three_lanes(device_build):
     """The bench workload itself (3375 SPC/E, N = 10 125, Nk = 2242) in miniature: 48 chains on three lanes,
     150 steps; every chain's running energy equals a from-scratch evaluation of its final configuration and
     A(k) equals a fresh S(k) -- the size-independent invariant of the whole submit / wait / commit pipeline."""
     from maniac_mc_amd.fortran_host import FortranFarm
     s = synth.spce_box(15)
     R, steps = 48, 150
-    farm = FortranFarm(s, R, seed=29, translation_step=0.3, rotation_step=0.3, n_threads=4, n_lanes=3)
+    farm = FortranFarm(s, R, seed=29, translation_step=0.3, rotation_step=0.3, n_threads=4, n_lanes=3, device_build=device_build)
     assert farm.n_lanes == 3
     acc = farm.run(steps)
     assert farm.trials == R * steps and 0.4 * farm.trials < acc < 0.95 * farm.trials
@@ -170,7 +177,8 @@ def test_farm_at_benchmark_size_three_lanes():
     farm.close()
 
 
-def test_gcmc_farm_framework_water_at_stated_size():
+@pytest.mark.parametrize("device_build", [False, True], ids=["host_built", "device_built"])
+def test_gcmc_farm_framework_water_at_stated_size(device_build):
     """BASELINE.json configs[3] at its stated size: the 2208-atom inactive framework (site-major sweep, 35
     chunks per molecule) + 4-site water as the adsorbate, full move set (translation / rotation / insertion /
     deletion) on 12 chains at two fugacities.  Bookkeeping invariants: counts, running 5-component energies
@@ -182,7 +190,7 @@ def test_gcmc_farm_framework_water_at_stated_size():
     V = 34.0 ** 3
     fug = np.repeat([30.0, 80.0], R // 2) / V
     farm = FortranFarm(s, R, seed=23, translation_step=0.5, rotation_step=0.5, n_threads=4, mol_capacity=[1, 120],
-                       gcmc=dict(p_translation=0.25, p_rotation=0.25, fugacity=fug))
+                       gcmc=dict(p_translation=0.25, p_rotation=0.25, fugacity=fug), device_build=device_build)
     farm.run(400)
     c = farm.counters()
     assert c["trial_creations"] > 0 and c["trial_deletions"] > 0 and c["creations"] > 0 and c["deletions"] > 0

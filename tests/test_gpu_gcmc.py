@@ -163,3 +163,82 @@ def test_deferred_commit_is_bitwise_the_immediate_commit():
         assert np.array_equal(oa, ob) and np.array_equal(na, nb)
     for r in range(R):
         assert np.array_equal(st_a["A"][r], st_b["A"][r]) and np.array_equal(st_a["pos"][r], st_b["pos"][r])
+
+
+def test_device_built_trials_match_host_built_rows():
+    """mgpu_move_trial_submit builds the trial geometry on the device from the resident molecule frames and the host's
+    uniform numbers (Translation / Rotation / CreateMolecule of the reference).  Here the same moves are constructed in
+    numpy from the same numbers and handed over as explicit rows (mgpu_gcmc_trial_submit): energies agree to the parity
+    bar (the rotated offsets may differ in the last bit: device sincos against numpy's); after committing a few of the
+    device-built candidates from the lane's resident rows, sites == com + offsets of the frames read back, the counts
+    follow and A(k) equals a fresh S(k)."""
+    s = synth.co2_box(30, seed=3)
+    L = np.diag(s.box_matrix)
+    lo = s.bounds_lo
+    eng = Engine(s.topo, s.box_matrix, s.bounds_lo, s.real_space_cutoff, s.ewald_tolerance, 2, 0, [48])
+    eng.set_frames(0, 0, s.com[0], s.offsets[0])
+    eng.init_structure_factor(0, True)
+    eng.replica_copy(1, 0)
+    com0, off0 = eng.get_frames(1, 0)
+    assert np.array_equal(com0, s.com[0]) and np.array_equal(off0, s.offsets[0])
+    assert np.array_equal(eng.get_molecules(1, 0), s.all_sites(0))
+    rng = np.random.default_rng(12)
+    n = 24
+    rep = ((np.arange(n) // 4) % 2).astype(np.int32)        # every move code on both replicas
+    t = np.zeros(n, np.int32)
+    move = np.array([1, 2, 3, 4] * 6, dtype=np.int32)
+    m = rng.integers(0, 30, n).astype(np.int32)
+    u = rng.random((n, 5))
+    t_step, r_step = 1.0, 0.6
+    rows = np.zeros((n, 3, 3))
+    kinds = np.zeros(n, np.int32)
+    for c in range(n):
+        com, off = s.com[0][m[c]].copy(), s.offsets[0][m[c]].copy()
+        if move[c] == 1:
+            x = (com + (u[c, :3] - 0.5) * t_step) - lo
+            x = np.where((x < 0) | (x >= L), np.mod(x, L), x)
+            com = lo + x
+            kinds[c] = MGPU_MOVE
+        elif move[c] in (2, 3):
+            if move[c] == 3:
+                com, off = lo + L * u[c, :3], s.offsets[0][0].copy()
+            theta = (u[c, 3] - 0.5) * r_step if move[c] == 2 else u[c, 3] * 2 * np.pi
+            axis = int(u[c, 4] * 3.0) + 1
+            p, q = axis % 3, (axis + 1) % 3
+            x, y = off[:, p].copy(), off[:, q].copy()
+            off[:, p] = np.cos(theta) * x - np.sin(theta) * y
+            off[:, q] = np.sin(theta) * x + np.cos(theta) * y
+            kinds[c] = MGPU_MOVE if move[c] == 2 else MGPU_CREATION
+        else:
+            kinds[c] = MGPU_DELETION
+        rows[c] = com[None, :] + off
+    old_h, new_h = eng.gcmc_trial(rep, t, m, kinds, rows, lane=1)
+    old_d, new_d = eng.move_trial(rep, t, m, move, u, t_step, r_step, lane=0)
+    close(old_d, old_h, "device-built old")
+    close(new_d, new_h, "device-built new")
+    # commit: one move on replica 0, one insertion on replica 1 (resident rows of lane 0)
+    acc = np.zeros(n, np.int32)
+    c_mv = int(np.flatnonzero((move == 1) & (rep == 0))[0])
+    c_cr = int(np.flatnonzero((move == 3) & (rep == 1))[0])
+    acc[c_mv] = 1
+    acc[c_cr] = 1
+    eng.commit_lane(0, rep, t, m, kinds, acc)
+    assert [eng.num_molecules(r, 0) for r in range(2)] == [30, 31]
+    for r in range(2):
+        com, off = eng.get_frames(r, 0)
+        assert np.array_equal(eng.get_molecules(r, 0), com[:, None, :] + off)
+        A = eng.structure_factor(r)
+        eng.init_structure_factor(r, True)
+        amp_close(A, eng.structure_factor(r), f"replica {r} A after a device-built commit")
+    assert np.max(np.abs(eng.get_molecules(0, 0)[m[c_mv]] - rows[c_mv])) < 1e-12
+    assert np.max(np.abs(eng.get_molecules(1, 0)[30] - rows[c_cr])) < 1e-12
+    # a deletion on replica 0 moves the last molecule's frame with its sites
+    c_de = int(np.flatnonzero((move == 4) & (rep == 0))[0])
+    old2, new2 = eng.move_trial([0], [0], [m[c_de]], [4], np.zeros((1, 5)), t_step, r_step)
+    eng.commit_lane(0, [0], [0], [m[c_de]], [MGPU_DELETION], [1])
+    com, off = eng.get_frames(0, 0)
+    assert com.shape[0] == 29 and np.array_equal(eng.get_molecules(0, 0), com[:, None, :] + off)
+    # bare-site commits would leave the frames behind: refused while the replica holds frames
+    with pytest.raises(Exception):
+        eng.commit_candidates([0], [0], [1], [MGPU_MOVE], rows[:1], [1])
+    eng.close()
