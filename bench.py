@@ -593,6 +593,25 @@ def main():
             eng.trial_energy_candidates(np.arange(n_l, dtype=np.int32), np.zeros(n_l, np.int32), m_iso, sites_iso)
         n_iso, ms_iso = eng.profile_get(_lib.KERNEL_PAIR)
         iso_us = ms_iso / max(1, n_iso) * 1e3
+    iso_gc = None
+    if rank == 0 and wl != "spce" and args.device_build:
+        # grand-canonical workloads: one lane's batch of device-built trials (the farm's move mix on the chains' current
+        # states) launched alone, evaluation only
+        rng = np.random.default_rng(5)
+        n_l = max(1, R // farm.n_lanes)
+        cnt_l = farm.counts()[:n_l, 0]
+        draw = rng.random(n_l)
+        mv = np.where(draw < p_move / 2, 1, np.where(draw < p_move, 2, np.where(rng.random(n_l) < 0.5, 3, 4))).astype(np.int32)
+        mv[(cnt_l == 0) & (mv != 3)] = 3
+        m_iso = np.minimum((rng.random(n_l) * np.maximum(cnt_l, 1)).astype(np.int32), np.maximum(cnt_l, 1) - 1).astype(np.int32)
+        u_iso = rng.random((n_l, 5))
+        eng.profile_reset()
+        for _ in range(10):
+            eng.move_trial(np.arange(n_l, dtype=np.int32), np.full(n_l, t_act, np.int32), m_iso, mv, u_iso, t_step, r_step)
+        ev_iso = float(2 * (mv <= 2).sum() + (mv > 2).sum())
+        n_ip, ms_ip = eng.profile_get(_lib.KERNEL_PAIR)
+        n_ik, ms_ik = eng.profile_get(_lib.KERNEL_RECIP)
+        iso_gc = {"candidates": int(n_l), "evaluations": ev_iso, "pair_sweep_us": ms_ip / 10 * 1e3, "k_sweep_us": ms_ik / max(1, n_ik) * 1e3}
     eng.profile_enable(False)
 
     if rank == 0:
@@ -653,6 +672,12 @@ def main():
                             "peak": HBM_PEAK_GBS,
                             "note": "36 N bytes per evaluation (SURVEY 8(d)) / pair-sweep time: an algorithmic figure served mostly from "
                                     "L2 / Infinity Cache, NOT an HBM utilisation"}}
+            if iso_gc:
+                roof["isolated"] = {"avg_launch_us": iso_gc["pair_sweep_us"], "evaluations": iso_gc["evaluations"],
+                                    "achieved": iso_gc["evaluations"] * flop_eval / (iso_gc["pair_sweep_us"] * 1e-6) / 1e12,
+                                    "frac": iso_gc["evaluations"] * flop_eval / (iso_gc["pair_sweep_us"] * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                    "note": "one lane's batch of device-built trials launched alone after the timed region (pair-sweep "
+                                            "time per launch group)"}
             if iso_us:
                 ev_l = 2.0 * max(1, R // n_lanes)
                 roof["isolated"] = {"avg_launch_us": iso_us, "achieved": ev_l * flop_eval / (iso_us * 1e-6) / 1e12,
@@ -675,6 +700,14 @@ def main():
                                        f"libmaniac_hip.so sha256 {pmc['lib_sha256'][:16]} = the library loaded now; per evaluation x "
                                        "this run's evaluations per launch)") if fresh else
                                       ("STALE: " + pmc["path"] + " was taken from another build of libmaniac_hip.so" if pmc else "none"),
+                    "isolated": ({"avg_launch_us": iso_gc["k_sweep_us"], "evaluations": iso_gc["evaluations"],
+                                  "achieved": bytes_k_eval * iso_gc["evaluations"] / (iso_gc["k_sweep_us"] * 1e-6) / 1e9,
+                                  "frac": bytes_k_eval * iso_gc["evaluations"] / (iso_gc["k_sweep_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                  "measured_traffic_GBs": pmc["hbm_bytes_per_eval"] * iso_gc["evaluations"] / (iso_gc["k_sweep_us"] * 1e-6) / 1e9 if fresh else None,
+                                  "measured_traffic_frac": pmc["hbm_bytes_per_eval"] * iso_gc["evaluations"] / (iso_gc["k_sweep_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS if fresh else None,
+                                  "note": "one lane's batch launched alone after the timed region; measured_traffic = the PMC bytes per "
+                                          "evaluation (A(k) is 32 B per +-kz pair and is only read by the k sweep, a third of the 52 Nk "
+                                          "algorithmic figure) over the same time"} if iso_gc else None),
                     "job_frac": evals_rank * (bytes_pair_eval + bytes_k_eval) / elapsed / 1e9 / HBM_PEAK_GBS,
                     "job_frac_note": "all evaluations x (36 N + 52 Nk) algorithmic bytes / timed_region_s / HBM peak"}
         roof["kernels"] = kernels

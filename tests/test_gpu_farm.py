@@ -235,8 +235,9 @@ def test_farm_options_keep_the_invariants(env):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("gcmc", [False, True], ids=["spce_nvt", "co2_gcmc"])
-def test_long_run_drift(gcmc):
+@pytest.mark.parametrize("gcmc,host_build", [(False, False), (True, False), (True, True)],
+                         ids=["spce_nvt_device_built", "co2_gcmc_device_built", "co2_gcmc_host_built"])
+def test_long_run_drift(gcmc, host_build):
     """tools/long_run_check.py as a test: ~1 M trials at the benchmark size (SPC/E NVT: 256 chains x 4000 steps on four
     lanes; CO2 GCMC: 512 chains x 2000 steps), after which every sampled chain's running energies must equal a
     from-scratch evaluation to the random-walk tolerance of tests/util.py::farm_tol and A(k) a fresh S(k) to 1e-9
@@ -248,7 +249,7 @@ def test_long_run_drift(gcmc):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     steps = 2000 if gcmc else 4000
     cmd = [sys.executable, os.path.join(root, "tools", "long_run_check.py"), "--steps", str(steps), "--lanes", "4",
-           "--replicas", "512" if gcmc else "256"] + (["--gcmc"] if gcmc else [])
+           "--replicas", "512" if gcmc else "256"] + (["--gcmc"] if gcmc else []) + (["--host-build"] if host_build else [])
     p = subprocess.run(cmd, capture_output=True, text=True, cwd=root, timeout=1200)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     m = re.search(r"energy\| = ([0-9.e+-]+) K, max \|A - S\(k\)\| = ([0-9.e+-]+), largest \|E\| = ([0-9.e+-]+)", p.stdout)
