@@ -61,7 +61,7 @@ def pmc_summary(workload, kernel_substr):
             d = json.load(f)
     except Exception:
         return None
-    out = {"path": path, "build": d.get("build"), "lib_sha256": d.get("lib_sha256"),
+    out = {"path": path, "build": d.get("build"), "lib_sha256": d.get("lib_sha256"), "candidates": float(d.get("candidates_per_launch") or 0.0),
            "evals": float(d.get("evaluations_per_launch_group") or 0.0), "stale": d.get("lib_sha256") != lib_sha256(), "kernels": []}
     if out["stale"] or not out["evals"]:
         return out
@@ -688,6 +688,7 @@ def main():
             pmc = pmc_summary(wl if wl != "co2_isotherm" else "co2_gcmc", "recip_rows_kernel<false")
             fresh = bool(pmc) and not pmc["stale"] and pmc.get("hbm_bytes_per_eval") is not None
             gbs = bytes_k_eval * evals_rank / (ms_rec * 1e-3) / 1e9 if ms_rec else None
+            k_item_bytes = pmc["hbm_bytes_per_eval"] * pmc["evals"] / pmc["candidates"] if fresh and pmc.get("candidates") else 0.0
             roof = {"bound": "hbm", "kernel": "recip_rows_kernel<false,true> (k sweep: old and new reciprocal energy of every candidate from one pass over A(k))",
                     "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS if gbs else None,
                     "achieved_basis": f"ALGORITHMIC bytes: 52 Nk = {bytes_k_eval:.0f} B per evaluation (SURVEY 8(d)) x "
@@ -703,11 +704,11 @@ def main():
                     "isolated": ({"avg_launch_us": iso_gc["k_sweep_us"], "evaluations": iso_gc["evaluations"],
                                   "achieved": bytes_k_eval * iso_gc["evaluations"] / (iso_gc["k_sweep_us"] * 1e-6) / 1e9,
                                   "frac": bytes_k_eval * iso_gc["evaluations"] / (iso_gc["k_sweep_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                  "measured_traffic_GBs": pmc["hbm_bytes_per_eval"] * iso_gc["evaluations"] / (iso_gc["k_sweep_us"] * 1e-6) / 1e9 if fresh else None,
-                                  "measured_traffic_frac": pmc["hbm_bytes_per_eval"] * iso_gc["evaluations"] / (iso_gc["k_sweep_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS if fresh else None,
+                                  "measured_traffic_GBs": k_item_bytes * iso_gc["candidates"] / (iso_gc["k_sweep_us"] * 1e-6) / 1e9 if fresh else None,
+                                  "measured_traffic_frac": k_item_bytes * iso_gc["candidates"] / (iso_gc["k_sweep_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS if fresh else None,
                                   "note": "one lane's batch launched alone after the timed region; measured_traffic = the PMC bytes per "
-                                          "evaluation (A(k) is 32 B per +-kz pair and is only read by the k sweep, a third of the 52 Nk "
-                                          "algorithmic figure) over the same time"} if iso_gc else None),
+                                          "CANDIDATE (one pass over A(k) serves both evaluations of a move; A(k) is 32 B per +-kz pair "
+                                          "and is only read by the k sweep: a third of the 52 Nk algorithmic figure) over the same time"} if iso_gc else None),
                     "job_frac": evals_rank * (bytes_pair_eval + bytes_k_eval) / elapsed / 1e9 / HBM_PEAK_GBS,
                     "job_frac_note": "all evaluations x (36 N + 52 Nk) algorithmic bytes / timed_region_s / HBM peak"}
         roof["kernels"] = kernels

@@ -85,7 +85,10 @@ struct Lane {
     bool last_trial_built = false;                 // ... built on the device (rows carry the candidates' frames)
     int last_trial_frame = 0;                      // site index of the frame inside such a row
     int n_pair_items = 0, n_split = 1;   // reduced pair-energy entries of the trial in flight (2 per fused item + 1 per single)
-    int n_fused = 0;                      // of which the first 2 * n_fused belong to fused (old + new) items
+    int n_fused = 0;                      // fused (old + new) items of the trial in flight, all site-count classes together
+    // reduced pair-energy entry i sums `n_split` partials starting at double ent_off[i] of the result block, ent_stride[i]
+    // doubles apart (a fused item's partials are laid out [split][state], a single item's [split])
+    std::vector<int> ent_off, ent_stride;
     const RecipItem *d_trial_items = nullptr;   // RecipItems of the last trial, resident while last_trial_n != 0
     const RecipItem *h_trial_items = nullptr;   // their host image in h_in (valid until the next trial_submit)
     int trial_n1_max = 1;
@@ -1461,22 +1464,61 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     ln.intra_idx.assign(n, -1);
     ln.kinds.assign(n, MGPU_MOVE);
     ln.self_of.assign(n, 0.0);
-    int n1_max = 1, common = -1, n_intra = 0, n_moves = 0;
+    int n1_max = 1, n_intra = 0;
+    // Candidates are grouped by the site count of their residue type: every class gets its own pair-sweep launches with
+    // the register-site kernels of that size (a mixture of a 3-site and a 2-site species used to fall to the generic
+    // NS = 0 sweep for the whole launch).  Within a class, trial moves of molecules with a few sites are swept old + new
+    // together (fused items, two entries each); insertions, deletions and everything else are single-state items.
+    struct Seg { int n1, fused, first_item, n_items, first_entry; };
+    int cls_n1[kMaxRes], cls_moves[kMaxRes], cls_single[kMaxRes], n_cls = 0;
     for (int c = 0; c < n; ++c) {
         const int k = kind ? kind[c] : MGPU_MOVE;
         if (k < MGPU_MOVE || k > MGPU_DELETION) return set_error(MGPU_ERR_INVALID_ARG, "trial_submit: unknown candidate kind");
         if (t[c] < 0 || t[c] >= e->tp.n_res) return set_error(MGPU_ERR_INVALID_ARG, "trial_submit: residue type out of range");
         const int n1 = e->tp.n1[t[c]];
-        common = (common == -1 || common == n1) ? n1 : 0;
-        n_moves += (k == MGPU_MOVE);
+        int ci = 0;
+        while (ci < n_cls && cls_n1[ci] != n1) ++ci;
+        if (ci == n_cls) { cls_n1[ci] = n1; cls_moves[ci] = 0; cls_single[ci] = 0; ++n_cls; }     // <= n_res distinct values
+        const bool fz = k == MGPU_MOVE && e->pair_fuse && !e->bx.triclinic && n1 <= e->pair_fuse_max;
+        if (fz) cls_moves[ci] += 1;
+        else cls_single[ci] += (k == MGPU_MOVE) ? 2 : 1;
     }
-    // Trial moves of molecules with a few sites are swept old + new together (fused items, two entries each);
-    // insertions, deletions and everything else are single-state items.  Entry layout of the reduced pair
-    // energies: [2 i + {0 old, 1 new} for fused item i | 2 n_fused + j for single item j].
-    const bool fuse = e->pair_fuse && !e->bx.triclinic && common >= 1 && common <= e->pair_fuse_max;
-    const int n_fused = fuse ? n_moves : 0;
-    int i_fused = 0, i_single = 0;
-    PairItem *pit_single = pit + n_fused;
+    std::vector<Seg> segs;
+    int seg_fused[kMaxRes], seg_single[kMaxRes];        // per class: index of its fused / single segment (-1: none)
+    int n_items_total = 0, n_pair = 0, n_fused = 0;
+    for (int ci = 0; ci < n_cls; ++ci) {
+        seg_fused[ci] = seg_single[ci] = -1;
+        if (cls_moves[ci]) {
+            seg_fused[ci] = (int)segs.size();
+            segs.push_back(Seg{cls_n1[ci], 1, n_items_total, 0, n_pair});
+            n_items_total += cls_moves[ci];
+            n_pair += 2 * cls_moves[ci];
+            n_fused += cls_moves[ci];
+        }
+        if (cls_single[ci]) {
+            seg_single[ci] = (int)segs.size();
+            segs.push_back(Seg{cls_n1[ci], 0, n_items_total, 0, n_pair});
+            n_items_total += cls_single[ci];
+            n_pair += cls_single[ci];
+        }
+    }
+    const int nsplit = e->pair_nsplit;
+    ln.ent_off.assign(n_pair, 0);
+    ln.ent_stride.assign(n_pair, 2);
+    auto add_item = [&](Seg &sg, const PairItem &it) {     // returns the item's first entry
+        const int i = sg.n_items++;
+        pit[sg.first_item + i] = it;
+        const int e0 = sg.first_entry + (sg.fused ? 2 * i : i);
+        // partial records (double2) of the segment start at first_entry * nsplit; [split][state] for fused items
+        if (sg.fused) {
+            ln.ent_off[e0] = 2 * ((sg.first_entry + 2 * i) * nsplit);
+            ln.ent_off[e0 + 1] = ln.ent_off[e0] + 2;
+            ln.ent_stride[e0] = ln.ent_stride[e0 + 1] = 4;
+        } else {
+            ln.ent_off[e0] = 2 * ((sg.first_entry + i) * nsplit);
+        }
+        return e0;
+    };
     bool fast = true;                 // all replicas of this trial within the fast fold's range
     ln.cand_ok.assign(n, 1);          // and per candidate: would committing it keep its replica there
     for (int c = 0; c < n; ++c) {
@@ -1486,6 +1528,8 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
         const int n1 = e->tp.n1[t[c]];
         if (n1 > site_stride) return set_error(MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res");
         n1_max = std::max(n1_max, n1);
+        int ci = 0;
+        while (cls_n1[ci] != n1) ++ci;
         ln.kinds[c] = k;
         fast = fast && replica_in_range(e, replica[c]);
         if (build) {
@@ -1504,18 +1548,19 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
             fast = fast && ln.cand_ok[c];          // the candidate's own sites are swept in this launch
         }
         if (k != MGPU_MOVE) ln.self_of[c] = e->self_of_type[t[c]];
-        if (k == MGPU_MOVE && fuse) {
-            ln.pair_old[c] = 2 * i_fused; ln.pair_new[c] = 2 * i_fused + 1;
-            pit[i_fused++] = PairItem{replica[c], t[c], mc, c, 0};
+        const bool fz = k == MGPU_MOVE && seg_fused[ci] >= 0;
+        if (fz) {
+            const int e0 = add_item(segs[seg_fused[ci]], PairItem{replica[c], t[c], mc, c, 0});
+            ln.pair_old[c] = e0; ln.pair_new[c] = e0 + 1;
         } else {
-            if (k != MGPU_CREATION) { ln.pair_old[c] = 2 * n_fused + i_single; pit_single[i_single++] = PairItem{replica[c], t[c], mc, -1, 0}; }
-            if (k != MGPU_DELETION) { ln.pair_new[c] = 2 * n_fused + i_single; pit_single[i_single++] = PairItem{replica[c], t[c], mc, c, 0}; }
+            Seg &sg = segs[seg_single[ci]];
+            if (k != MGPU_CREATION) ln.pair_old[c] = add_item(sg, PairItem{replica[c], t[c], mc, -1, 0});
+            if (k != MGPU_DELETION) ln.pair_new[c] = add_item(sg, PairItem{replica[c], t[c], mc, c, 0});
         }
         rit[c] = RecipItem{replica[c], t[c], mc, k, k == MGPU_DELETION ? -1 : c, 0, frame_at};   // one k sweep: old and new
         if (k == MGPU_CREATION) { ln.intra_idx[c] = n_intra; iit[n_intra++] = PairItem{replica[c], t[c], -1, c, 0}; }
         if (k == MGPU_DELETION) { ln.intra_idx[c] = n_intra; iit[n_intra++] = PairItem{replica[c], t[c], mc, -1, 0}; }
     }
-    const int n_single = i_single, n_pair = 2 * n_fused + n_single;     // reduced pair-energy entries
     if (build) {
         std::memcpy((char *)ln.h_in.p + build_at, build->move, (size_t)n * sizeof(int));
         std::memcpy((char *)ln.h_in.p + build_at + build_mv, build->u, (size_t)5 * n * sizeof(double));
@@ -1526,7 +1571,6 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     const size_t iit_bytes = (size_t)n_intra * sizeof(PairItem);
     // results in device memory, copied out once: [split partials of the pair sweep (n_pair * nsplit complex-sized
     // records, reduced on the host in trial_wait) | u_old | u_new | intra]
-    const int nsplit = e->pair_nsplit;
     const size_t out_doubles = 2 * (size_t)n_pair * nsplit + 3 * (size_t)n;
     // A deferred commit of this lane rides in this trial's k sweep when every new candidate sits on its own replica
     // and the row-form kernel applies; otherwise it is launched on its own first.
@@ -1597,15 +1641,10 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
             return rc;
         ln.deferred.active = false;
     }
-    if (n_fused) {
-        if ((rc = launch_pair(e, ln, d_pit, n_fused, common, site_stride, nsplit, nullptr, nullptr, false, d_part, true, fast)))
+    for (const Seg &sg : segs)
+        if ((rc = launch_pair(e, ln, d_pit + sg.first_item, sg.n_items, sg.n1, site_stride, nsplit, nullptr, nullptr, false,
+                              d_part + (size_t)sg.first_entry * nsplit, sg.fused != 0, fast)))
             return rc;
-    }
-    if (n_single) {
-        if ((rc = launch_pair(e, ln, d_pit + n_fused, n_single, std::max(common, 0), site_stride, nsplit, nullptr, nullptr, false,
-                              d_part + 2 * (size_t)n_fused * nsplit, false, fast)))
-            return rc;
-    }
     if (!fused_k && (rc = launch_recip(e, ln, d_rit, n, n1_max, site_stride, false, e->d_A, d_un, d_uo)))
         return rc;
     if (n_intra) {
@@ -1635,7 +1674,7 @@ static int trial_wait_impl(mgpu_engine *e, Lane &ln, double *old_energy, double 
     ln.n_submitted = 0;
     int rc = sync_lane(e, ln);
     if (rc) return rc;
-    const int np = ln.n_pair_items, ns = ln.n_split, nf = ln.n_fused;
+    const int np = ln.n_pair_items, ns = ln.n_split;
     const double *h = (const double *)ln.h_out.p;
     const double *uo = h + 2 * (size_t)np * ns, *un = uo + n, *in = un + n;
     // the ordered sum of the split partials and the Coulomb rescale e_coulomb * EPS0_INV_eVA / KB_eVK
@@ -1645,9 +1684,8 @@ static int trial_wait_impl(mgpu_engine *e, Lane &ln, double *old_energy, double 
     ln.h_cc.resize(np);
     for (int i = 0; i < np; ++i) {
         double a = 0.0, b = 0.0;
-        const bool fz = i < 2 * nf;
-        const double *p = fz ? h + 2 * ((size_t)(i >> 1) * ns * 2 + (i & 1)) : h + 2 * ((size_t)2 * nf * ns + (size_t)(i - 2 * nf) * ns);
-        const int stride = fz ? 4 : 2;
+        const double *p = h + ln.ent_off[i];
+        const int stride = ln.ent_stride[i];
         for (int s2 = 0; s2 < ns; ++s2) { a += p[stride * s2]; b += p[stride * s2 + 1]; }
         ln.h_lj[i] = a;
         ln.h_cc[i] = b * kEps0InvEvA / kKbEvK;
