@@ -47,7 +47,7 @@ module mc_farm
     private
     public :: mfarm_create, mfarm_run, mfarm_destroy, mfarm_get_energy, mfarm_get_molecule, mfarm_recalibrate
     public :: mfarm_get_timers, mfarm_set_gcmc, mfarm_get_counts, mfarm_get_counters, mfarm_set_triclinic
-    public :: mfarm_rng_sample, mfarm_set_drivers, mfarm_configure
+    public :: mfarm_rng_sample, mfarm_set_drivers, mfarm_configure, mfarm_select
 
     real(real64), parameter :: PI = 3.14159265358979323846_real64
     real(real64), parameter :: TWOPI = 2.0_real64 * PI
@@ -113,7 +113,12 @@ module mc_farm
         integer(int64), allocatable :: cxs(:, :)           ! (4, R) xoshiro256+ state of every chain
     end type farm_state
 
-    type(farm_state), save, target :: F
+    ! Several farms may exist in one process (one per engine: different boxes, force fields or GPUs); the entry points act
+    ! on the SELECTED one (mfarm_select; slot 0 until told otherwise).  The selection is process-wide: farms are driven
+    ! one call at a time.
+    integer, parameter :: MAX_FARMS = 8
+    type(farm_state), save, target :: farms(0:MAX_FARMS - 1)
+    type(farm_state), pointer, save :: F => farms(0)
     logical, save :: want_device_build = .false.           ! consumed by the next mfarm_create (mfarm_configure)
 
     interface
@@ -849,6 +854,16 @@ contains
             t = t + F%lane(g)%ticks
         end do
     end subroutine lane_ticks
+
+    ! Select the farm slot (0 .. MAX_FARMS - 1) the following calls act on; returns 0, or 1 for a slot out of range.
+    function mfarm_select(slot) bind(C, name="mfarm_select") result(rc)
+        integer(c_int), value :: slot
+        integer(c_int) :: rc
+        rc = 1
+        if (slot < 0 .or. slot >= MAX_FARMS) return
+        F => farms(slot)
+        rc = 0
+    end function mfarm_select
 
     ! device_build /= 0: the NEXT farm created builds its trial moves on the device from the frames the caller uploaded with
     ! mgpu_replica_set_frames (orthorhombic boxes); 0: on the host from its mirror (the default)

@@ -69,17 +69,20 @@ class FortranFarm:
     type, or (n_active, R) for an isotherm sweep; ``mol_capacity`` bounds the molecule count per type.
     """
 
-    _live = None          # the one farm the Fortran module holds (see __init__)
+    _live = None          # the farm created last that is still open (tests close leftovers through it)
+    _slots = {}           # farm slot of the Fortran module (mfarm_select) -> the open farm that holds it
+    MAX_FARMS = 8
 
     def __init__(self, system: System, n_replicas: int, device: int = 0, seed: int = 1,
                  translation_step: float = 0.3, rotation_step: float = 0.3, p_translation: float = 0.5,
                  rng_kind: int = 1, n_threads: int = 8, mol_capacity=None, gcmc=None,
                  n_lanes: int = 2, n_drivers: int = 1, device_build: bool = False):
         self.H = lib()
-        # mc_farm.f90 keeps ONE farm in module state (as the reference keeps one simulation): a second live
-        # instance would silently take it over
-        if FortranFarm._live is not None:
-            raise RuntimeError("a FortranFarm is already active in this process: close() it first")
+        # mc_farm.f90 keeps up to MAX_FARMS farms; every call below selects this farm's slot first
+        free = [k for k in range(FortranFarm.MAX_FARMS) if k not in FortranFarm._slots]
+        if not free:
+            raise RuntimeError(f"{FortranFarm.MAX_FARMS} FortranFarms are already open in this process: close() one first")
+        self.slot = -1
         self.sys = system
         self.R = int(n_replicas)
         topo = system.topo
@@ -118,6 +121,9 @@ class FortranFarm:
                             e0["intra_coulomb"]])
         lo = np.ascontiguousarray(system.bounds_lo)
         length = np.ascontiguousarray(np.diag(system.box_matrix))
+        self.slot = free[0]
+        FortranFarm._slots[self.slot] = self
+        self._select()
         self.H.mfarm_configure(C.c_int(1 if self.device_build else 0))
         rc = self.H.mfarm_create(self.eng.h, C.c_int(self.R), C.c_int(len(active)), self.active.ctypes.data_as(_ip),
                                  n1.ctypes.data_as(_ip), nmol.ctypes.data_as(_ip), cap.ctypes.data_as(_ip),
@@ -154,14 +160,19 @@ class FortranFarm:
             if rc:
                 raise ValueError(f"mfarm_set_gcmc: bad probabilities / fugacity (code {rc})")
 
+    def _select(self):
+        self.H.mfarm_select(C.c_int(self.slot))
+
     def run(self, n_steps: int) -> int:
         """Advance every chain by n_steps move selections; returns the moves accepted during this call."""
+        self._select()
         before = self.stats[1]
         rc = self.H.mfarm_run(C.c_int(n_steps), self.stats.ctypes.data_as(_dp))
         _lib.check(rc)
         return int(self.stats[1] - before)
 
     def recalibrate(self):
+        self._select()
         s = np.zeros(2)
         self.H.mfarm_recalibrate(s.ctypes.data_as(_dp))
         return s
@@ -169,11 +180,13 @@ class FortranFarm:
     def timers(self):
         """Host seconds in: generate, submit, wait-for-GPU, resolve, commit-submit."""
         t = np.zeros(7)
+        self._select()
         self.H.mfarm_get_timers(t.ctypes.data_as(_dp))
         return dict(zip(("generate", "submit", "wait", "resolve", "commit", "gen_rng", "gen_gather"), t.tolist()))
 
     def counters(self):
         c = np.zeros(8)
+        self._select()
         self.H.mfarm_get_counters(c.ctypes.data_as(_dp))
         names = ("trial_translations", "translations", "trial_rotations", "rotations", "trial_creations",
                  "creations", "trial_deletions", "deletions")
@@ -182,17 +195,20 @@ class FortranFarm:
     def counts(self):
         """Current molecule counts, shape (R, n_active)."""
         c = np.zeros((self.R, self.n_active), dtype=np.int32)
+        self._select()
         self.H.mfarm_get_counts(c.ctypes.data_as(_ip))
         return c
 
     def energy(self, replica: int):
         e = np.zeros(5)
+        self._select()
         self.H.mfarm_get_energy(C.c_int(replica), e.ctypes.data_as(_dp))
         return e
 
     def molecule(self, replica: int, ia: int, slot: int):
         com = np.zeros(3)
         off = np.zeros((self.max_n1, 3))
+        self._select()
         self.H.mfarm_get_molecule(C.c_int(replica), C.c_int(ia), C.c_int(slot), com.ctypes.data_as(_dp),
                                   off.ctypes.data_as(_dp))
         return com, off
@@ -210,7 +226,10 @@ class FortranFarm:
         return int(self.stats[2])
 
     def close(self):
-        if FortranFarm._live is self:
+        if FortranFarm._slots.get(getattr(self, "slot", -1)) is self:
+            self._select()
             self.H.mfarm_destroy()
-            FortranFarm._live = None
+            del FortranFarm._slots[self.slot]
+        if FortranFarm._live is self:
+            FortranFarm._live = next(iter(FortranFarm._slots.values()), None)
         self.eng.close()

@@ -51,5 +51,6 @@ def _close_leftover_farm():
     """A test that fails before farm.close() must not leave the process-wide Fortran farm occupied."""
     yield
     mod = sys.modules.get("maniac_mc_amd.fortran_host")
-    if mod is not None and mod.FortranFarm._live is not None:
-        mod.FortranFarm._live.close()
+    if mod is not None:
+        for farm in list(mod.FortranFarm._slots.values()):
+            farm.close()

@@ -256,3 +256,28 @@ def test_long_run_drift(gcmc, host_build):
     assert m, p.stdout
     worst_e, worst_a, big = (float(m.group(i)) for i in (1, 2, 3))
     assert worst_e < farm_tol([big], steps) and worst_a < 1e-9, p.stdout
+
+
+def test_two_farms_in_one_process():
+    """Farms are objects, not module state: two farms on two engines (different boxes) advance alternately in one
+    process and each keeps its own invariants."""
+    from maniac_mc_amd.fortran_host import FortranFarm
+    a = FortranFarm(synth.spce_box(5, seed=2), 6, seed=3, n_threads=2)
+    b = FortranFarm(synth.co2_box(20, seed=4), 5, seed=7, translation_step=1.0, rotation_step=0.6, n_threads=2, mol_capacity=[60],
+                    gcmc=dict(p_translation=0.25, p_rotation=0.25, fugacity=20.0 / 50.0 ** 3), device_build=True)
+    assert a.slot != b.slot
+    for _ in range(3):
+        a.run(15)
+        b.run(25)
+    assert a.trials + a.skipped == 6 * 45 and b.trials + b.skipped == 5 * 75
+    for farm, keys in ((a, ("non_coulomb", "coulomb", "recip_coulomb")),
+                       (b, ("non_coulomb", "coulomb", "recip_coulomb", "ewald_self", "intra_coulomb"))):
+        for r in range(farm.R):
+            e = farm.eng.system_energy(r)
+            run = farm.energy(r)
+            ref = np.array([e[k] for k in keys])
+            assert np.max(np.abs(run[: len(keys)] - ref)) < farm_tol(ref, 75), (r, run, ref)
+    b.close()
+    a.run(5)
+    assert a.trials + a.skipped == 6 * 50
+    a.close()
