@@ -1,5 +1,7 @@
 #!/bin/bash
-# round-3 measurement session on the final build: PMC passes (sha-tied), rocprofv3 kernel stats, bench lines
+# One measurement session on an MI355X box (run as: gpurun -- bash tools/measure_round.sh): GPU tests, PMC passes (tied to the
+# library hash), rocprofv3 kernel stats of the three workloads, the bench lines and the kernel-only timings that
+# profiles/rNN/ keeps.  Output under gpurun_out/r3final (traces are deleted at the end: 64 MiB merge limit).
 set -e -o pipefail
 out=gpurun_out/r3final
 mkdir -p $out
