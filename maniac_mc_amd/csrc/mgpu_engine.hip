@@ -84,11 +84,13 @@ struct Lane {
     int last_trial_n = 0, last_trial_stride = 0;   // shape of the site rows still resident in d_sites
     bool last_trial_built = false;                 // ... built on the device (rows carry the candidates' frames)
     int last_trial_frame = 0;                      // site index of the frame inside such a row
-    int n_pair_items = 0, n_split = 1;   // reduced pair-energy entries of the trial in flight (2 per fused item + 1 per single)
+    int n_pair_items = 0, n_partials = 0;   // reduced pair-energy entries of the trial in flight (2 per fused item + 1 per single) and its split partials
     int n_fused = 0;                      // fused (old + new) items of the trial in flight, all site-count classes together
     // reduced pair-energy entry i sums `n_split` partials starting at double ent_off[i] of the result block, ent_stride[i]
     // doubles apart (a fused item's partials are laid out [split][state], a single item's [split])
-    std::vector<int> ent_off, ent_stride;
+    std::vector<int> ent_off, ent_stride, ent_ns;     // ... ent_ns[i] of them
+    std::vector<char> ent_extra;          // entry i has an extra record (the framework part, pair_frozen_kernel) behind the energies
+    DevBuf d_scratch;                     // chunk partials of pair_frozen_kernel
     const RecipItem *d_trial_items = nullptr;   // RecipItems of the last trial, resident while last_trial_n != 0
     const RecipItem *h_trial_items = nullptr;   // their host image in h_in (valid until the next trial_submit)
     int trial_n1_max = 1;
@@ -115,6 +117,7 @@ struct Lane {
     void release() {
         if (commit_staged_ev) { (void)hipEventDestroy(commit_staged_ev); commit_staged_ev = nullptr; }
         d_items.release(); d_items2.release(); d_sites.release(); d_partials.release(); d_out.release(); d_prev.release();
+        d_scratch.release();
         h_in.release(); h_commit.release(); h_out.release();
     }
 };
@@ -175,6 +178,16 @@ struct mgpu_engine {
     std::vector<char> frozen;        // [n_res]
     bool any_frozen = false;
     int *d_atom_ty = nullptr;        // [Ncap] 0-based atom type of every slot (pair_flat_kernel fetches it per lane)
+    // A frozen framework is normally the SAME in every replica (a farm copies replica 0): frozen_ref[t] = the coordinates
+    // replica 0 was given (engine site order), frozen_same[r * n_res + t] = replica r holds exactly those, frozen_diff[t] =
+    // replicas that do not.  Where all agree, batched trials sweep the framework with pair_frozen_kernel (candidates in the
+    // lanes, the atoms scalar) -- MGPU_NO_FROZEN_BATCH=1 keeps pair_flat_kernel for it.
+    std::vector<std::vector<double>> frozen_ref;
+    std::vector<char> frozen_same;
+    std::vector<int> frozen_diff;
+    bool frozen_batch = true;
+    int frozen_chunk = 32;           // framework atoms per pair_frozen_kernel work unit (engine constant: the chunk partials are
+                                     // summed in order, so the chunking must not depend on the batch; MGPU_FROZEN_CHUNK, <= 64)
     // molecule frames (mgpu_replica_set_frames): com [R][3][n_mol_slots], off [R][3][Ncap]; allocated on first use
     double *d_com = nullptr, *d_off = nullptr;
     std::vector<char> frames_ok;     // [R][n_res]: the frames of (replica, type) mirror its sites
@@ -384,7 +397,7 @@ int resident_blocks(size_t dyn_lds) {
 // inter-kernel gap less per batch; d_lj / d_c are unused).
 int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, int common_n1, int site_stride,
                 int nsplit, double *d_lj, double *d_c, bool ordered = false, double2 *host_partials = nullptr,
-                bool fused = false, bool fast_fold = false) {
+                bool fused = false, bool fast_fold = false, bool skip_frozen = false) {
     const int n_work = n_items * nsplit;
     int rc = MGPU_OK;
     if (fused && (!host_partials || ordered || e->bx.triclinic || common_n1 < 1 || common_n1 > e->pair_fuse_max))
@@ -417,7 +430,7 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
         const int grid_f = std::max(1, std::min((n_work + kPairWaves - 1) / kPairWaves, e->n_cu * nb));               \
         hipExtLaunchKernelGGL((pair_flat_kernel<NS, FU, FW>), dim3(grid_f), dim3(kPairBlock), e->coul_bytes, ln.stream, a, b, 0, \
                               e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab,   \
-                              d_items, (const double *)ln.d_sites.p, site_stride, nsplit, n_work, d_part);                   \
+                              d_items, (const double *)ln.d_sites.p, site_stride, nsplit, n_work, d_part, skip_frozen ? 1 : 0); \
     } while (0)
 #define MGPU_LAUNCH_FLAT(NS, FU)                                                                                        \
     do {                                                                                                               \
@@ -477,6 +490,50 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
     if (!host_partials)
         hipLaunchKernelGGL(pair_finalize_kernel, dim3((n_items + 255) / 256), dim3(256), 0, ln.stream,
                            (const double2 *)ln.d_partials.p, n_items, nsplit, d_lj, d_c);
+    HIP_TRY(hipGetLastError());
+    return MGPU_OK;
+}
+
+// The framework part of a launch segment, candidates in the lanes (pair_frozen_kernel + frozen_finalize_kernel): items of
+// ONE residue type with n1 register sites; one extra record {e_lj, e_coul} per entry lands in d_extra.
+int launch_frozen(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, int n1, int site_stride, bool fused, bool fast_fold,
+                  int t_frozen, double2 *d_scratch, double2 *d_extra) {
+    const int n_atoms = e->h_nmol[t_frozen] * e->tp.n1[t_frozen];
+    const int n_chunks = (n_atoms + e->frozen_chunk - 1) / e->frozen_chunk;
+    if (n_chunks == 0 || n_items == 0) return MGPU_OK;
+    const int n_work = ((n_items + 63) / 64) * n_chunks;
+    const bool ff = fast_fold && e->pair_fast_fold;
+    hipEvent_t a = nullptr, b = nullptr;
+    int rc = prof_begin(e, ln, MGPU_KERNEL_PAIR, &a, &b);
+    if (rc) return rc;
+#define MGPU_LAUNCH_FROZEN_1(NS, FU, FW)                                                                                \
+    do {                                                                                                               \
+        const int nb = resident_blocks<&pair_frozen_kernel<NS, FU, FW>>(e->coul_bytes);                                \
+        const int grid_f = std::max(1, std::min((n_work + kPairWaves - 1) / kPairWaves, e->n_cu * nb));               \
+        hipExtLaunchKernelGGL((pair_frozen_kernel<NS, FU, FW>), dim3(grid_f), dim3(kPairBlock), e->coul_bytes, ln.stream, a, b, 0, \
+                              e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab,   \
+                              d_items, (const double *)ln.d_sites.p, site_stride, n_items, t_frozen, n_chunks, e->frozen_chunk, d_scratch); \
+    } while (0)
+#define MGPU_LAUNCH_FROZEN(NS)                                                                                          \
+    do {                                                                                                               \
+        if (fused && ff) MGPU_LAUNCH_FROZEN_1(NS, true, true);                                                         \
+        else if (fused) MGPU_LAUNCH_FROZEN_1(NS, true, false);                                                         \
+        else if (ff) MGPU_LAUNCH_FROZEN_1(NS, false, true);                                                            \
+        else MGPU_LAUNCH_FROZEN_1(NS, false, false);                                                                   \
+    } while (0)
+    switch (n1) {
+        case 1: MGPU_LAUNCH_FROZEN(1); break;
+        case 2: MGPU_LAUNCH_FROZEN(2); break;
+        case 3: MGPU_LAUNCH_FROZEN(3); break;
+        case 4: MGPU_LAUNCH_FROZEN(4); break;
+        default: MGPU_LAUNCH_FROZEN(5); break;
+    }
+#undef MGPU_LAUNCH_FROZEN
+#undef MGPU_LAUNCH_FROZEN_1
+    if ((rc = prof_end(e, ln, MGPU_KERNEL_PAIR, a, b))) return rc;
+    const int n_entries = n_items * (fused ? 2 : 1);
+    hipLaunchKernelGGL(frozen_finalize_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, ln.stream, (const double2 *)d_scratch, n_entries,
+                       n_chunks, d_extra);
     HIP_TRY(hipGetLastError());
     return MGPU_OK;
 }
@@ -720,6 +777,11 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     tp.n_mol_slots = 0;
     for (int t = 0; t < n_res; ++t) { tp.mol_off[t] = tp.n_mol_slots; tp.n_mol_slots += mol_capacity[t]; }
     e->frames_ok.assign((size_t)n_replicas * n_res, 0);
+    e->frozen_ref.assign(n_res, std::vector<double>());
+    e->frozen_same.assign((size_t)n_replicas * n_res, 0);
+    e->frozen_diff.assign(n_res, n_replicas);
+    e->frozen_batch = std::getenv("MGPU_NO_FROZEN_BATCH") == nullptr;
+    if (const char *ov = std::getenv("MGPU_FROZEN_CHUNK")) e->frozen_chunk = std::max(1, std::min(std::atoi(ov), 64));
     e->frames_tight.assign((size_t)n_replicas * n_res, 0);
     // Layout of the big inactive residues and the register-site pair kernel go together: "frozen" (sites sorted by
     // atom type, one group per type present) + pair_flat_kernel, or site-major + pair_sweep_kernel.  Default: flat
@@ -1035,6 +1097,22 @@ int mgpu_replica_set_molecules(mgpu_engine *e, int replica, int t, int n_mol, co
         HIP_TRY(hipMemcpy(e->d_pos + ((size_t)replica * 3 + d) * tp.n_cap_atoms + tp.seg_off[t], st + d * seg,
                           seg * sizeof(double), hipMemcpyHostToDevice));
     e->h_nmol[replica * tp.n_res + t] = n_mol;
+    if (e->frozen[t]) {
+        auto set_same = [&](int r, char v) {
+            char &f = e->frozen_same[(size_t)r * tp.n_res + t];
+            e->frozen_diff[t] += (f ? 1 : 0) - (v ? 1 : 0);
+            f = v;
+        };
+        if (replica == 0) {
+            e->frozen_ref[t].assign(st, st + 3 * seg);
+            for (int r = 1; r < e->n_replicas; ++r) set_same(r, 0);
+            set_same(0, 1);
+        } else {
+            const bool same = e->frozen_ref[t].size() == 3 * seg && n_mol == e->h_nmol[t] &&
+                              std::memcmp(e->frozen_ref[t].data(), st, 3 * seg * sizeof(double)) == 0;
+            set_same(replica, same ? 1 : 0);
+        }
+    }
     e->frames_ok[(size_t)replica * tp.n_res + t] = 0;       // sites given without com / offsets (set_frames sets it again)
     e->in_range[(size_t)replica * tp.n_res + t] = sites_in_range(e, sites, n_mol * n1) ? 1 : 0;
     HIP_TRY(hipMemcpy(e->d_nmol + replica * tp.n_res + t, &n_mol, sizeof(int), hipMemcpyHostToDevice));
@@ -1167,6 +1245,11 @@ int mgpu_replica_set_num_molecules(mgpu_engine *e, int replica, int t, int n_mol
     if (n_mol < 0 || n_mol > e->tp.cap[t]) return set_error(MGPU_ERR_CAPACITY, "n_mol exceeds mol_capacity");
     if ((rc = use_device(e))) return rc;
     if ((rc = sync_all_lanes(e))) return rc;
+    if (e->frozen[t]) {
+        char &f = e->frozen_same[(size_t)replica * e->tp.n_res + t];
+        e->frozen_diff[t] += f ? 1 : 0;
+        f = 0;
+    }
     // a larger count exposes slots the range flag was never computed for (zero-filled, or stale coordinates)
     if (n_mol > e->h_nmol[replica * e->tp.n_res + t]) e->in_range[(size_t)replica * e->tp.n_res + t] = 0;
     e->h_nmol[replica * e->tp.n_res + t] = n_mol;
@@ -1198,6 +1281,19 @@ int mgpu_replica_copy(mgpu_engine *e, int dst, int src) {
         e->h_nmol[dst * tp.n_res + t] = e->h_nmol[src * tp.n_res + t];
         e->in_range[(size_t)dst * tp.n_res + t] = e->in_range[(size_t)src * tp.n_res + t];
         e->frames_ok[(size_t)dst * tp.n_res + t] = e->frames_ok[(size_t)src * tp.n_res + t];
+        if (e->frozen[t]) {
+            // a copy of replica 0 (or of a replica equal to it) equals replica 0; overwriting replica 0 itself loses the reference
+            const char v = dst == 0 ? 0 : e->frozen_same[(size_t)src * tp.n_res + t];
+            char &f = e->frozen_same[(size_t)dst * tp.n_res + t];
+            e->frozen_diff[t] += (f ? 1 : 0) - (v ? 1 : 0);
+            f = v;
+            if (dst == 0)
+                for (int r = 1; r < e->n_replicas; ++r) {
+                    char &g = e->frozen_same[(size_t)r * tp.n_res + t];
+                    e->frozen_diff[t] += g ? 1 : 0;
+                    g = 0;
+                }
+        }
         e->frames_tight[(size_t)dst * tp.n_res + t] = e->frames_tight[(size_t)src * tp.n_res + t];
     }
     return sync_stream(e);
@@ -1465,57 +1561,76 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     ln.kinds.assign(n, MGPU_MOVE);
     ln.self_of.assign(n, 0.0);
     int n1_max = 1, n_intra = 0;
-    // Candidates are grouped by the site count of their residue type: every class gets its own pair-sweep launches with
-    // the register-site kernels of that size (a mixture of a 3-site and a 2-site species used to fall to the generic
-    // NS = 0 sweep for the whole launch).  Within a class, trial moves of molecules with a few sites are swept old + new
-    // together (fused items, two entries each); insertions, deletions and everything else are single-state items.
-    struct Seg { int n1, fused, first_item, n_items, first_entry; };
-    int cls_n1[kMaxRes], cls_moves[kMaxRes], cls_single[kMaxRes], n_cls = 0;
+    // Candidates are grouped by residue type: every type gets its own pair-sweep launches with the register-site kernels
+    // of its size (a mixture of a 3-site and a 2-site species used to fall to the generic NS = 0 sweep for the whole
+    // launch), and which kernels a type's candidates take never depends on what else shares the launch.  Within a type,
+    // trial moves of molecules with a few sites are swept old + new together (fused items, two entries each);
+    // insertions, deletions and everything else are single-state items.
+    struct Seg { int n1, fused, first_item, n_items, first_entry, type, nsplit, first_partial; };
+    int cls_n1[kMaxRes], cls_moves[kMaxRes], cls_single[kMaxRes], cls_type[kMaxRes], n_cls = 0;
     for (int c = 0; c < n; ++c) {
         const int k = kind ? kind[c] : MGPU_MOVE;
         if (k < MGPU_MOVE || k > MGPU_DELETION) return set_error(MGPU_ERR_INVALID_ARG, "trial_submit: unknown candidate kind");
         if (t[c] < 0 || t[c] >= e->tp.n_res) return set_error(MGPU_ERR_INVALID_ARG, "trial_submit: residue type out of range");
         const int n1 = e->tp.n1[t[c]];
         int ci = 0;
-        while (ci < n_cls && cls_n1[ci] != n1) ++ci;
-        if (ci == n_cls) { cls_n1[ci] = n1; cls_moves[ci] = 0; cls_single[ci] = 0; ++n_cls; }     // <= n_res distinct values
+        while (ci < n_cls && cls_type[ci] != t[c]) ++ci;
+        if (ci == n_cls) { cls_n1[ci] = n1; cls_moves[ci] = 0; cls_single[ci] = 0; cls_type[ci] = t[c]; ++n_cls; }   // <= n_res classes
         const bool fz = k == MGPU_MOVE && e->pair_fuse && !e->bx.triclinic && n1 <= e->pair_fuse_max;
         if (fz) cls_moves[ci] += 1;
         else cls_single[ci] += (k == MGPU_MOVE) ? 2 : 1;
     }
+    // Framework boxes: one frozen residue type, identical in every replica, flat kernels in use, an active residue type of
+    // <= 5 sites -> the type's items go to pair_frozen_kernel (candidates in the lanes; framework atoms as scalars, then the
+    // replica's few other atoms per lane); their sums arrive as ONE extra record per entry behind the other results
+    int t_frozen = -1;
+    if (e->pair_flat && e->frozen_batch && !e->bx.triclinic) {
+        int nf = 0;
+        for (int tt = 0; tt < e->tp.n_res; ++tt)
+            if (e->frozen[tt]) { ++nf; t_frozen = tt; }
+        if (nf != 1 || e->frozen_diff[t_frozen] != 0 || e->h_nmol[t_frozen] < 1) t_frozen = -1;
+    }
+    auto type_batched = [&](int ty, int n1) { return t_frozen >= 0 && ty != t_frozen && n1 <= kMaxFusedSitesWide; };
+    const int n_chunks_f = t_frozen >= 0 ? (e->h_nmol[t_frozen] * e->tp.n1[t_frozen] + e->frozen_chunk - 1) / e->frozen_chunk : 0;
+    const int nsplit_engine = e->pair_nsplit;
     std::vector<Seg> segs;
     int seg_fused[kMaxRes], seg_single[kMaxRes];        // per class: index of its fused / single segment (-1: none)
-    int n_items_total = 0, n_pair = 0, n_fused = 0;
+    int n_items_total = 0, n_pair = 0, n_fused = 0, n_partials = 0;
     for (int ci = 0; ci < n_cls; ++ci) {
         seg_fused[ci] = seg_single[ci] = -1;
+        const int ns_seg = type_batched(cls_type[ci], cls_n1[ci]) ? 0 : nsplit_engine;      // batched: the extra record is all
         if (cls_moves[ci]) {
             seg_fused[ci] = (int)segs.size();
-            segs.push_back(Seg{cls_n1[ci], 1, n_items_total, 0, n_pair});
+            segs.push_back(Seg{cls_n1[ci], 1, n_items_total, 0, n_pair, cls_type[ci], ns_seg, n_partials});
             n_items_total += cls_moves[ci];
             n_pair += 2 * cls_moves[ci];
+            n_partials += 2 * cls_moves[ci] * ns_seg;
             n_fused += cls_moves[ci];
         }
         if (cls_single[ci]) {
             seg_single[ci] = (int)segs.size();
-            segs.push_back(Seg{cls_n1[ci], 0, n_items_total, 0, n_pair});
+            segs.push_back(Seg{cls_n1[ci], 0, n_items_total, 0, n_pair, cls_type[ci], ns_seg, n_partials});
             n_items_total += cls_single[ci];
             n_pair += cls_single[ci];
+            n_partials += cls_single[ci] * ns_seg;
         }
     }
-    const int nsplit = e->pair_nsplit;
     ln.ent_off.assign(n_pair, 0);
     ln.ent_stride.assign(n_pair, 2);
+    ln.ent_ns.assign(n_pair, 1);
     auto add_item = [&](Seg &sg, const PairItem &it) {     // returns the item's first entry
         const int i = sg.n_items++;
         pit[sg.first_item + i] = it;
         const int e0 = sg.first_entry + (sg.fused ? 2 * i : i);
-        // partial records (double2) of the segment start at first_entry * nsplit; [split][state] for fused items
+        // partial records (double2) of the segment start at first_partial; [split][state] for fused items
         if (sg.fused) {
-            ln.ent_off[e0] = 2 * ((sg.first_entry + 2 * i) * nsplit);
+            ln.ent_off[e0] = 2 * (sg.first_partial + 2 * i * sg.nsplit);
             ln.ent_off[e0 + 1] = ln.ent_off[e0] + 2;
             ln.ent_stride[e0] = ln.ent_stride[e0 + 1] = 4;
+            ln.ent_ns[e0] = ln.ent_ns[e0 + 1] = sg.nsplit;
         } else {
-            ln.ent_off[e0] = 2 * ((sg.first_entry + i) * nsplit);
+            ln.ent_off[e0] = 2 * (sg.first_partial + i * sg.nsplit);
+            ln.ent_ns[e0] = sg.nsplit;
         }
         return e0;
     };
@@ -1529,7 +1644,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
         if (n1 > site_stride) return set_error(MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res");
         n1_max = std::max(n1_max, n1);
         int ci = 0;
-        while (cls_n1[ci] != n1) ++ci;
+        while (cls_type[ci] != t[c]) ++ci;
         ln.kinds[c] = k;
         fast = fast && replica_in_range(e, replica[c]);
         if (build) {
@@ -1571,7 +1686,18 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     const size_t iit_bytes = (size_t)n_intra * sizeof(PairItem);
     // results in device memory, copied out once: [split partials of the pair sweep (n_pair * nsplit complex-sized
     // records, reduced on the host in trial_wait) | u_old | u_new | intra]
-    const size_t out_doubles = 2 * (size_t)n_pair * nsplit + 3 * (size_t)n;
+    auto seg_batched = [&](const Seg &sg) { return type_batched(sg.type, sg.n1); };
+    ln.ent_extra.assign(n_pair, 0);
+    size_t scratch_records = 0;
+    for (const Seg &sg : segs)
+        if (seg_batched(sg)) {
+            const int ne = sg.n_items * (sg.fused ? 2 : 1);
+            for (int i = 0; i < ne; ++i) ln.ent_extra[sg.first_entry + i] = 1;
+            scratch_records += (size_t)ne * n_chunks_f;
+        }
+    const size_t extra_at = 2 * (size_t)n_partials + 3 * (size_t)n;          // doubles
+    const size_t out_doubles = extra_at + (scratch_records ? 2 * (size_t)n_pair : 0);
+    if (scratch_records && (rc = ln.d_scratch.reserve(scratch_records * sizeof(double2)))) return rc;
     // A deferred commit of this lane rides in this trial's k sweep when every new candidate sits on its own replica
     // and the row-form kernel applies; otherwise it is launched on its own first.
     bool fused_k = false;
@@ -1632,7 +1758,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     const PairItem *d_iit = (const PairItem *)((char *)ln.d_sites.p + site_bytes + pit_cap + rit_bytes);
     const int *d_pend_idx = (const int *)((const char *)d_iit + iit_bytes);
     double2 *d_part = (double2 *)ln.d_out.p;
-    double *d_uo = (double *)ln.d_out.p + 2 * (size_t)n_pair * nsplit, *d_un = d_uo + n, *d_in = d_un + n;
+    double *d_uo = (double *)ln.d_out.p + 2 * (size_t)n_partials, *d_un = d_uo + n, *d_in = d_un + n;
     // Kernel order.  With a deferred commit: [commit + k sweep] first (the pair sweep and the intra kernel must see
     // the committed coordinates), then the pair sweep.  Without: pair sweep first, k sweep second (the order the
     // stand-alone commit of the other lane overlaps best with; k sweep first was measured 10 % slower there).
@@ -1641,10 +1767,19 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
             return rc;
         ln.deferred.active = false;
     }
-    for (const Seg &sg : segs)
-        if ((rc = launch_pair(e, ln, d_pit + sg.first_item, sg.n_items, sg.n1, site_stride, nsplit, nullptr, nullptr, false,
-                              d_part + (size_t)sg.first_entry * nsplit, sg.fused != 0, fast)))
+    size_t scratch_at = 0;
+    for (const Seg &sg : segs) {
+        const bool fb = seg_batched(sg);
+        if (!fb && (rc = launch_pair(e, ln, d_pit + sg.first_item, sg.n_items, sg.n1, site_stride, sg.nsplit, nullptr, nullptr, false,
+                                     d_part + sg.first_partial, sg.fused != 0, fast)))
             return rc;
+        if (fb) {
+            if ((rc = launch_frozen(e, ln, d_pit + sg.first_item, sg.n_items, sg.n1, site_stride, sg.fused != 0, fast, t_frozen,
+                                    (double2 *)ln.d_scratch.p + scratch_at, (double2 *)((double *)ln.d_out.p + extra_at) + sg.first_entry)))
+                return rc;
+            scratch_at += (size_t)sg.n_items * (sg.fused ? 2 : 1) * n_chunks_f;
+        }
+    }
     if (!fused_k && (rc = launch_recip(e, ln, d_rit, n, n1_max, site_stride, false, e->d_A, d_un, d_uo)))
         return rc;
     if (n_intra) {
@@ -1656,7 +1791,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     ln.n_submitted = n;
     ln.n_pair_items = n_pair;
     ln.n_fused = n_fused;
-    ln.n_split = nsplit;
+    ln.n_partials = n_partials;
     ln.last_trial_n = n;
     ln.last_trial_stride = site_stride;
     ln.last_trial_built = build != nullptr;
@@ -1674,9 +1809,9 @@ static int trial_wait_impl(mgpu_engine *e, Lane &ln, double *old_energy, double 
     ln.n_submitted = 0;
     int rc = sync_lane(e, ln);
     if (rc) return rc;
-    const int np = ln.n_pair_items, ns = ln.n_split;
+    const int np = ln.n_pair_items;
     const double *h = (const double *)ln.h_out.p;
-    const double *uo = h + 2 * (size_t)np * ns, *un = uo + n, *in = un + n;
+    const double *uo = h + 2 * (size_t)ln.n_partials, *un = uo + n, *in = un + n, *ex = in + n;
     // the ordered sum of the split partials and the Coulomb rescale e_coulomb * EPS0_INV_eVA / KB_eVK
     // (energy_utils.f90:440), exactly as pair_finalize_kernel does them.  Partials of a fused item are laid out
     // [split][state], those of a single item [split].
@@ -1685,8 +1820,9 @@ static int trial_wait_impl(mgpu_engine *e, Lane &ln, double *old_energy, double 
     for (int i = 0; i < np; ++i) {
         double a = 0.0, b = 0.0;
         const double *p = h + ln.ent_off[i];
-        const int stride = ln.ent_stride[i];
+        const int stride = ln.ent_stride[i], ns = ln.ent_ns[i];
         for (int s2 = 0; s2 < ns; ++s2) { a += p[stride * s2]; b += p[stride * s2 + 1]; }
+        if (ln.ent_extra[i]) { a += ex[2 * i]; b += ex[2 * i + 1]; }       // the framework part (pair_frozen_kernel), last
         ln.h_lj[i] = a;
         ln.h_cc[i] = b * kEps0InvEvA / kKbEvK;
     }

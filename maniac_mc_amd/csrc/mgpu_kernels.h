@@ -564,7 +564,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
     Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
     const char *__restrict__ coul_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
-    int site_stride, int nsplit, int n_work, double2 *__restrict__ partials) {
+    int site_stride, int nsplit, int n_work, double2 *__restrict__ partials, int skip_frozen) {
     static_assert(NS > 0, "register sites only");
     constexpr int NTY = NS;
     constexpr int NST = FUSED ? 2 : 1;
@@ -652,7 +652,9 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                         const int m2 = nm2 == 1 ? 0 : pl / ng;
                         const int4 gr = s_grp[tp.grp_off[i] + (pl - m2 * ng)];
                         e_off = tp.seg_off[i] + m2 * tp.n1[i] + gr.x;
-                        e_cnt = (same_t && m2 == it.m) ? 0 : gr.y;      // an inactive molecule evaluated itself: skipped whole
+                        // an inactive molecule evaluated itself is skipped whole; skip_frozen: the frameworks are swept by
+                        // pair_frozen_kernel (candidates in the lanes) in the same launch group
+                        e_cnt = ((same_t && m2 == it.m) || skip_frozen) ? 0 : gr.y;
                         e_flags = 0;
                     } else {
                         e_off = tp.seg_off[i] + pl * tp.cap[i];
@@ -790,6 +792,235 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
             if (lane == 0) partials[(size_t)w * NST + st] = make_double2(a, b);
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Frameworks, transposed: the CANDIDATES sit in the lanes.  An inactive framework is the same in every replica of a
+// farm (the engine verifies it on upload), so a wave takes 64 items of one residue type and ONE chunk of 64 framework
+// atoms (chunk_atoms <= 64, an engine constant): each lane loads one atom of the chunk (coalesced), the wave then walks them with v_readlane -- atom
+// coordinates, charge and type are SCALARS -- against the lane's own NREG candidate sites in registers.  No masks, no
+// tails, no per-unit bookkeeping, no cross-lane reduction: per (site, atom) term just the distance, the table and the
+// accumulate.  The (4 epsilon,
+// sigma^2) of the candidate's sites against the atom's type are reloaded (LDS broadcast) only when the type changes: the
+// frozen layout keeps atoms of one type together.  The few OTHER atoms of a framework box (the adsorbates of each lane's
+// own replica) follow in the same wave with per-lane coordinates, so one kernel yields the item's whole pair energy.
+// Work = (item group, chunk); every (item, chunk) writes one partial
+// {e_lj, e_coul} per state into `scratch`, and frozen_finalize_kernel adds a item's chunks in order -- one extra record
+// per entry for the host's ordered sum.  Items: PairItem of ONE residue type (the engine checks), unordered, orthorhombic.
+// ------------------------------------------------------------------------------------------
+template <int NS, bool FUSED, bool FASTW>
+__global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MGPU_PAIR_MINWAVES) void pair_frozen_kernel(
+    Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
+    const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
+    const char *__restrict__ coul_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
+    int site_stride, int n_items, int t_frozen, int n_chunks, int chunk_atoms, double2 *__restrict__ scratch) {
+    constexpr int NTY = NS;
+    constexpr int NST = FUSED ? 2 : 1;
+    constexpr int NREG = NTY * NST;
+    extern __shared__ __attribute__((aligned(16))) char s_coul[];     // (coul_last_row + 1) x 48 B
+    __shared__ double2 s_pair[kMaxTypes * kMaxTypes];
+    for (int i = threadIdx.x; i < (bx.coul_last_row + 1) * 3; i += kPairBlock)
+        reinterpret_cast<double2 *>(s_coul)[i] = reinterpret_cast<const double2 *>(coul_tab_g)[i];
+    const int nt = tp.n_types;
+    for (int i = threadIdx.x; i < nt * nt; i += kPairBlock) s_pair[i] = pair_tab[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_groups = (n_items + 63) >> 6;
+    const int n_work = n_groups * n_chunks;
+    const int n_waves = gridDim.x * kPairWaves;
+    // the framework's atoms: every molecule of the frozen type of replica 0 (identical in all replicas)
+    const int n_atoms = nmol[t_frozen] * tp.n1[t_frozen];
+    const double *fx = pos + tp.seg_off[t_frozen], *fy = fx + tp.n_cap_atoms, *fz = fy + tp.n_cap_atoms;
+    const double *fq = tp.slot_q + tp.seg_off[t_frozen];
+    const int *fty = tp.slot_ty + tp.seg_off[t_frozen];
+
+    for (int w = blockIdx.x * kPairWaves + wave; w < n_work; w += n_waves) {
+        const int grp = w / n_chunks, chunk = w - grp * n_chunks;
+        const int item_id = grp * 64 + lane;
+        const bool live = item_id < n_items;
+        const PairItem it = items[live ? item_id : n_items - 1];
+        const double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
+        const double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
+        // the lane's own candidate: both states' sites (per-lane gathers), charges / types of its residue type (uniform)
+        double rx[NREG], ry[NREG], rz[NREG], rq[NTY];
+        int rty[NTY];
+#pragma unroll
+        for (int a = 0; a < NTY; ++a) {
+            if constexpr (FUSED) {
+                const int j = atom_slot(tp, it.t, it.m, a);
+                rx[a] = px[j]; ry[a] = py[j]; rz[a] = pz[j];
+                const double *c = cand_sites + ((size_t)it.src * site_stride + a) * 3;
+                rx[NTY + a] = c[0]; ry[NTY + a] = c[1]; rz[NTY + a] = c[2];
+            } else if (it.src < 0) {
+                const int j = atom_slot(tp, it.t, it.m, a);
+                rx[a] = px[j]; ry[a] = py[j]; rz[a] = pz[j];
+            } else {
+                const double *c = cand_sites + ((size_t)it.src * site_stride + a) * 3;
+                rx[a] = c[0]; ry[a] = c[1]; rz[a] = c[2];
+            }
+        }
+        const int t_item = __builtin_amdgcn_readfirstlane(it.t);          // one residue type per launch
+        bool any_c = false;
+#pragma unroll
+        for (int s = 0; s < NTY; ++s) {
+            rq[s] = res_q[t_item * tp.max_atom + s];
+            rty[s] = res_atype[t_item * tp.max_atom + s] * nt;
+            const bool on = fabs(rq[s]) >= kErrorTol;                     // energy_utils.f90:430
+            any_c = any_c || on;
+            rq[s] = on ? rq[s] : 0.0;
+        }
+        // this chunk's atoms: one per lane
+        const int a0 = chunk * chunk_atoms, na = min(chunk_atoms, n_atoms - a0);        // chunk_atoms <= 64
+        const int ja = a0 + (lane < na ? lane : 0);
+        const double ax = fx[ja], ay = fy[ja], az = fz[ja];
+        double aq = fq[ja];
+        aq = fabs(aq) >= kErrorTol ? aq : 0.0;
+        const int aty = fty[ja];
+
+        double acc[NREG], elj[NST];
+#pragma unroll
+        for (int s = 0; s < NREG; ++s) acc[s] = 0.0;
+#pragma unroll
+        for (int st = 0; st < NST; ++st) elj[st] = 0.0;
+        int cur_ty = -1;
+        double e4[NTY], sg2[NTY];
+        bool lj_on[NTY];
+#pragma unroll
+        for (int s = 0; s < NTY; ++s) { e4[s] = 0.0; sg2[s] = 0.0; lj_on[s] = false; }
+        for (int k = 0; k < na; ++k) {
+            const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ax), k), __builtin_amdgcn_readlane(__double2loint(ax), k));
+            const double yj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ay), k), __builtin_amdgcn_readlane(__double2loint(ay), k));
+            const double zj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(az), k), __builtin_amdgcn_readlane(__double2loint(az), k));
+            const double qj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(aq), k), __builtin_amdgcn_readlane(__double2loint(aq), k));
+            const int tyj = __builtin_amdgcn_readlane(aty, k);
+            if (tyj != cur_ty) {                                            // rare: the atoms are sorted by type
+                cur_ty = tyj;
+#pragma unroll
+                for (int s = 0; s < NTY; ++s) {
+                    const double2 pt = s_pair[rty[s] + tyj];                // LDS broadcast read
+                    e4[s] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(pt.x)), __builtin_amdgcn_readfirstlane(__double2loint(pt.x)));
+                    sg2[s] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(pt.y)), __builtin_amdgcn_readfirstlane(__double2loint(pt.y)));
+                    lj_on[s] = e4[s] != 0.0;                               // epsilon = 0 contributes 0
+                }
+            }
+            double r2[NREG];
+#pragma unroll
+            for (int s = 0; s < NREG; ++s)
+                r2[s] = FASTW ? image_r2_fast(xj - rx[s], yj - ry[s], zj - rz[s], bx)
+                              : image_r2<false>(xj - rx[s], yj - ry[s], zj - rz[s], bx);
+            if (any_c && qj != 0.0) {
+                double g[NREG];
+                bool any_below = false;
+#pragma unroll
+                for (int s = 0; s < NREG; ++s) {
+                    bool below;
+                    g[s] = coul_lds(r2[s], s_coul, bx.coul_idx_base, bx.coul_last_row, below);
+                    any_below = any_below || below;
+                }
+                if (any_below) {   // r < 0.5 A for some lane: rare slow path
+#pragma unroll
+                    for (int s = 0; s < NREG; ++s)
+                        if (r2[s] < 0.25) g[s] = coul_slow(r2[s], bx.alpha, false);
+                }
+#pragma unroll
+                for (int s = 0; s < NREG; ++s) acc[s] = fma(qj, g[s], acc[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < NTY; ++s) {
+                if (!lj_on[s]) continue;
+#pragma unroll
+                for (int st = 0; st < NST; ++st) {
+                    const double rr = r2[st * NTY + s];
+                    const double s2 = sg2[s] * fast_rcp(rr);
+                    const double s6 = s2 * s2 * s2;
+                    const double e = e4[s] * fma(s6, s6, -s6);                     // energy_utils.f90:421-423
+                    elj[st] += (rr < bx.rc2) ? e : 0.0;                            // energy_utils.f90:417
+                }
+            }
+        }
+        // ---- everything else in the lanes' replicas: the molecules of the plane-major (active) residue types, dealt over
+        //      the group's chunk waves (molecule m2 = chunk, chunk + n_chunks, ...).  Coordinates are per lane here (every
+        //      lane has its own replica: 64 separate 8-byte gathers per load, affordable for the few dozen adsorbate atoms of
+        //      a framework box); charge, type and LJ pair are uniform per (type, site).  Masked lanes (no such molecule in
+        //      their replica, or the candidate itself) are removed by selects, never by a zero weight: their slot may hold
+        //      anything.
+        for (int t2 = 0; t2 < tp.n_res; ++t2) {
+            if (tp.site_major[t2] != 0) continue;
+            const int nm_l = live ? nmol[it.replica * tp.n_res + t2] : 0;
+            int nm_max = nm_l;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) nm_max = max(nm_max, __shfl_xor(nm_max, off, 64));
+            nm_max = __builtin_amdgcn_readfirstlane(nm_max);
+            const int n2 = tp.n1[t2], cap2 = tp.cap[t2], seg2 = tp.seg_off[t2];
+            const bool same_t = t2 == t_item;
+            for (int m2 = chunk; m2 < nm_max; m2 += n_chunks) {
+                const bool ok = m2 < nm_l && !(same_t && m2 == it.m);
+                for (int a2 = 0; a2 < n2; ++a2) {
+                    double qj = res_q[t2 * tp.max_atom + a2];                       // scalar
+                    qj = fabs(qj) >= kErrorTol ? qj : 0.0;
+                    const int tyj = res_atype[t2 * tp.max_atom + a2];
+                    const int j = seg2 + a2 * cap2 + (ok ? m2 : 0);
+                    const double xj = px[j], yj = py[j], zj = pz[j];
+                    double r2[NREG];
+#pragma unroll
+                    for (int s = 0; s < NREG; ++s)
+                        r2[s] = FASTW ? image_r2_fast(xj - rx[s], yj - ry[s], zj - rz[s], bx)
+                                      : image_r2<false>(xj - rx[s], yj - ry[s], zj - rz[s], bx);
+                    if (any_c && qj != 0.0) {
+                        double g[NREG];
+                        bool any_below = false;
+#pragma unroll
+                        for (int s = 0; s < NREG; ++s) {
+                            bool below;
+                            g[s] = coul_lds(r2[s], s_coul, bx.coul_idx_base, bx.coul_last_row, below);
+                            any_below = any_below || (below && ok);
+                        }
+                        if (any_below) {
+#pragma unroll
+                            for (int s = 0; s < NREG; ++s)
+                                if (ok && r2[s] < 0.25) g[s] = coul_slow(r2[s], bx.alpha, false);
+                        }
+#pragma unroll
+                        for (int s = 0; s < NREG; ++s) acc[s] = ok ? fma(qj, g[s], acc[s]) : acc[s];
+                    }
+#pragma unroll
+                    for (int s = 0; s < NTY; ++s) {
+                        const double2 pt = pair_tab[rty[s] + tyj];                  // scalar load
+                        if (pt.x == 0.0) continue;                                  // epsilon = 0 contributes 0
+#pragma unroll
+                        for (int st = 0; st < NST; ++st) {
+                            const double rr = r2[st * NTY + s];
+                            const double s2 = pt.y * fast_rcp(rr);
+                            const double s6 = s2 * s2 * s2;
+                            const double e = pt.x * fma(s6, s6, -s6);              // energy_utils.f90:421-423
+                            elj[st] += (ok && rr < bx.rc2) ? e : 0.0;              // energy_utils.f90:417
+                        }
+                    }
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                double ec = 0.0;
+#pragma unroll
+                for (int s = 0; s < NTY; ++s) ec = fma(rq[s], acc[st * NTY + s], ec);
+                scratch[((size_t)item_id * NST + st) * n_chunks + chunk] = make_double2(elj[st], ec);
+            }
+        }
+    }
+}
+
+// ordered sum of an entry's chunk partials (pair_frozen_kernel) into its extra record
+__global__ void frozen_finalize_kernel(const double2 *__restrict__ scratch, int n_entries, int n_chunks, double2 *__restrict__ extra) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_entries) return;
+    double a = 0.0, b = 0.0;
+    for (int c = 0; c < n_chunks; ++c) { const double2 p = scratch[(size_t)i * n_chunks + c]; a += p.x; b += p.y; }
+    extra[i] = make_double2(a, b);
 }
 
 // Ordered sum of the split partials; Coulomb rescale e_coulomb * EPS0_INV_eVA / KB_eVK

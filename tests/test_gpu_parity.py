@@ -652,3 +652,82 @@ def test_flat_and_plane_by_plane_sweeps_agree(make, refcpu_mod):
                 close(e_res[1][c, :3], en, "new")
     for e in engines:
         e.close()
+
+
+@pytest.mark.parametrize("three_site", [False, True], ids=["water4_single_state", "adsorbate3_fused"])
+def test_framework_batch_kernel_matches_the_flat_sweep(three_site, refcpu_mod):
+    """Batched trials in a framework box sweep the framework with pair_frozen_kernel (the candidates in the lanes, the
+    framework atoms as scalars; valid because the inactive framework is the same in every replica) and everything else
+    with pair_flat_kernel.  MGPU_NO_FROZEN_BATCH=1 leaves the framework to pair_flat_kernel: both engines must agree to
+    the parity bar, and the moves with the C restatement.  three_site: a 3-site adsorbate, whose moves take the fused
+    (old + new) instantiations; otherwise the 4-site water (single-state items).  A replica whose framework differs
+    from replica 0's switches the batch kernel off for the engine (checked through identical results again)."""
+    import os
+    from maniac_mc_amd.system import System, Topology
+    s = synth.framework_water_box(n_water=20, n_frame=300, L=24.0, seed=5)
+    if three_site:
+        tp = s.topo
+        at = tp.atom_types.copy(); q = tp.charges.copy()
+        at[1, :] = 0; q[1, :] = 0.0
+        at[1, :3] = [8, 9, 9]; q[1, :3] = [-0.8476, 0.4238, 0.4238]
+        topo = Topology([300, 3], at, q, tp.is_active, tp.epsilon, tp.sigma)
+        s = System(topo, s.box_matrix, s.bounds_lo, s.real_space_cutoff, s.ewald_tolerance, s.temperature,
+                   [s.com[0], s.com[1]], [s.offsets[0], s.offsets[1][:, :3, :]])
+    n1 = int(s.topo.atoms_in_res[1])
+    engines = []
+    for nobatch in (False, True):
+        if nobatch:
+            os.environ["MGPU_NO_FROZEN_BATCH"] = "1"
+        try:
+            e = Engine.from_system(s, n_replicas=3)
+        finally:
+            os.environ.pop("MGPU_NO_FROZEN_BATCH", None)
+        for r in range(3):
+            e.init_structure_factor(r, True)
+        engines.append(e)
+    rng = np.random.default_rng(9)
+    L = np.diag(s.box_matrix)
+    n = int(s.n_mol[1])
+    k = 18
+    m = rng.integers(0, n, k).astype(np.int32)
+    base = s.all_sites(1)
+    cand = base[m] + rng.uniform(-0.4, 0.4, (k, 1, 3))
+    kinds = np.array([MGPU_MOVE, MGPU_CREATION, MGPU_DELETION] * 6, dtype=np.int32)
+    cr = kinds == MGPU_CREATION
+    cand[cr] = base[m[cr]] - base[m[cr]].mean(axis=1, keepdims=True) + (s.bounds_lo + L * rng.uniform(0.05, 0.95, (int(cr.sum()), 3)))[:, None, :]
+    rep = ((np.arange(k) // 3) % 3).astype(np.int32)           # every kind on every replica
+    tt = np.ones(k, np.int32)
+
+    def same(a, b):
+        fin = np.isfinite(a) & np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), np.isfinite(b))
+        assert np.all(np.abs(a[fin] - b[fin]) <= np.maximum(TOL_K, 16 * np.finfo(float).eps * np.abs(a[fin]))), np.max(np.abs(a[fin] - b[fin]))
+
+    res = [e.gcmc_trial(rep, tt, m, kinds, cand) for e in engines]
+    same(res[0][0], res[1][0]); same(res[0][1], res[1][1])
+    P = refcpu_mod.RefCPU(s)
+    P.system_energy()
+    P.init_amplitude(True)
+    for c in np.flatnonzero(kinds == MGPU_MOVE):
+        com, off = P.get_molecule(1, int(m[c]))
+        P.save_fourier(1, int(m[c]))
+        eo = P.old_energy(1, int(m[c]), 0)[:3]
+        P.set_molecule(1, int(m[c]), cand[c, 0], cand[c] - cand[c, 0][None, :])
+        en = P.new_energy(1, int(m[c]), 0)[:3]
+        P.set_molecule(1, int(m[c]), com, off)
+        P.restore_fourier(1, int(m[c]))
+        for r_ in res:
+            close(r_[0][c, :3], eo, "old")
+            close(r_[1][c, :3], en, "new")
+    # a replica with ANOTHER framework: the engine must leave the batch kernel (results still those of the flat sweep)
+    frame2 = s.all_sites(0).copy()
+    frame2[0, 5] += 0.05
+    for e in engines:
+        e.set_molecules(2, 0, frame2)
+        e.init_structure_factor(2, True)
+    res2 = [e.gcmc_trial(rep, tt, m, kinds, cand) for e in engines]
+    same(res2[0][0], res2[1][0]); same(res2[0][1], res2[1][1])
+    on2 = rep == 2
+    assert np.max(np.abs(res2[0][1][on2 & (kinds != MGPU_DELETION)] - res[0][1][on2 & (kinds != MGPU_DELETION)])) > 0    # the moved atom is felt
+    for e in engines:
+        e.close()
