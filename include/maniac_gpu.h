@@ -54,6 +54,11 @@ extern "C" {
  *                               at most 1024 molecule slots -- or a frozen framework, orthorhombic boxes)
  *   MGPU_NO_FROZEN=1            inactive residues of >= 64 atoms stay site-major in the caller's site order (default:
  *                               "frozen" layout, sites sorted by atom type, swept by pair_flat_kernel)
+ *   MGPU_NO_FROZEN_BATCH=1      framework boxes keep one wave per candidate (pair_flat_kernel) instead of 64 candidates
+ *                               per wave against chunks of the framework (pair_frozen_kernel; default where exactly one
+ *                               frozen residue type exists and it is identical in every replica)
+ *   MGPU_FROZEN_CHUNK=<n>       framework atoms per pair_frozen_kernel chunk, 1..64 (engine constant, default 32; the
+ *                               chunk partials are summed in chunk order, so results are reproducible per value)
  *   MGPU_PAIR_FUSE_MAX=<n>      largest molecule whose trial moves sweep old + new state in one pass (default 3; 4 and
  *                               5 select kernels of up to 256 VGPRs at half the occupancy: measured slower)
  *   MGPU_DEFER_COMMIT=1         a commit from a lane's resident rows is not launched but folded into the lane's

@@ -657,8 +657,8 @@ def test_flat_and_plane_by_plane_sweeps_agree(make, refcpu_mod):
 @pytest.mark.parametrize("three_site", [False, True], ids=["water4_single_state", "adsorbate3_fused"])
 def test_framework_batch_kernel_matches_the_flat_sweep(three_site, refcpu_mod):
     """Batched trials in a framework box sweep the framework with pair_frozen_kernel (the candidates in the lanes, the
-    framework atoms as scalars; valid because the inactive framework is the same in every replica) and everything else
-    with pair_flat_kernel.  MGPU_NO_FROZEN_BATCH=1 leaves the framework to pair_flat_kernel: both engines must agree to
+    framework atoms as scalars; valid because the inactive framework is the same in every replica) and, in the same
+    waves, each lane's own adsorbates.  MGPU_NO_FROZEN_BATCH=1 leaves the framework to pair_flat_kernel: both engines must agree to
     the parity bar, and the moves with the C restatement.  three_site: a 3-site adsorbate, whose moves take the fused
     (old + new) instantiations; otherwise the 4-site water (single-state items).  A replica whose framework differs
     from replica 0's switches the batch kernel off for the engine (checked through identical results again)."""
@@ -719,6 +719,19 @@ def test_framework_batch_kernel_matches_the_flat_sweep(three_site, refcpu_mod):
         for r_ in res:
             close(r_[0][c, :3], eo, "old")
             close(r_[1][c, :3], en, "new")
+    # replicas with different adsorbate counts (the per-lane molecule loop of the batch kernel): accept one insertion on
+    # replica 0 and one deletion on replica 1, then the same trials again on 21 / 19 / 20 molecules
+    acc = np.zeros(k, np.int32)
+    acc[1] = 1; acc[5] = 1
+    assert kinds[1] == MGPU_CREATION and rep[1] == 0 and kinds[5] == MGPU_DELETION and rep[5] == 1
+    for e in engines:
+        e.commit_lane(0, rep, tt, m, kinds, acc)
+    assert [engines[0].num_molecules(r, 1) for r in range(3)] == [n + 1, n - 1, n]
+    m3 = np.minimum(m, n - 2).astype(np.int32)
+    res3 = [e.gcmc_trial(rep, tt, m3, kinds, cand) for e in engines]
+    same(res3[0][0], res3[1][0]); same(res3[0][1], res3[1][1])
+    d3 = np.abs(res3[0][1][cr] - res[0][1][cr])              # (candidate 1 now overlaps its accepted copy: inf / nan there)
+    assert np.max(d3[np.isfinite(d3)]) > 0
     # a replica with ANOTHER framework: the engine must leave the batch kernel (results still those of the flat sweep)
     frame2 = s.all_sites(0).copy()
     frame2[0, 5] += 0.05
