@@ -290,6 +290,27 @@ int mgpu_replica_get_frames(mgpu_engine *e, int replica, int t, int *n_mol, doub
  * candidates from the rows the device built, sites and frames. */
 int mgpu_move_trial_submit(mgpu_engine *e, int lane, int n_candidates, const int *replica, const int *t, const int *m,
                            const int *move, const double *u, double translation_step, double rotation_step);
+/* The same trials with the ACCEPTANCE TEST ON THE DEVICE.  The k sweep is the last kernel of a trial, one workgroup per
+ * candidate; once it has summed the candidate's reciprocal energies its first thread holds everything
+ * mc_acceptance_probability (src/monte_carlo_utils.f90:184-226) needs, so it applies the rule itself,
+ *     accept  <=>  accept_u[c] <= min(1, accept_pref[c] * exp(-(new%total - old%total) / temperature)),
+ * with old%total / new%total the sums of the five components in the order the wait calls return them, and the workgroup of
+ * an accepted candidate commits it from the phase tables it already holds (A <- A + delta in a second pass over the
+ * replica's A(k), then coordinates / frames / count: AcceptMove, src/monte_carlo_utils.f90:410-422; create_molecule.f90:
+ * 100-112; delete_molecule.f90:100-142).  The caller supplies the test's uniform number and prefactor per candidate
+ * (1 for translations / rotations; phi V / (N + 1) for an insertion, N / (phi V) for a deletion -- create_molecule.f90:64,
+ * delete_molecule.f90:73) and learns the outcome from mgpu_trial_decide_wait: accepted[c] = 0 / 1 beside the energies.
+ * There is no commit call, no second upload and no second kernel; the engine's host-side counts follow when the lane is
+ * waited for (or drained by any synchronous entry point).  One candidate per replica per launch; row-form k sweep
+ * (molecules of a few sites).  The committed state is bitwise that of mgpu_commit_submit with the same flags.
+ * mgpu_gcmc_trial_decide_submit takes candidate rows from the host (replicas without resident frames). */
+int mgpu_move_trial_decide_submit(mgpu_engine *e, int lane, int n_candidates, const int *replica, const int *t, const int *m,
+                                  const int *move, const double *u, double translation_step, double rotation_step,
+                                  const double *accept_u, const double *accept_pref, double temperature);
+int mgpu_gcmc_trial_decide_submit(mgpu_engine *e, int lane, int n_candidates, const int *replica, const int *t, const int *m,
+                                  const int *kind, const double *sites, int site_stride, const double *accept_u,
+                                  const double *accept_pref, double temperature);
+int mgpu_trial_decide_wait(mgpu_engine *e, int lane, double *old_energy, double *new_energy, int *accepted);
 /* Pinned staging of a lane's NEXT trial, sized for n_max candidates of site_stride sites: a host that builds its
  * candidate rows directly in *sites and then passes that same pointer as `sites` to mgpu_trial_submit /
  * mgpu_gcmc_trial_submit on this lane (with at most n_max candidates and the same site_stride) saves the engine's copy

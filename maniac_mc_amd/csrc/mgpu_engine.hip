@@ -112,6 +112,10 @@ struct Lane {
     } deferred;
     DevBuf d_prev;                            // the staging block the deferred commit still reads
     std::vector<int> mark;                    // [n_replicas] scratch: replica -> deferred candidate index
+    // A trial whose acceptance is decided (and whose accepted candidates are committed) on the device: the flags arrive
+    // with the energies; the engine's host mirrors (counts, range flags) follow when the lane is next synchronised
+    int decided_n = 0;                        // candidates of such a trial not yet folded into the mirrors (0 = none)
+    size_t decided_at = 0;                    // byte offset of the flags in h_out
     hipEvent_t commit_staged_ev = nullptr;                    // recorded behind the H2D copies that read h_commit
     bool commit_staged = false;
     void release() {
@@ -250,9 +254,11 @@ int prof_collect(mgpu_engine *e, Lane &ln) {
     return MGPU_OK;
 }
 
+void finish_decided(mgpu_engine *e, Lane &ln);
 int sync_lane(mgpu_engine *e, Lane &ln) {
     HIP_TRY(hipStreamSynchronize(ln.stream));
     ln.dirty = false;
+    if (ln.decided_n) finish_decided(e, ln);
     return prof_collect(e, ln);
 }
 int sync_stream(mgpu_engine *e) { return sync_lane(e, e->lanes[0]); }
@@ -268,6 +274,25 @@ int sync_all_lanes(mgpu_engine *e) {
         if (&ln == &e->lanes[0] || ln.dirty || !ln.pending.empty())
             if (int rc = sync_lane(e, ln)) return rc;
     return MGPU_OK;
+}
+
+// The device accepted and committed some candidates of the lane's last trial (recip_rows_kernel<false, true, true>): the
+// host mirrors of the molecule counts and of the fast-fold range flags catch up from the flags in the result block.
+void finish_decided(mgpu_engine *e, Lane &ln) {
+    const int n = ln.decided_n;
+    ln.decided_n = 0;
+    const int *flags = (const int *)((const char *)ln.h_out.p + ln.decided_at);
+    const RecipItem *items = ln.h_trial_items;
+    for (int c = 0; c < n; ++c) {
+        if (!flags[c]) continue;
+        const int idx = items[c].replica * e->tp.n_res + items[c].t;
+        if (items[c].kind == MGPU_CREATION) e->h_nmol[idx] += 1;
+        if (items[c].kind == MGPU_DELETION) e->h_nmol[idx] -= 1;
+        if (items[c].kind != MGPU_DELETION && !(c < (int)ln.cand_ok.size() && ln.cand_ok[c])) e->in_range[idx] = 0;
+    }
+    // the rows were consumed by the device's commit: nothing is left to commit "from the lane's resident rows"
+    ln.last_trial_n = 0;
+    ln.d_trial_items = nullptr;
 }
 
 int check_candidate(const mgpu_engine *e, int c, int replica, int t, int m, bool need_resident) {
@@ -569,13 +594,15 @@ bool recip_by_rows(const mgpu_engine *e, int n1_max) {
 // those whose bit is set are applied
 int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items, int n1_max, int site_stride,
                  bool commit, double2 *A_base, double *d_u, double *d_u_old = nullptr, const AcceptBits *accept = nullptr,
-                 const double *sites_override = nullptr) {
+                 const double *sites_override = nullptr, const DecideArgs *decide = nullptr) {
     const bool by_rows = recip_by_rows(e, n1_max);
     const double *d_cand = sites_override ? sites_override : (const double *)ln.d_sites.p;
     static const AcceptBits no_bits{};
     const AcceptBits &bits = accept ? *accept : no_bits;
     const int use_accept = accept ? 1 : 0;
     if (accept && !by_rows) return set_error(MGPU_ERR_STATE, "commit by accept mask needs the row-form kernel");
+    if (decide && (!by_rows || commit || !d_u_old)) return set_error(MGPU_ERR_STATE, "device-side acceptance needs the row-form old + new k sweep");
+    const DecideArgs no_decide{};
     const size_t lds = by_rows ? recip_rows_lds_bytes(e, n1_max) : recip_lds_bytes(e, n1_max);
     if (lds > 64 * 1024)
         return set_error(MGPU_ERR_CAPACITY, "reciprocal update: molecule too large for the LDS phase tables (" +
@@ -590,13 +617,17 @@ int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items
             hipExtLaunchKernelGGL((recip_rows_kernel<COMMIT, BOTH>), dim3(n_items), dim3(kBlock), lds, ln.stream, a, b, \
                                   0, e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_trj, e->d_tw, e->n_rtasks, e->d_rrows, e->n_rrows, \
                                A_base, d_items, d_cand, site_stride, d_u, d_u_old,      \
-                                  bits, use_accept);                                                                \
+                                  bits, use_accept, no_decide);                                                     \
         else                                                                                                         \
             hipExtLaunchKernelGGL((recip_kernel<COMMIT, BOTH>), dim3(n_items), dim3(kBlock), lds, ln.stream, a, b, 0,   \
                                   e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_kpack, e->d_kslot, e->d_kw, A_base, d_items,  \
                                d_cand, site_stride, d_u, d_u_old);                               \
     } while (0)
-    if (commit) MGPU_LAUNCH_RECIP(true, false);
+    if (decide)
+        hipExtLaunchKernelGGL((recip_rows_kernel<false, true, true>), dim3(n_items), dim3(kBlock), lds, ln.stream, a, b, 0, e->tp,
+                              e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_trj, e->d_tw, e->n_rtasks, e->d_rrows, e->n_rrows, A_base,
+                              d_items, d_cand, site_stride, d_u, d_u_old, bits, 0, *decide);
+    else if (commit) MGPU_LAUNCH_RECIP(true, false);
     else if (d_u_old) MGPU_LAUNCH_RECIP(false, true);
     else MGPU_LAUNCH_RECIP(false, false);
 #undef MGPU_LAUNCH_RECIP
@@ -1520,10 +1551,31 @@ struct TrialBuild {
     const double *u;              // [n][5]
     double t_step, r_step;
 };
+// decide != nullptr: the acceptance test runs on the device behind the k sweep and accepted candidates are committed there
+// (DecideItem, mgpu_kernels.h); accept_u[n] = the test's uniform numbers, accept_pref[n] = its prefactors
+struct TrialDecide {
+    const double *u, *pref;
+    double temperature;
+};
 static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica, const int *t, const int *m,
-                             const int *kind, const double *sites, int site_stride, const TrialBuild *build = nullptr) {
+                             const int *kind, const double *sites, int site_stride, const TrialBuild *build = nullptr,
+                             const TrialDecide *decide = nullptr) {
     if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "trial_submit: the lane still holds an un-waited trial");
     int rc;
+    if (decide) {
+        if (!(decide->temperature > 0.0)) return set_error(MGPU_ERR_INVALID_ARG, "trial_decide_submit: temperature must be positive");
+        if ((rc = flush_deferred(e, ln))) return rc;
+        // one candidate per replica: the workgroups commit independently
+        if ((int)ln.mark.size() != e->n_replicas) ln.mark.assign(e->n_replicas, -1);
+        bool twice = false;
+        for (int c = 0; c < n; ++c) {
+            if (replica[c] < 0 || replica[c] >= e->n_replicas) return set_error(MGPU_ERR_INVALID_ARG, "trial_decide_submit: replica out of range");
+            twice = twice || ln.mark[replica[c]] == -3;
+            ln.mark[replica[c]] = -3;
+        }
+        for (int c = 0; c < n; ++c) ln.mark[replica[c]] = -1;
+        if (twice) return set_error(MGPU_ERR_INVALID_ARG, "trial_decide_submit: more than one candidate for a replica");
+    }
     ln.dirty = true;
     ln.last_trial_built = false;
     int frame_at = 0;
@@ -1548,9 +1600,15 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     const size_t build_at = (site_bytes + pit_cap + rit_bytes + iit_cap + 7) & ~(size_t)7;
     const size_t build_mv = ((size_t)n * sizeof(int) + 7) & ~(size_t)7;
     const size_t build_bytes = build ? build_mv + (size_t)5 * n * sizeof(double) : 0;
+    // ... and the deciding form its DecideItems behind that
+    const size_t dec_at = (build_at + build_bytes + 7) & ~(size_t)7;
+    const size_t dec_bytes = decide ? (size_t)n * sizeof(DecideItem) : 0;
     if (sites && sites == ln.h_in.p && site_bytes + pit_cap + rit_bytes + iit_cap > ln.h_in.bytes)
         return set_error(MGPU_ERR_INVALID_ARG, "trial_submit: more candidates than the lane's site buffer was sized for");
-    if ((rc = ln.h_in.reserve(build_at + build_bytes))) return rc;
+    if (sites && sites == ln.h_in.p && dec_at + dec_bytes > ln.h_in.bytes)
+        return set_error(MGPU_ERR_INVALID_ARG, "trial_decide_submit: the lane's site buffer is too small for the acceptance records "
+                                               "(mgpu_lane_site_buffer sizes it for them)");
+    if ((rc = ln.h_in.reserve(dec_at + dec_bytes))) return rc;
     double *h_sites = (double *)ln.h_in.p;
     PairItem *pit = (PairItem *)((char *)ln.h_in.p + site_bytes);
     RecipItem *rit = (RecipItem *)((char *)ln.h_in.p + site_bytes + pit_cap);
@@ -1663,6 +1721,13 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
             fast = fast && ln.cand_ok[c];          // the candidate's own sites are swept in this launch
         }
         if (k != MGPU_MOVE) ln.self_of[c] = e->self_of_type[t[c]];
+        if (decide) {
+            const size_t idx = (size_t)replica[c] * e->tp.n_res + t[c];
+            if (k == MGPU_CREATION && e->h_nmol[idx] >= e->tp.cap[t[c]])
+                return set_error(MGPU_ERR_CAPACITY, "trial_decide_submit: residue type is at mol_capacity");
+            if (!build && k != MGPU_DELETION && e->d_com && e->frames_ok[idx])
+                return set_error(MGPU_ERR_STATE, "trial_decide_submit: this replica holds molecule frames: submit device-built trials");
+        }
         const bool fz = k == MGPU_MOVE && seg_fused[ci] >= 0;
         if (fz) {
             const int e0 = add_item(segs[seg_fused[ci]], PairItem{replica[c], t[c], mc, c, 0});
@@ -1696,7 +1761,24 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
             scratch_records += (size_t)ne * n_chunks_f;
         }
     const size_t extra_at = 2 * (size_t)n_partials + 3 * (size_t)n;          // doubles
-    const size_t out_doubles = extra_at + (scratch_records ? 2 * (size_t)n_pair : 0);
+    const size_t acc_at = extra_at + (scratch_records ? 2 * (size_t)n_pair : 0);     // the deciding form's flags (ints)
+    const size_t out_doubles = acc_at + (decide ? ((size_t)n + 1) / 2 : 0);
+    if (decide) {
+        if (!recip_by_rows(e, n1_max)) return set_error(MGPU_ERR_STATE, "trial_decide_submit: needs the row-form k sweep");
+        DecideItem *dit = (DecideItem *)((char *)ln.h_in.p + dec_at);
+        for (int c = 0; c < n; ++c) {
+            DecideItem d{0, 2, -1, -1, 0, 2, -1, -1, ln.intra_idx[c], ln.kinds[c], ln.self_of[c], decide->pref[c], decide->u[c]};
+            if (const int i = ln.pair_old[c]; i >= 0) {
+                d.old_off = ln.ent_off[i]; d.old_stride = ln.ent_stride[i]; d.old_ns = ln.ent_ns[i];
+                d.old_extra = ln.ent_extra[i] ? (int)(extra_at + 2 * (size_t)i) : -1;
+            }
+            if (const int i = ln.pair_new[c]; i >= 0) {
+                d.new_off = ln.ent_off[i]; d.new_stride = ln.ent_stride[i]; d.new_ns = ln.ent_ns[i];
+                d.new_extra = ln.ent_extra[i] ? (int)(extra_at + 2 * (size_t)i) : -1;
+            }
+            dit[c] = d;
+        }
+    }
     if (scratch_records && (rc = ln.d_scratch.reserve(scratch_records * sizeof(double2)))) return rc;
     // A deferred commit of this lane rides in this trial's k sweep when every new candidate sits on its own replica
     // and the row-form kernel applies; otherwise it is launched on its own first.
@@ -1738,12 +1820,12 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     }
     // one staging block [sites | pair items (2n slots) | recip items | intra items | pend_idx] -> one H2D copy
     const size_t in_bytes = site_bytes + pit_cap + rit_bytes + iit_bytes + (fused_k ? pend_bytes : 0);
-    if ((rc = ln.d_sites.reserve(build_at + build_bytes))) return rc;
+    if ((rc = ln.d_sites.reserve(dec_at + dec_bytes))) return rc;
     if ((rc = ln.d_out.reserve(out_doubles * sizeof(double)))) return rc;
     if ((rc = ln.h_out.reserve(out_doubles * sizeof(double)))) return rc;
     if (build) {
         // the rows are written by the device: only [items | move codes | uniforms] travel
-        HIP_TRY(hipMemcpyAsync((char *)ln.d_sites.p + site_bytes, (char *)ln.h_in.p + site_bytes, build_at + build_bytes - site_bytes,
+        HIP_TRY(hipMemcpyAsync((char *)ln.d_sites.p + site_bytes, (char *)ln.h_in.p + site_bytes, dec_at + dec_bytes - site_bytes,
                                hipMemcpyHostToDevice, ln.stream));
         hipLaunchKernelGGL(trial_build_kernel, dim3((n + 127) / 128), dim3(128), 0, ln.stream, e->tp, e->bx,
                            (const RecipItem *)((char *)ln.d_sites.p + site_bytes + pit_cap), (const int *)((char *)ln.d_sites.p + build_at),
@@ -1752,6 +1834,8 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
         HIP_TRY(hipGetLastError());
     } else {
         HIP_TRY(hipMemcpyAsync(ln.d_sites.p, ln.h_in.p, in_bytes, hipMemcpyHostToDevice, ln.stream));
+        if (decide)
+            HIP_TRY(hipMemcpyAsync((char *)ln.d_sites.p + dec_at, (char *)ln.h_in.p + dec_at, dec_bytes, hipMemcpyHostToDevice, ln.stream));
     }
     const PairItem *d_pit = (const PairItem *)((char *)ln.d_sites.p + site_bytes);
     const RecipItem *d_rit = (const RecipItem *)((char *)ln.d_sites.p + site_bytes + pit_cap);
@@ -1780,12 +1864,20 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
             scratch_at += (size_t)sg.n_items * (sg.fused ? 2 : 1) * n_chunks_f;
         }
     }
-    if (!fused_k && (rc = launch_recip(e, ln, d_rit, n, n1_max, site_stride, false, e->d_A, d_un, d_uo)))
+    if (!decide && !fused_k && (rc = launch_recip(e, ln, d_rit, n, n1_max, site_stride, false, e->d_A, d_un, d_uo)))
         return rc;
     if (n_intra) {
         hipLaunchKernelGGL(intra_kernel, dim3((n_intra + 63) / 64), dim3(64), 0, ln.stream, e->tp, e->bx, e->d_pos, e->d_res_q,
                            d_iit, n_intra, (const double *)ln.d_sites.p, site_stride, d_in);
         HIP_TRY(hipGetLastError());
+    }
+    if (decide) {
+        // the k sweep comes last: its workgroups decide and commit (everything else of the trial has read the old state)
+        const DecideArgs da{(const DecideItem *)((const char *)ln.d_sites.p + dec_at), (const double *)ln.d_out.p, d_in,
+                            (int *)((double *)ln.d_out.p + acc_at), decide->temperature};
+        if ((rc = launch_recip(e, ln, d_rit, n, n1_max, site_stride, false, e->d_A, d_un, d_uo, nullptr, nullptr, &da))) return rc;
+        ln.decided_n = n;
+        ln.decided_at = acc_at * sizeof(double);
     }
     HIP_TRY(hipMemcpyAsync(ln.h_out.p, ln.d_out.p, out_doubles * sizeof(double), hipMemcpyDeviceToHost, ln.stream));
     ln.n_submitted = n;
@@ -1803,12 +1895,15 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
 }
 
 // ncomp = 3: non_coulomb, coulomb, recip_coulomb; ncomp = 5: + ewald_self, intra_coulomb
-static int trial_wait_impl(mgpu_engine *e, Lane &ln, double *old_energy, double *new_energy, int ncomp) {
+static int trial_wait_impl(mgpu_engine *e, Lane &ln, double *old_energy, double *new_energy, int ncomp, int *accepted = nullptr) {
     const int n = ln.n_submitted;
     if (n == 0) return set_error(MGPU_ERR_STATE, "trial_wait: nothing was submitted on this lane");
+    if (accepted && ln.decided_n != n) return set_error(MGPU_ERR_STATE, "trial_decide_wait: the lane's trial was not submitted with an acceptance test");
     ln.n_submitted = 0;
+    const size_t flags_at = ln.decided_at;
     int rc = sync_lane(e, ln);
     if (rc) return rc;
+    if (accepted) std::memcpy(accepted, (const char *)ln.h_out.p + flags_at, (size_t)n * sizeof(int));
     const int np = ln.n_pair_items;
     const double *h = (const double *)ln.h_out.p;
     const double *uo = h + 2 * (size_t)ln.n_partials, *un = uo + n, *in = un + n, *ex = in + n;
@@ -1969,7 +2064,7 @@ static int check_lane(const mgpu_engine *e, int lane) {
 
 static size_t trial_staging_bytes(int n, int site_stride) {
     return (size_t)n * site_stride * 3 * sizeof(double) + 2 * (size_t)n * sizeof(PairItem) + (size_t)n * sizeof(RecipItem) +
-           (size_t)n * sizeof(PairItem) + (size_t)n * sizeof(int);
+           (size_t)n * sizeof(PairItem) + (size_t)n * sizeof(int) + 16 + (size_t)n * sizeof(DecideItem);   // + acceptance records
 }
 
 int mgpu_lane_site_buffer(mgpu_engine *e, int lane, int n_max, int site_stride, double **sites) {
@@ -2021,6 +2116,46 @@ int mgpu_move_trial_submit(mgpu_engine *e, int lane, int n, const int *replica, 
     }
     const TrialBuild build{move, u, translation_step, rotation_step};
     return trial_submit_impl(e, ln, n, replica, t, m, ln.build_kind.data(), nullptr, 0, &build);
+}
+
+int mgpu_move_trial_decide_submit(mgpu_engine *e, int lane, int n, const int *replica, const int *t, const int *m, const int *move,
+                                  const double *u, double translation_step, double rotation_step, const double *accept_u,
+                                  const double *accept_pref, double temperature) {
+    int rc = check_lane(e, lane);
+    if (rc) return rc;
+    if (n <= 0 || !replica || !t || !m || !move || !u || !accept_u || !accept_pref)
+        return set_error(MGPU_ERR_INVALID_ARG, "move_trial_decide_submit: bad argument");
+    if (e->bx.triclinic) return set_error(MGPU_ERR_STATE, "move_trial_decide_submit: orthorhombic boxes only");
+    if ((rc = use_device(e))) return rc;
+    Lane &ln = e->lanes[lane];
+    ln.build_kind.resize(n);
+    for (int c = 0; c < n; ++c) {
+        if (move[c] < 1 || move[c] > 4) return set_error(MGPU_ERR_INVALID_ARG, "move_trial_decide_submit: unknown move code");
+        ln.build_kind[c] = move[c] <= 2 ? MGPU_MOVE : (move[c] == 3 ? MGPU_CREATION : MGPU_DELETION);
+    }
+    const TrialBuild build{move, u, translation_step, rotation_step};
+    const TrialDecide dec{accept_u, accept_pref, temperature};
+    return trial_submit_impl(e, ln, n, replica, t, m, ln.build_kind.data(), nullptr, 0, &build, &dec);
+}
+
+int mgpu_gcmc_trial_decide_submit(mgpu_engine *e, int lane, int n, const int *replica, const int *t, const int *m,
+                                  const int *kind, const double *sites, int site_stride, const double *accept_u,
+                                  const double *accept_pref, double temperature) {
+    int rc = check_lane(e, lane);
+    if (rc) return rc;
+    if (n <= 0 || !replica || !t || !m || !kind || !sites || !accept_u || !accept_pref)
+        return set_error(MGPU_ERR_INVALID_ARG, "gcmc_trial_decide_submit: bad argument");
+    if ((rc = use_device(e))) return rc;
+    const TrialDecide dec{accept_u, accept_pref, temperature};
+    return trial_submit_impl(e, e->lanes[lane], n, replica, t, m, kind, sites, site_stride, nullptr, &dec);
+}
+
+int mgpu_trial_decide_wait(mgpu_engine *e, int lane, double *old_energy, double *new_energy, int *accepted) {
+    int rc = check_lane(e, lane);
+    if (rc) return rc;
+    if (!old_energy || !new_energy || !accepted) return set_error(MGPU_ERR_INVALID_ARG, "trial_decide_wait: null output");
+    if ((rc = use_device(e))) return rc;
+    return trial_wait_impl(e, e->lanes[lane], old_energy, new_energy, 5, accepted);
 }
 
 int mgpu_gcmc_trial_wait(mgpu_engine *e, int lane, double *old_energy, double *new_energy) {

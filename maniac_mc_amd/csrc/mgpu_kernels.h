@@ -1290,15 +1290,63 @@ struct AcceptBits {
 #define MGPU_RECIP_TASK_CHUNK 2
 #endif
 constexpr int kRecipTaskChunk = MGPU_RECIP_TASK_CHUNK;   // tasks a thread requests ahead of their use
-template <bool COMMIT, bool BOTH>
+
+// Acceptance decided on the device (recip_rows_kernel<false, true, true>): the k sweep's workgroup is the last kernel of a
+// candidate's trial, so once its two reciprocal energies are summed thread 0 has everything mc_acceptance_probability
+// needs (monte_carlo_utils.f90:184-226) -- the pair entries' split partials (summed in split order, framework record last,
+// exactly as trial_wait does on the host), ewald_self and intra_coulomb on the side where the molecule exists
+// (monte_carlo_utils.f90:298-299, :378-379) -- and an accepted candidate is committed by the SAME workgroup from the phase
+// tables it already holds: a second pass over its replica's A(k) (A <- A + delta, the stand-alone commit's arithmetic) and the
+// coordinate / frame / count update.  Offsets are in doubles into the lane's result block.
+struct DecideItem {
+    int old_off, old_stride, old_ns, old_extra;     // old-state pair entry: ns = -1 none; extra = -1 none
+    int new_off, new_stride, new_ns, new_extra;
+    int intra;                                      // index of the candidate's intra_coulomb result, -1 none
+    int kind;                                       // MGPU_MOVE / CREATION / DELETION
+    double self;                                    // ewald_self of the candidate's residue type
+    double pref;                                    // acceptance prefactor: 1 (moves), phi V / (N + 1), N / (phi V)
+    double u;                                       // the uniform number of the test
+};
+struct DecideArgs {
+    const DecideItem *items;
+    const double *out;                              // the lane's result block (partials | u_old | u_new | intra | extra)
+    const double *intra;
+    int *accepted;                                  // [n] flags, copied out with the energies
+    double temperature;
+};
+// old%total and new%total as the host driver forms them: components added in the order non_coulomb, coulomb, recip_coulomb,
+// ewald_self, intra_coulomb (mc_farm.f90 resolve_and_commit)
+__device__ inline bool decide_candidate(const DecideItem &d, const DecideArgs &g, double u_old, double u_new) {
+    double o[5] = {0.0, 0.0, u_old, 0.0, 0.0}, w[5] = {0.0, 0.0, u_new, 0.0, 0.0};
+    auto entry = [&](int off, int stride, int ns, int extra, double &lj, double &cc) {
+        double a = 0.0, b = 0.0;
+        const double *p = g.out + off;
+        for (int s2 = 0; s2 < ns; ++s2) { a += p[stride * s2]; b += p[stride * s2 + 1]; }
+        if (extra >= 0) { a += g.out[extra]; b += g.out[extra + 1]; }
+        lj = a;
+        cc = b * kEps0InvEvA / kKbEvK;                                        // energy_utils.f90:440
+    };
+    if (d.old_ns >= 0) entry(d.old_off, d.old_stride, d.old_ns, d.old_extra, o[0], o[1]);
+    if (d.new_ns >= 0) entry(d.new_off, d.new_stride, d.new_ns, d.new_extra, w[0], w[1]);
+    if (d.kind == 1) { w[3] = d.self; w[4] = g.intra[d.intra]; }
+    if (d.kind == 2) { o[3] = d.self; o[4] = g.intra[d.intra]; }
+    double e_old = 0.0, e_new = 0.0;
+    for (int k = 0; k < 5; ++k) { e_old = e_old + o[k]; e_new = e_new + w[k]; }
+    const double x = d.pref * exp(-(e_new - e_old) / g.temperature);          // min(1, x); a NaN (overlap) rejects
+    return x >= 1.0 || d.u <= x;
+}
+
+template <bool COMMIT, bool BOTH, bool DECIDE = false>
 __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_MINWAVES) void recip_rows_kernel(
     Topo tp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
     const int *__restrict__ trj, const double2 *__restrict__ tw, int n_tasks, const RecipRow *__restrict__ rows, int n_rows,
     double2 *__restrict__ A_base, const RecipItem *__restrict__ items,
     const double *__restrict__ cand_sites, int site_stride, double *__restrict__ u_new, double *__restrict__ u_old,
-    AcceptBits accept, int use_accept) {
+    AcceptBits accept, int use_accept, DecideArgs dec) {
+    static_assert(!DECIDE || (!COMMIT && BOTH), "the deciding form is the old + new k sweep");
     extern __shared__ double2 s_tab[];
     __shared__ double s_red[2 * kWavesPerBlock];
+    __shared__ int s_flag;
 
     RecipItem it = items[blockIdx.x];
     if (COMMIT && use_accept) {
@@ -1344,7 +1392,7 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
         double2 Ap[kRecipTaskChunk], Am[kRecipTaskChunk], w[kRecipTaskChunk];
     };
     Chunk ch0;
-    auto load_chunk = [&](Chunk &ch, int t0) {
+    auto load_chunk = [&](Chunk &ch, int t0, auto store) {             // store: the chunk feeds the commit pass (no weights)
 #pragma unroll
         for (int c = 0; c < kRecipTaskChunk; ++c) {
             const int t = t0 + c * kBlock;
@@ -1352,11 +1400,12 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
             ch.rj[c] = in ? trj[t] : 0;                                // filler: row 0, j 0, nothing present
             ch.Ap[c] = in ? A[2 * t] : make_double2(0.0, 0.0);
             ch.Am[c] = in ? A[2 * t + 1] : make_double2(0.0, 0.0);
-            ch.w[c] = (in && !COMMIT) ? tw[t] : make_double2(0.0, 0.0);
+            ch.w[c] = (in && !decltype(store)::value) ? tw[t] : make_double2(0.0, 0.0);
         }
     };
+    constexpr std::integral_constant<bool, COMMIT> kStore{};
     constexpr bool kEarly = ((MGPU_RECIP_EARLY_LOAD) >> (COMMIT ? 1 : 0)) & 1;
-    if constexpr (kEarly) load_chunk(ch0, threadIdx.x);
+    if constexpr (kEarly) load_chunk(ch0, threadIdx.x, kStore);
 
     // phase 1: entry (s, axis, k >= 0) at s_tab[s * ktot + kofs[axis] + k]; s = set * n1 + a with both sets, s = a with one
     // (set 0 = the new sites, set 1 = the old ones)
@@ -1404,7 +1453,7 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
     double acc = 0.0, acc0 = 0.0;
     // the tasks of one chunk: a thread's tasks are visited in ascending order whatever the chunk size, so the sums do
     // not depend on it
-    auto compute_chunk = [&](const Chunk &ch, int t0) {
+    auto compute_chunk = [&](const Chunk &ch, int t0, auto store) {
 #pragma unroll
         for (int c = 0; c < kRecipTaskChunk; ++c) {
             const double2 *xy = s_xy + ((ch.rj[c] >> 8) & 0xfffff) * nss;
@@ -1420,10 +1469,10 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
             const double wp = ch.w[c].x, wm = ch.w[c].y;
             // explicit fma forms: the deferred-commit kernel must produce the same bits, and a contraction left to the
             // compiler may pick a different product to fuse in a different kernel
-            if (BOTH) acc0 += fma(wp, fma(ch.Ap[c].x, ch.Ap[c].x, ch.Ap[c].y * ch.Ap[c].y), wm * fma(ch.Am[c].x, ch.Am[c].x, ch.Am[c].y * ch.Am[c].y));
+            if (BOTH && !decltype(store)::value) acc0 += fma(wp, fma(ch.Ap[c].x, ch.Ap[c].x, ch.Ap[c].y * ch.Ap[c].y), wm * fma(ch.Am[c].x, ch.Am[c].x, ch.Am[c].y * ch.Am[c].y));
             const double npx = ch.Ap[c].x + (sac - sbd), npy = ch.Ap[c].y + (sad + sbc);
             const double nmx = ch.Am[c].x + (sac + sbd), nmy = ch.Am[c].y + (sbc - sad);
-            if (COMMIT) {
+            if (decltype(store)::value) {
                 const int t = t0 + c * kBlock;
                 if (t < n_tasks) {        // absent members stay zero
                     A[2 * t] = (ch.rj[c] & kTaskHasP) ? make_double2(npx, npy) : make_double2(0.0, 0.0);
@@ -1440,22 +1489,22 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
     {
         Chunk ch1;
         int t0 = threadIdx.x;
-        if (!kEarly && t0 < n_tasks) load_chunk(ch0, t0);
+        if (!kEarly && t0 < n_tasks) load_chunk(ch0, t0, kStore);
         while (t0 < n_tasks) {
             const int t1 = t0 + kStride;
-            if (t1 < n_tasks) load_chunk(ch1, t1);
-            compute_chunk(ch0, t0);
+            if (t1 < n_tasks) load_chunk(ch1, t1, kStore);
+            compute_chunk(ch0, t0, kStore);
             if (t1 >= n_tasks) break;
             const int t2 = t1 + kStride;
-            if (t2 < n_tasks) load_chunk(ch0, t2);
-            compute_chunk(ch1, t1);
+            if (t2 < n_tasks) load_chunk(ch0, t2, kStore);
+            compute_chunk(ch1, t1, kStore);
             t0 = t2;
         }
     }
 #else
     for (int t0 = threadIdx.x; t0 < n_tasks; t0 += kStride) {
-        if (!kEarly || t0 != (int)threadIdx.x) load_chunk(ch0, t0);
-        compute_chunk(ch0, t0);
+        if (!kEarly || t0 != (int)threadIdx.x) load_chunk(ch0, t0, kStore);
+        compute_chunk(ch0, t0, kStore);
     }
 #endif
 
@@ -1467,10 +1516,35 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
         if (threadIdx.x == 0) {
             double u = 0.0, u0 = 0.0;
             for (int wv = 0; wv < kWavesPerBlock; ++wv) { u += s_red[2 * wv]; u0 += s_red[2 * wv + 1]; }
-            u_new[blockIdx.x] = u * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;   // ewald_energy.f90:272
-            if (BOTH) u_old[blockIdx.x] = u0 * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;
+            const double e_new = u * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;   // ewald_energy.f90:272
+            const double e_old = u0 * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;
+            u_new[blockIdx.x] = e_new;
+            if (BOTH) u_old[blockIdx.x] = e_old;
+            if constexpr (DECIDE) {
+                const bool yes = decide_candidate(dec.items[blockIdx.x], dec, e_old, e_new);
+                dec.accepted[blockIdx.x] = yes ? 1 : 0;
+                s_flag = yes ? 1 : 0;
+            }
         }
-    } else {
+    }
+    if constexpr (DECIDE) {
+        __syncthreads();
+        if (!s_flag) return;                                          // uniform per workgroup
+        if (it.kind != 0) {
+            // as the commit by accept mask: target slot / new count from the replica's live count
+            const int nm = nmol[it.replica * tp.n_res + it.t];
+            if (it.kind == 1) { it.m = nm; it.aux = nm + 1; }
+            else it.aux = nm - 1;
+        }
+        // A <- A + delta from the tables still in LDS: the stand-alone commit's pass (same sums, same bits); this
+        // workgroup has just read the replica's A(k), so the second read comes from L2 / the Infinity Cache
+        constexpr std::true_type kYes{};
+        for (int t0 = threadIdx.x; t0 < n_tasks; t0 += kStride) {
+            load_chunk(ch0, t0, kYes);
+            compute_chunk(ch0, t0, kYes);
+        }
+    }
+    if (COMMIT || DECIDE) {
         // every read of the old coordinates happened before the first barrier
         if (it.kind == 0 || it.kind == 1) {
             if (threadIdx.x < n1) {

@@ -168,6 +168,36 @@ class Engine:
         check(self.L.mgpu_gcmc_trial_wait(self.h, C.c_int(lane), _d(old), _d(new)))
         return old, new
 
+    def move_trial_decide(self, replica, t, m, move, u, translation_step, rotation_step, accept_u, accept_pref, temperature,
+                          lane=0):
+        """Device-built trials decided and committed on the device (mgpu_move_trial_decide_submit + wait):
+        (old[n,5], new[n,5], accepted[n])."""
+        m = _ints(m); n = m.shape[0]
+        replica = _ints(replica, n); t = _ints(t, n); move = _ints(move, n)
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(n, 5)
+        au = np.ascontiguousarray(accept_u, dtype=np.float64).reshape(n)
+        ap = np.ascontiguousarray(accept_pref, dtype=np.float64).reshape(n)
+        old = np.zeros((n, 5)); new = np.zeros((n, 5)); acc = np.zeros(n, np.int32)
+        self._last_stride = 0
+        check(self.L.mgpu_move_trial_decide_submit(self.h, C.c_int(lane), C.c_int(n), _i(replica), _i(t), _i(m), _i(move), _d(u),
+                                                   C.c_double(translation_step), C.c_double(rotation_step), _d(au), _d(ap),
+                                                   C.c_double(temperature)))
+        check(self.L.mgpu_trial_decide_wait(self.h, C.c_int(lane), _d(old), _d(new), _i(acc)))
+        return old, new, acc
+
+    def gcmc_trial_decide(self, replica, t, m, kind, sites, accept_u, accept_pref, temperature, lane=0):
+        """Host-built rows, decided and committed on the device: (old[n,5], new[n,5], accepted[n])."""
+        n, replica, t, m, sites = self._cand(replica, t, m, sites)
+        kind = _ints(kind, n)
+        au = np.ascontiguousarray(accept_u, dtype=np.float64).reshape(n)
+        ap = np.ascontiguousarray(accept_pref, dtype=np.float64).reshape(n)
+        old = np.zeros((n, 5)); new = np.zeros((n, 5)); acc = np.zeros(n, np.int32)
+        self._last_stride = sites.shape[1]
+        check(self.L.mgpu_gcmc_trial_decide_submit(self.h, C.c_int(lane), C.c_int(n), _i(replica), _i(t), _i(m), _i(kind),
+                                                   _d(sites), C.c_int(sites.shape[1]), _d(au), _d(ap), C.c_double(temperature)))
+        check(self.L.mgpu_trial_decide_wait(self.h, C.c_int(lane), _d(old), _d(new), _i(acc)))
+        return old, new, acc
+
     def num_molecules(self, replica, t):
         n = C.c_int()
         check(self.L.mgpu_replica_num_molecules(self.h, C.c_int(replica), C.c_int(t), C.byref(n)))

@@ -242,3 +242,103 @@ def test_device_built_trials_match_host_built_rows():
     with pytest.raises(Exception):
         eng.commit_candidates([0], [0], [1], [MGPU_MOVE], rows[:1], [1])
     eng.close()
+
+
+def _decide_host(old, new, u, pref, T):
+    """mc_farm.f90 resolve_and_commit: totals in component order, min(1, pref exp(-dE / T)), accept iff u <= p"""
+    e_old = np.zeros(len(u)); e_new = np.zeros(len(u))
+    for k in range(5):
+        e_old = e_old + old[:, k]
+        e_new = e_new + new[:, k]
+    with np.errstate(over="ignore", invalid="ignore"):
+        x = pref * np.exp(-(e_new - e_old) / T)
+    return ((x >= 1.0) | (u <= x)).astype(np.int32)
+
+
+@pytest.mark.parametrize("system", ["co2", "framework_water"])
+@pytest.mark.parametrize("built", [False, True], ids=["host_rows", "device_built"])
+def test_device_decided_trials_commit_the_same_state(system, built):
+    """mgpu_*_trial_decide_submit: the k sweep's workgroup applies the acceptance rule and commits.  Two engines run the
+    same scripted grand-canonical steps, one candidate per replica and step: engine A the classic way (trial, decision
+    on the host, mgpu_commit_submit), engine B with the decision on the device.  Energies, flags, counts, coordinates,
+    frames and A(k) must be bitwise equal after every step."""
+    if system == "co2":
+        s = synth.co2_box(20, seed=4)
+        ta, caps = 0, [40]
+    else:
+        s = synth.framework_water_box(n_water=12, n_frame=300, L=24.0, seed=7)
+        ta, caps = 1, [1, 30]
+    R = 7
+    T = 300.0
+    engines = []
+    for _ in range(2):
+        e = Engine(s.topo, s.box_matrix, s.bounds_lo, s.real_space_cutoff, s.ewald_tolerance, R, 0, caps)
+        for tt in range(s.topo.n_res):
+            if built and tt == ta:
+                e.set_frames(0, tt, s.com[tt], s.offsets[tt])
+            else:
+                e.set_molecules(0, tt, s.all_sites(tt))
+        e.init_structure_factor(0, True)
+        for r in range(1, R):
+            e.replica_copy(r, 0)
+        engines.append(e)
+    A_, B_ = engines
+    rng = np.random.default_rng(21)
+    L = np.diag(s.box_matrix)
+    V = float(np.prod(L))
+    n1 = int(s.topo.atoms_in_res[ta])
+    tmpl = s.all_sites(ta)[0] - s.all_sites(ta)[0].mean(axis=0)
+    rep = np.arange(R, dtype=np.int32)
+    t = np.full(R, ta, np.int32)
+    n_acc = 0
+    for step in range(14):
+        nm = np.array([A_.num_molecules(r, ta) for r in range(R)])
+        assert np.array_equal(nm, [B_.num_molecules(r, ta) for r in range(R)])
+        move = rng.integers(1, 5, R).astype(np.int32)
+        move[nm <= 2] = 3
+        move[nm >= caps[ta] - 1] = 4
+        m = (rng.random(R) * nm).astype(np.int32)
+        kinds = np.where(move <= 2, MGPU_MOVE, np.where(move == 3, MGPU_CREATION, MGPU_DELETION)).astype(np.int32)
+        u5 = rng.random((R, 5))
+        au = rng.random(R)
+        phi = 30.0 / V
+        pref = np.where(move <= 2, 1.0, np.where(move == 3, phi * V / (nm + 1.0), nm / (phi * V)))
+        pref = pref * np.exp(rng.normal(0.0, 2.0, R))            # spread the outcomes: both answers occur
+        if built:
+            oa, na = A_.move_trial(rep, t, m, move, u5, 0.8, 0.7)
+            acc_h = _decide_host(oa, na, au, pref, T)
+            A_.commit_lane(0, rep, t, m, kinds, acc_h)
+            ob, nb, acc_d = B_.move_trial_decide(rep, t, m, move, u5, 0.8, 0.7, au, pref, T)
+        else:
+            cur = [A_.get_molecules(r, ta) for r in range(R)]
+            rows = np.zeros((R, n1, 3))
+            for r in range(R):
+                if move[r] == 3:
+                    rows[r] = tmpl + (s.bounds_lo + L * u5[r, :3])
+                else:
+                    rows[r] = cur[r][m[r]] + (u5[r, :3] - 0.5) * (0.8 if move[r] <= 2 else 0.0)
+            oa, na = A_.gcmc_trial(rep, t, m, kinds, rows)
+            acc_h = _decide_host(oa, na, au, pref, T)
+            A_.commit_lane(0, rep, t, m, kinds, acc_h)
+            ob, nb, acc_d = B_.gcmc_trial_decide(rep, t, m, kinds, rows, au, pref, T)
+        assert np.array_equal(oa, ob) and np.array_equal(na, nb), step
+        assert np.array_equal(acc_h, acc_d), (step, acc_h, acc_d)
+        n_acc += int(acc_d.sum())
+        for r in range(R):
+            assert A_.num_molecules(r, ta) == B_.num_molecules(r, ta)
+    assert 0.2 * 14 * R < n_acc < 0.8 * 14 * R
+    for r in range(R):
+        assert np.array_equal(A_.get_molecules(r, ta), B_.get_molecules(r, ta))
+        assert np.array_equal(A_.structure_factor(r), B_.structure_factor(r))
+        if built:
+            ca, fa = A_.get_frames(r, ta)
+            cb, fb = B_.get_frames(r, ta)
+            assert np.array_equal(ca, cb) and np.array_equal(fa, fb)
+    # a second candidate on a replica is refused (the workgroups commit independently)
+    with pytest.raises(Exception):
+        if built:
+            B_.move_trial_decide([0, 0], [ta, ta], [0, 1], [1, 1], np.zeros((2, 5)), 0.8, 0.7, [0.5, 0.5], [1.0, 1.0], T)
+        else:
+            B_.gcmc_trial_decide([0, 0], [ta, ta], [0, 1], [MGPU_MOVE] * 2, np.zeros((2, n1, 3)), [0.5, 0.5], [1.0, 1.0], T)
+    for e in engines:
+        e.close()
