@@ -332,14 +332,19 @@ WORKLOADS = {
     # device_build: the engine keeps the molecules' frames and builds the trial geometry itself (no host mirror, no candidate
     # rows staged; measured round 3, SPC/E: 1 / 2 / 6 host threads 5.25 / 7.02 / 7.41 M host-built, 7.24 / 7.31 / 7.32 M
     # device-built -- one host thread per GPU then keeps the GPU busy)
-    "spce": dict(replicas=8192, lanes=4, drivers=1, threads=6, device_build=1, config="metric workload: 10 125-atom SPC/E box (configs[1] recipe at 15^3)"),
+    # device_accept: the engine also applies the acceptance rule behind the k sweep and commits accepted candidates in the same
+    # workgroup (mgpu_move_trial_decide_submit): no commit launch, no second upload, no host commit phase.  Host threads,
+    # measured with it (round 3, 16-CPU box; drivers x team): SPC/E 1 x 2 / 1 x 4 / 2 x 2 / 3 x 2 = 7.59 / 7.60 / 7.34 / 7.33 M
+    # (GPU-bound: one driver); CO2 1 x 4 / 2 x 2 / 3 x 2 / 2 x 4 = 13.4 / 21.9 / 21.5 / 19.9 M; framework + water 1 x 4 / 2 x 2 /
+    # 3 x 2 / 2 x 4 = 3.7 / 6.27 / 6.12 / 4.71 M -- two drivers with a team of two; larger teams lose to their fork / join.
+    "spce": dict(replicas=8192, lanes=4, drivers=1, threads=4, device_build=1, device_accept=1, config="metric workload: 10 125-atom SPC/E box (configs[1] recipe at 15^3)"),
     # the grand-canonical boxes are small (a few hundred atoms): per lane step the fixed host costs (OpenMP regions, HIP calls)
     # weigh as much as the kernels, so they run MANY chains (measured round 3, co2_gcmc, one driver thread: 2048 x 2 lanes
     # 5.4 M, 8192 x 4 6.6 M, 8192 x 2 11.2 M, 16384 x 2 13.7 M accepted moves/s) and TWO host driver threads sharing four
-    # lanes (16384 x 4 lanes, 8 threads: 19.8 M; the SPC/E box is GPU-bound and gains nothing from a second driver)
-    "co2_gcmc": dict(replicas=16384, lanes=4, drivers=2, threads=8, device_build=1, config="configs[2]: GCMC of CO2 in a 50 A box, insertion / deletion at one fugacity"),
-    "framework_water": dict(replicas=8192, lanes=4, drivers=2, threads=8, device_build=1, config="configs[3] stand-in: 2208-atom framework + 4-site water, full move set"),
-    "co2_isotherm": dict(replicas=16384, lanes=4, drivers=2, threads=8, device_build=1, config="configs[4]: 8 fugacity points dealt over the ranks"),
+    # lanes (the SPC/E box is GPU-bound and gains nothing from a second driver)
+    "co2_gcmc": dict(replicas=16384, lanes=4, drivers=2, threads=4, device_build=1, device_accept=1, config="configs[2]: GCMC of CO2 in a 50 A box, insertion / deletion at one fugacity"),
+    "framework_water": dict(replicas=8192, lanes=4, drivers=2, threads=4, device_build=1, device_accept=1, config="configs[3] stand-in: 2208-atom framework + 4-site water, full move set"),
+    "co2_isotherm": dict(replicas=16384, lanes=4, drivers=2, threads=4, device_build=1, device_accept=1, config="configs[4]: 8 fugacity points dealt over the ranks"),
 }
 
 
@@ -362,6 +367,10 @@ def main():
     ap.add_argument("--drivers", type=int, default=None,
                     help="host driver threads of the Fortran farm that share the lanes, each with a team of host-threads / drivers "
                          "(default 1 for SPC/E, 2 for the grand-canonical workloads)")
+    ap.add_argument("--device-accept", type=int, default=None, choices=[0, 1],
+                    help="1: the engine applies the acceptance rule behind the k sweep and commits accepted candidates itself "
+                         "(mgpu_move_trial_decide_submit; needs --device-build 1); 0: the Fortran driver decides and commits "
+                         "(default: the workload's setting)")
     ap.add_argument("--device-build", type=int, default=None, choices=[0, 1],
                     help="1: the engine keeps the molecules' frames and builds the trial moves on the device (no host mirror, no "
                          "candidate rows staged); 0: the Fortran driver builds them from its mirror (default: see WORKLOADS)")
@@ -452,8 +461,11 @@ def main():
         sys.exit("bench.py: the grand-canonical workloads run on the Fortran farm")
     if args.device_build is None:
         args.device_build = WORKLOADS[wl].get("device_build", 0)
+    if args.device_accept is None:
+        args.device_accept = WORKLOADS[wl].get("device_accept", 0)
+    args.device_accept = int(bool(args.device_accept and args.device_build))
     kw = dict(n_threads=args.host_threads, n_lanes=args.lanes, n_drivers=args.drivers,
-              device_build=bool(args.device_build)) if args.host == "fortran" else {}
+              device_build=bool(args.device_build), device_accept=bool(args.device_accept)) if args.host == "fortran" else {}
     R = args.replicas
     iso_pts, fug_grid, point_of_chain = None, None, None
     t_act, p_move, fug_one = 0, 1.0, None        # active residue type, share of translation + rotation, the fugacity
@@ -689,7 +701,10 @@ def main():
             fresh = bool(pmc) and not pmc["stale"] and pmc.get("hbm_bytes_per_eval") is not None
             gbs = bytes_k_eval * evals_rank / (ms_rec * 1e-3) / 1e9 if ms_rec else None
             k_item_bytes = pmc["hbm_bytes_per_eval"] * pmc["evals"] / pmc["candidates"] if fresh and pmc.get("candidates") else 0.0
-            roof = {"bound": "hbm", "kernel": "recip_rows_kernel<false,true> (k sweep: old and new reciprocal energy of every candidate from one pass over A(k))",
+            roof = {"bound": "hbm", "kernel": ("recip_rows_kernel<false,true,true> (k sweep: old and new reciprocal energy of every candidate from one pass "
+                                               "over A(k); its workgroup then applies the acceptance rule and commits an accepted candidate -- a second "
+                                               "pass A <- A + delta -- so avg_launch_us covers sweep AND commit)") if args.device_accept else
+                                              "recip_rows_kernel<false,true> (k sweep: old and new reciprocal energy of every candidate from one pass over A(k))",
                     "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS if gbs else None,
                     "achieved_basis": f"ALGORITHMIC bytes: 52 Nk = {bytes_k_eval:.0f} B per evaluation (SURVEY 8(d)) x "
                                       f"{evals_per_k_launch:.0f} evaluations per launch / the k sweep's average launch time (dispatch events "
@@ -706,7 +721,8 @@ def main():
                                   "frac": bytes_k_eval * iso_gc["evaluations"] / (iso_gc["k_sweep_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                   "measured_traffic_GBs": k_item_bytes * iso_gc["candidates"] / (iso_gc["k_sweep_us"] * 1e-6) / 1e9 if fresh else None,
                                   "measured_traffic_frac": k_item_bytes * iso_gc["candidates"] / (iso_gc["k_sweep_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS if fresh else None,
-                                  "note": "one lane's batch launched alone after the timed region; measured_traffic = the PMC bytes per "
+                                  "note": "one lane's batch launched alone after the timed region, evaluation only (no acceptance, no commit "
+                                          "pass); measured_traffic = the PMC bytes per "
                                           "CANDIDATE (one pass over A(k) serves both evaluations of a move; A(k) is 32 B per +-kz pair "
                                           "and is only read by the k sweep: a third of the 52 Nk algorithmic figure) over the same time"} if iso_gc else None),
                     "job_frac": evals_rank * (bytes_pair_eval + bytes_k_eval) / elapsed / 1e9 / HBM_PEAK_GBS,
@@ -725,6 +741,7 @@ def main():
                        "baseline_config": WORKLOADS[wl]["config"],
                        "replicas_per_gpu": R, "host_driver": args.host, "host_threads": args.host_threads if args.host == "fortran" else 1,
                        "lanes": n_lanes, "host_drivers": args.drivers, "trial_geometry": "device-built" if args.device_build else "host-built",
+                       "acceptance": "device (k sweep decides and commits)" if args.device_accept else "host driver + commit launch",
                        "host_cores": pinned, "moves": moves,
                        "trials_per_step": R * world, "parallelism": f"replicas x{world}"},
             "trial_moves_per_s": tot_trials / elapsed,

@@ -227,6 +227,26 @@ module maniac_gpu
             real(c_double), value :: translation_step, rotation_step
             integer(c_int) :: rc
         end function
+        ! the same trials with the acceptance test and the commit of accepted candidates on the device
+        function mgpu_move_trial_decide_submit(e, lane, n, replica, t, m, move, u, translation_step, rotation_step, &
+                                               accept_u, accept_pref, temperature) &
+                bind(C, name="mgpu_move_trial_decide_submit") result(rc)
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: e
+            integer(c_int), value :: lane, n
+            integer(c_int), intent(in) :: replica(*), t(*), m(*), move(*)
+            real(c_double), intent(in) :: u(*), accept_u(*), accept_pref(*)
+            real(c_double), value :: translation_step, rotation_step, temperature
+            integer(c_int) :: rc
+        end function
+        function mgpu_trial_decide_wait(e, lane, old_energy, new_energy, accepted) bind(C, name="mgpu_trial_decide_wait") result(rc)
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: e
+            integer(c_int), value :: lane
+            real(c_double), intent(out) :: old_energy(*), new_energy(*)
+            integer(c_int), intent(out) :: accepted(*)
+            integer(c_int) :: rc
+        end function
         ! pinned staging of a lane's next trial: candidate rows built in place are not copied again
         function mgpu_lane_site_buffer(e, lane, n_max, site_stride, sites) bind(C, name="mgpu_lane_site_buffer") result(rc)
             import :: c_ptr, c_int

@@ -74,6 +74,7 @@ module mc_farm
         real(real64), allocatable :: new_com(:, :), new_off(:, :, :)
         integer(c_int), allocatable :: mvc(:)              ! device-built trials: move code per candidate
         real(real64), allocatable :: u5(:, :)              ! ... and its five uniform numbers (5, n)
+        real(real64), allocatable :: acc_u(:), acc_pref(:) ! device-decided trials: the test's number and prefactor
         real(real64), allocatable :: old_e(:), new_e(:)    ! (ne * nc) rows packed by the engine
         real(real64), allocatable :: u(:, :)
         ! per-lane accumulators (lanes may run on different host threads), folded into the farm's totals by mfarm_run
@@ -110,6 +111,7 @@ module mc_farm
         ! (mgpu_move_trial_submit): the host keeps counts, energies and the random stream -- no mirror of the coordinates,
         ! no gathers from it, no candidate rows to stage
         logical :: device_build = .false.
+        logical :: device_accept = .false.       ! ... and the engine applies the acceptance rule and commits (mfarm_configure(2))
         integer(int64), allocatable :: cxs(:, :)           ! (4, R) xoshiro256+ state of every chain
     end type farm_state
 
@@ -120,6 +122,7 @@ module mc_farm
     type(farm_state), save, target :: farms(0:MAX_FARMS - 1)
     type(farm_state), pointer, save :: F => farms(0)
     logical, save :: want_device_build = .false.           ! consumed by the next mfarm_create (mfarm_configure)
+    logical, save :: want_device_accept = .false.
 
     interface
         function c_posix_memalign(ptr, alignment, bytes) bind(C, name="posix_memalign") result(rc)
@@ -250,6 +253,7 @@ contains
         end do
         F%cap_total = tot
         F%device_build = want_device_build
+        F%device_accept = want_device_build .and. want_device_accept
         if (.not. F%device_build) call alloc_mirror(3 + 3 * max_n1, tot, int(n_replicas))
         allocate(F%energy(5, n_replicas))
         F%n_threads = max(1, int(n_threads))
@@ -357,7 +361,7 @@ contains
         allocate(L%rep(n), L%t(n), L%m(n), L%kind(n), L%accept(n), L%ia(n), L%move(n), L%cidx(n))
         allocate(L%sel_ia(n), L%sel_mv(n), L%sel_slot(n))
         allocate(L%new_com(3, n), L%new_off(3, max_n1, n))
-        allocate(L%old_e(5 * n), L%new_e(5 * n), L%u(NRAND, n), L%mvc(n), L%u5(5, n))
+        allocate(L%old_e(5 * n), L%new_e(5 * n), L%u(NRAND, n), L%mvc(n), L%u5(5, n), L%acc_u(n), L%acc_pref(n))
         rc = mgpu_lane_site_buffer(F%engine, int(g, c_int), int(n, c_int), int(max_n1, c_int), staged)
         if (rc == MGPU_OK .and. c_associated(staged)) then
             call c_f_pointer(staged, L%sites, [3, max_n1, n])
@@ -534,6 +538,21 @@ contains
                 do d = 1, 5
                     L%u5(d, j) = L%u(3 + d, i)
                 end do
+                if (F%device_accept) then
+                    ! what mc_acceptance_probability multiplies exp(-dE / T) by (monte_carlo_utils.f90:184-226), formed as
+                    ! resolve_and_commit forms it, and the test's number
+                    r = L%rep(j) + 1
+                    ia = L%ia(j)
+                    L%acc_u(j) = L%u(9, i)
+                    select case (L%move(j))
+                    case (MV_CREATION)
+                        L%acc_pref(j) = F%fugacity(ia, r) * F%volume / real(F%cnt(ia, r) + 1, real64)
+                    case (MV_DELETION)
+                        L%acc_pref(j) = (real(F%cnt(ia, r) - 1, real64) + 1.0_real64) / (F%fugacity(ia, r) * F%volume)
+                    case default
+                        L%acc_pref(j) = 1.0_real64
+                    end select
+                end if
                 cycle
             end if
             r = L%rep(j) + 1
@@ -607,7 +626,10 @@ contains
         !$omp end parallel
         call system_clock(c1)
         if (L%nc > 0) then
-            if (F%device_build) then
+            if (F%device_accept) then
+                rc = mgpu_move_trial_decide_submit(F%engine, int(g, c_int), int(L%nc, c_int), L%rep, L%t, L%m, L%mvc, L%u5, &
+                                                   F%translation_step, F%rotation_step, L%acc_u, L%acc_pref, F%temperature)
+            else if (F%device_build) then
                 rc = mgpu_move_trial_submit(F%engine, int(g, c_int), int(L%nc, c_int), L%rep, L%t, L%m, L%mvc, L%u5, &
                                             F%translation_step, F%rotation_step)
             else if (F%gcmc) then
@@ -637,12 +659,16 @@ contains
         integer(int64) :: c0, c1, c2, c3
         integer(int64) :: k_tt, k_t, k_rt, k_r, k_ct, k_c, k_dt, k_d
         real(real64) :: delta_e, probability, nn, phi, e_old, e_new
+        logical :: yes
         type(lane_buffers), pointer :: L
         L => F%lane(g)
         rc = MGPU_OK
         if (L%nc == 0) return
         call system_clock(c0)
-        if (F%gcmc .or. F%device_build) then
+        if (F%device_accept) then
+            ne = 5
+            rc = mgpu_trial_decide_wait(F%engine, int(g, c_int), L%old_e, L%new_e, L%accept)   ! rows of 5 + the outcomes
+        else if (F%gcmc .or. F%device_build) then
             ne = 5
             rc = mgpu_gcmc_trial_wait(F%engine, int(g, c_int), L%old_e, L%new_e)   ! rows of 5
         else
@@ -653,7 +679,7 @@ contains
         call system_clock(c1)
         k_tt = 0; k_t = 0; k_rt = 0; k_r = 0; k_ct = 0; k_c = 0; k_dt = 0; k_d = 0
         !$omp parallel do num_threads(F%team) schedule(static) &
-        !$omp& private(i, k, r, ia, slot, n1, delta_e, probability, nn, phi, last, base, o, e_old, e_new) &
+        !$omp& private(i, k, r, ia, slot, n1, delta_e, probability, nn, phi, last, base, o, e_old, e_new, yes) &
         !$omp& reduction(+:k_tt, k_t, k_rt, k_r, k_ct, k_c, k_dt, k_d)
         do j = 1, L%nc
             i = L%cidx(j)
@@ -669,6 +695,20 @@ contains
                 e_new = e_new + L%new_e(o + k)
             end do
             delta_e = e_new - e_old
+            if (F%device_accept) then
+                ! the engine applied the rule (same totals, same prefactor, same number) and committed: L%accept holds the outcome
+                select case (L%move(j))
+                case (MV_CREATION)
+                    k_ct = k_ct + 1
+                case (MV_DELETION)
+                    k_dt = k_dt + 1
+                case (MV_TRANSLATION)
+                    k_tt = k_tt + 1
+                case default
+                    k_rt = k_rt + 1
+                end select
+                yes = L%accept(j) /= 0
+            else
             select case (L%move(j))
             case (MV_CREATION)
                 nn = real(F%cnt(ia, r) + 1, real64)                        ! N already incremented, create_molecule.f90:64
@@ -687,7 +727,9 @@ contains
                 probability = min(1.0_real64, exp(-delta_e / F%temperature))
                 k_rt = k_rt + 1
             end select
-            if (L%u(9, i) <= probability) then
+            yes = L%u(9, i) <= probability
+            end if
+            if (yes) then
                 L%accept(j) = 1
                 slot = L%m(j) + 1
                 select case (L%move(j))
@@ -725,8 +767,10 @@ contains
         L%accepted = L%accepted + k_t + k_r + k_c + k_d
         L%trials = L%trials + L%nc
         call system_clock(c2)
-        rc = mgpu_commit_submit(F%engine, int(g, c_int), int(L%nc, c_int), L%rep, L%t, L%m, L%kind, &
-                                c_null_ptr, int(F%max_n1, c_int), L%accept)
+        if (.not. F%device_accept) then
+            rc = mgpu_commit_submit(F%engine, int(g, c_int), int(L%nc, c_int), L%rep, L%t, L%m, L%kind, &
+                                    c_null_ptr, int(F%max_n1, c_int), L%accept)
+        end if
         call system_clock(c3)
         L%nc = 0
         L%ticks(3) = L%ticks(3) + (c1 - c0)
@@ -866,10 +910,13 @@ contains
     end function mfarm_select
 
     ! device_build /= 0: the NEXT farm created builds its trial moves on the device from the frames the caller uploaded with
-    ! mgpu_replica_set_frames (orthorhombic boxes); 0: on the host from its mirror (the default)
+    ! mgpu_replica_set_frames (orthorhombic boxes); 0: on the host from its mirror (the default); 2: the engine also applies
+    ! the acceptance rule and commits accepted candidates itself (mgpu_move_trial_decide_submit) -- the farm then only
+    ! draws the numbers, selects the moves and keeps its counts, energies and counters in step with the outcomes
     subroutine mfarm_configure(device_build) bind(C, name="mfarm_configure")
         integer(c_int), value :: device_build
         want_device_build = device_build /= 0
+        want_device_accept = device_build == 2               ! 2: the engine also decides and commits
     end subroutine mfarm_configure
 
     ! Driver threads of mfarm_run (1: the calling thread drives all lanes in lock step; d > 1: d threads, each driving

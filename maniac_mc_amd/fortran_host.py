@@ -76,7 +76,7 @@ class FortranFarm:
     def __init__(self, system: System, n_replicas: int, device: int = 0, seed: int = 1,
                  translation_step: float = 0.3, rotation_step: float = 0.3, p_translation: float = 0.5,
                  rng_kind: int = 1, n_threads: int = 8, mol_capacity=None, gcmc=None,
-                 n_lanes: int = 2, n_drivers: int = 1, device_build: bool = False):
+                 n_lanes: int = 2, n_drivers: int = 1, device_build: bool = False, device_accept: bool = False):
         self.H = lib()
         # mc_farm.f90 keeps up to MAX_FARMS farms; every call below selects this farm's slot first
         free = [k for k in range(FortranFarm.MAX_FARMS) if k not in FortranFarm._slots]
@@ -124,7 +124,9 @@ class FortranFarm:
         self.slot = free[0]
         FortranFarm._slots[self.slot] = self
         self._select()
-        self.H.mfarm_configure(C.c_int(1 if self.device_build else 0))
+        # device_accept (with device_build): the engine also applies the acceptance rule and commits accepted candidates
+        self.device_accept = bool(device_accept) and self.device_build
+        self.H.mfarm_configure(C.c_int((2 if self.device_accept else 1) if self.device_build else 0))
         rc = self.H.mfarm_create(self.eng.h, C.c_int(self.R), C.c_int(len(active)), self.active.ctypes.data_as(_ip),
                                  n1.ctypes.data_as(_ip), nmol.ctypes.data_as(_ip), cap.ctypes.data_as(_ip),
                                  C.c_int(max_n1), com.ctypes.data_as(_dp), off.ctypes.data_as(_dp),

@@ -281,3 +281,48 @@ def test_two_farms_in_one_process():
     a.run(5)
     assert a.trials + a.skipped == 6 * 50
     a.close()
+
+
+@pytest.mark.parametrize("case", ["spce_nvt", "co2_gcmc", "framework_water_gcmc", "mixture_nvt"])
+def test_device_decided_farm_is_the_host_decided_farm(case):
+    """mfarm_configure(2): the engine applies the acceptance rule behind the k sweep and commits accepted candidates
+    itself (mgpu_move_trial_decide_submit); the Fortran driver only draws numbers, selects moves and follows the
+    outcomes.  Same seeds, same chains: counters, counts, running energies, coordinates and A(k) must be those of the
+    farm that decides on the host and commits with mgpu_commit_submit -- bit for bit."""
+    from maniac_mc_amd.fortran_host import FortranFarm
+    kw = dict(seed=23, n_threads=4, n_lanes=3, device_build=True)
+    if case == "spce_nvt":
+        s, R, steps = synth.spce_box(6, seed=3), 9, 60
+        kw.update(translation_step=0.4, rotation_step=0.4)
+    elif case == "mixture_nvt":
+        s, R, steps = synth.mixture_box(seed=4), 6, 60
+        kw.update(translation_step=0.4, rotation_step=0.4)
+    elif case == "co2_gcmc":
+        s, R, steps = synth.co2_box(20, seed=13), 12, 150
+        kw.update(translation_step=1.0, rotation_step=0.6, mol_capacity=[90],
+                  gcmc=dict(p_translation=0.2, p_rotation=0.2, fugacity=np.repeat([10.0, 30.0], 6) / 50.0 ** 3))
+    else:
+        s, R, steps = synth.framework_water_box(n_water=12, n_frame=300, L=24.0, seed=7), 8, 120
+        kw.update(translation_step=0.5, rotation_step=0.5, mol_capacity=[1, 60],
+                  gcmc=dict(p_translation=0.25, p_rotation=0.25, fugacity=20.0 / 24.0 ** 3))
+    farms = [FortranFarm(s, R, device_accept=da, **kw) for da in (False, True)]
+    assert farms[1].device_accept and not farms[0].device_accept
+    for f in farms:
+        f.run(steps)
+    a, b = farms
+    assert a.trials == b.trials and a.accepted == b.accepted and a.skipped == b.skipped and a.accepted > 0
+    assert a.counters() == b.counters()
+    assert np.array_equal(a.counts(), b.counts())
+    for r in range(R):
+        assert np.array_equal(a.energy(r), b.energy(r)), r
+        assert np.array_equal(a.eng.structure_factor(r), b.eng.structure_factor(r)), r
+        for t in a.active:
+            assert a.eng.num_molecules(r, int(t)) == b.eng.num_molecules(r, int(t))
+            assert np.array_equal(a.eng.get_molecules(r, int(t)), b.eng.get_molecules(r, int(t)))
+    # and the device-decided farm is consistent with a from-scratch evaluation
+    for r in (0, R - 1):
+        e = b.eng.system_energy(r)
+        ref = np.array([e[k] for k in ("non_coulomb", "coulomb", "recip_coulomb", "ewald_self", "intra_coulomb")])
+        assert np.max(np.abs(b.energy(r) - ref)) < farm_tol(ref, steps), (r, b.energy(r) - ref)
+    for f in farms:
+        f.close()

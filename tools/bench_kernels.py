@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--json", default=None, help="also write the figures to this file")
     ap.add_argument("--kinds", choices=["workload", "moves", "insertions", "deletions"], default="workload",
                     help="override the workload's mix of trial kinds (diagnostics)")
+    ap.add_argument("--decide", action="store_true",
+                    help="the acceptance on the device (mgpu_gcmc_trial_decide_submit): the k sweep decides and commits; the "
+                         "outcomes are scripted through the prefactors (the same share of acceptances as the commit launch gets)")
     args = ap.parse_args()
     R = args.replicas
     s, eng, ta = build(args.workload, R, args.n_side)
@@ -114,6 +117,16 @@ def main():
             sites[cr] += (s.bounds_lo + L * rng.random((int(cr.sum()), 3)))[:, None, :] - sites[cr].mean(axis=1, keepdims=True)
         return kind, m, sites
 
+    def outcomes(kind):
+        if args.workload == "spce":
+            return (rng.random(R) < 0.7).astype(np.int32)
+        # keep every replica's count near n0: accept an insertion only below n0 + 4, a deletion only above n0 - 4
+        nm = np.array([eng.num_molecules(r, ta) for r in range(R)])
+        acc = (rng.random(R) < 0.6).astype(np.int32)
+        acc[(kind == _lib.MGPU_CREATION) & (nm >= n0 + 4)] = 0
+        acc[(kind == _lib.MGPU_DELETION) & (nm <= max(1, n0 - 4))] = 0
+        return acc
+
     kind, m, sites = batch()
     eng.gcmc_trial(rep, t, m, kind, sites)
     eng.profile_enable(True)
@@ -121,16 +134,14 @@ def main():
     evals = 0
     for _ in range(args.reps):
         kind, m, sites = batch()
-        eng.gcmc_trial(rep, t, m, kind, sites)
         evals += int(2 * (kind == _lib.MGPU_MOVE).sum() + (kind != _lib.MGPU_MOVE).sum())
-        if args.workload == "spce":
-            acc = (rng.random(R) < 0.7).astype(np.int32)
-        else:
-            # keep every replica's count near n0: accept an insertion only below n0 + 4, a deletion only above n0 - 4
-            nm = np.array([eng.num_molecules(r, ta) for r in range(R)])
-            acc = (rng.random(R) < 0.6).astype(np.int32)
-            acc[(kind == _lib.MGPU_CREATION) & (nm >= n0 + 4)] = 0
-            acc[(kind == _lib.MGPU_DELETION) & (nm <= max(1, n0 - 4))] = 0
+        if args.decide:
+            acc = outcomes(kind)
+            # prefactor 1e300: exp(-dE / T) * 1e300 >= 1 for any dE a liquid produces -> accepted; 0 -> rejected
+            _, _, got = eng.gcmc_trial_decide(rep, t, m, kind, sites, np.full(R, 0.5), np.where(acc == 1, 1e300, 0.0), 300.0)
+            continue
+        eng.gcmc_trial(rep, t, m, kind, sites)
+        acc = outcomes(kind)
         eng.commit_lane(0, rep, t, m, kind, acc)
     names = ["pair_sweep", "recip", "commit", "sfactor"]
     out = {}
@@ -146,7 +157,7 @@ def main():
             "sites_per_molecule": int(n1), "avg_us": out, "us_per_group": {k: v / args.reps for k, v in tot.items()},
             "pair_ns_per_eval": tot.get("pair_sweep", 0.0) / args.reps * 1e3 / ev,
             "recip_ns_per_eval": out.get("recip", 0.0) * 1e3 / ev,
-            "lib": os.path.basename(_lib.LIB_PATH), "nsplit": os.environ.get("MGPU_PAIR_NSPLIT", "auto"),
+            "acceptance": "device" if args.decide else "host + commit launch", "lib": os.path.basename(_lib.LIB_PATH), "nsplit": os.environ.get("MGPU_PAIR_NSPLIT", "auto"),
             "blocks_per_cu": os.environ.get("MGPU_PAIR_BLOCKS_PER_CU", "auto")}
     print(json.dumps(line))
     if args.json:

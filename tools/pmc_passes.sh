@@ -13,9 +13,10 @@ nsplit=${4:-}
 wl=${5:-spce}
 if [ -n "$nsplit" ]; then export MGPU_PAIR_NSPLIT=$nsplit; fi   # the engine constant the bench's engine uses at its replica count
 mkdir -p "$out"
+export PMC_EXTRA=${PMC_EXTRA---decide}    # the bench's default path: the k sweep decides and commits (PMC_EXTRA= for the separate commit launch)
 export TMPDIR=/tmp
 run() {  # name, counters
-    rocprofv3 --pmc $2 --kernel-trace --output-format csv -d "$out/${wl}_$1" -o "$1" -- python3 tools/bench_kernels.py --workload $wl --reps 3 --replicas $repl > "$out/${wl}_$1.log" 2>&1
+    rocprofv3 --pmc $2 --kernel-trace --output-format csv -d "$out/${wl}_$1" -o "$1" -- python3 tools/bench_kernels.py --workload $wl --reps 3 --replicas $repl $PMC_EXTRA > "$out/${wl}_$1.log" 2>&1
 }
 run sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"
 run sq2 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"
