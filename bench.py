@@ -654,7 +654,8 @@ def main():
             launch_tflops = evals_rank * flop_eval / (ms_pair * 1e-3) / 1e12 if ms_pair else None
             roof = {"bound": "valu", "bound_note": "fp64 vector issue (the contract's hbm / mfma do not apply: measured HBM-side "
                                                    "traffic is a fraction of the algorithmic bytes and there is no MFMA-shaped work; SURVEY 8(d))",
-                    "kernel": "pair_flat_kernel<4,...> (framework box: one software-pipelined loop over all units, single-state items)" if wl == "framework_water"
+                    "kernel": "pair_frozen_kernel<4,...> (framework box: 64 candidates in the lanes of a wave against chunks of 32 framework atoms "
+                              "held as scalars, then each lane's own adsorbates; frozen_finalize_kernel adds the chunk partials)" if wl == "framework_water"
                               else "pair_sweep_kernel<3,false,false,true,true> (old + new state of a trial move in one sweep, two-instruction fold)",
                     "achieved": job_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": job_tflops / FP64_VECTOR_PEAK_TFLOPS,

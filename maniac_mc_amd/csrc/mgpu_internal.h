@@ -34,13 +34,25 @@ int ewald_kvectors(const double rcp[9], double alpha, const int kmax[3], int nk,
 #define MGPU_COUL_M 6
 #endif
 constexpr int kCoulM = MGPU_COUL_M;
-constexpr int kCoulDeg = kCoulM == 7 ? 5 : 6;     // polynomial degree of a row
-constexpr int kCoulEmin = -2;    // table starts at r^2 = 2^-2 (r = 0.5 A); below it the slow path runs
+// 8 -> 256 rows per octave, degree-4 rows of 32 bytes (3 fp64 + 2 fp32 coefficients: TWO 16-byte LDS reads instead of three;
+// the same absolute error, 1.1e-15, as the degree-6 rows), table from r = 1 A
+constexpr int kCoulDeg = kCoulM == 8 ? 4 : (kCoulM == 7 ? 5 : 6);     // polynomial degree of a row
+constexpr int kCoulEmin = kCoulM == 8 ? 0 : -2;    // table starts at r^2 = 2^kCoulEmin (r = 0.5 A; 1 A); below it the slow path runs
+constexpr double kCoulSlowBelow = kCoulM == 8 ? 1.0 : 0.25;
+#if MGPU_COUL_M == 8
+struct CoulRow {
+    double c[3];
+    float c3, c4;
+};
+static_assert(sizeof(CoulRow) == 32, "CoulRow must be two 16-byte LDS reads");
+#else
 struct CoulRow {
     double c[5];
     float c5, c6;                // c6 unused (zero) for degree-5 rows
 };
 static_assert(sizeof(CoulRow) == 48, "CoulRow must be three 16-byte LDS reads");
+#endif
+constexpr int kCoulRowVec = sizeof(CoulRow) / 16;  // 16-byte LDS reads per row
 int build_coulomb_table(double alpha, double s_max, std::vector<CoulRow> &rows, int *idx_base);
 double coulomb_table_eval_host(const std::vector<CoulRow> &rows, int idx_base, double alpha, double s);
 

@@ -39,7 +39,7 @@ constexpr int kBlock = 256;       // threads per workgroup = 4 waves, one per SI
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kSiteChunk = 32;    // candidate sites staged in LDS per pass (generic path)
 #ifndef MGPU_PAIR_BLOCK
-#define MGPU_PAIR_BLOCK (MGPU_COUL_M == 7 ? 1024 : 512)   // 128 rows per octave: one workgroup per CU shares the (larger) table
+#define MGPU_PAIR_BLOCK (MGPU_COUL_M >= 7 ? 1024 : 512)   // 128 rows per octave: one workgroup per CU shares the (larger) table
 #endif
 #ifndef MGPU_PAIR_MINWAVES
 #define MGPU_PAIR_MINWAVES 4   // <= 128 VGPRs: two 8-wave workgroups per CU (measured best, tools/bench_kernels.py)
@@ -200,7 +200,15 @@ __device__ __forceinline__ double coul_lds(double s, const char *__restrict__ ta
     constexpr int kMant = (1 << (20 - kCoulM)) - 1;
     const double s0 = __hiloint2double(hi & ~kMant, 0);                  // the row's first s: low mantissa bits cleared
     const double t = s - s0;                                             // exact; rows are expanded in it
-    const double2 *r = reinterpret_cast<const double2 *>(tab + __umul24(row, 48));
+    const double2 *r = reinterpret_cast<const double2 *>(tab + __umul24(row, (unsigned)sizeof(CoulRow)));
+#if MGPU_COUL_M == 8
+    const double2 c01 = r[0], c2f = r[1];
+    double p = fma((double)__int_as_float(__double2hiint(c2f.y)), t, (double)__int_as_float(__double2loint(c2f.y)));
+    p = fma(p, t, c2f.x);
+    p = fma(p, t, c01.y);
+    p = fma(p, t, c01.x);
+    return p;
+#else
     const double2 c01 = r[0], c23 = r[1], c4f = r[2];
     const double c5 = (double)__int_as_float(__double2loint(c4f.y));
     double p = c5;
@@ -211,6 +219,7 @@ __device__ __forceinline__ double coul_lds(double s, const char *__restrict__ ta
     p = fma(p, t, c01.y);
     p = fma(p, t, c01.x);
     return p;
+#endif
 }
 
 // r < 0.5 A (never reached by a physical configuration): direct evaluation.  GUARD: CoulombEnergy's
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
     __shared__ double s_site[NSLAB * 4];
     __shared__ int s_sty[NSLAB];
 
-    for (int i = threadIdx.x; i < (bx.coul_last_row + 1) * 3; i += kPairBlock)
+    for (int i = threadIdx.x; i < (bx.coul_last_row + 1) * kCoulRowVec; i += kPairBlock)
         reinterpret_cast<double2 *>(s_coul)[i] = reinterpret_cast<const double2 *>(coul_tab_g)[i];
     const int nt = tp.n_types;
     for (int i = threadIdx.x; i < nt * nt; i += kPairBlock) s_pair[i] = pair_tab[i];
@@ -419,7 +428,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                             if (any_below) {   // r < 0.5 A somewhere in the wave: rare slow path
 #pragma unroll
                                 for (int s = 0; s < NREG; ++s)
-                                    if ((ALL_C || c_on[s % NTY]) && r2[s] < 0.25) g[s] = coul_slow(r2[s], bx.alpha, ORDERED);
+                                    if ((ALL_C || c_on[s % NTY]) && r2[s] < kCoulSlowBelow) g[s] = coul_slow(r2[s], bx.alpha, ORDERED);
                             }
 #pragma unroll
                             for (int s = 0; s < NREG; ++s)
@@ -575,7 +584,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
     __shared__ int4 s_plane[kPairWaves * kFlatMaxPlanes]; // per wave: the plane table of its current work unit
 
     if (threadIdx.x < kMaxGrp) s_grp[threadIdx.x] = make_int4(tp.grp_start[threadIdx.x], tp.grp_cnt[threadIdx.x], tp.grp_ty[threadIdx.x], 0);
-    for (int i = threadIdx.x; i < (bx.coul_last_row + 1) * 3; i += kPairBlock)
+    for (int i = threadIdx.x; i < (bx.coul_last_row + 1) * kCoulRowVec; i += kPairBlock)
         reinterpret_cast<double2 *>(s_coul)[i] = reinterpret_cast<const double2 *>(coul_tab_g)[i];
     const int nt = tp.n_types;
     for (int i = threadIdx.x; i < nt * nt; i += kPairBlock) s_pair[i] = pair_tab[i];
@@ -757,7 +766,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                 if (any_below) {   // r < 0.5 A somewhere in the wave: rare slow path
 #pragma unroll
                     for (int s = 0; s < NREG; ++s)
-                        if (r2[s] < 0.25) g[s] = coul_slow(r2[s], bx.alpha, false);
+                        if (r2[s] < kCoulSlowBelow) g[s] = coul_slow(r2[s], bx.alpha, false);
                 }
 #pragma unroll
                 for (int s = 0; s < NREG; ++s) acc[s] = fma(wq, g[s], acc[s]);
@@ -805,7 +814,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
 // sigma^2) of the candidate's sites against the atom's type are reloaded (LDS broadcast) only when the type changes: the
 // frozen layout keeps atoms of one type together.  The few OTHER atoms of a framework box (the adsorbates of each lane's
 // own replica) follow in the same wave with per-lane coordinates, so one kernel yields the item's whole pair energy.
-// Work = (item group, chunk); every (item, chunk) writes one partial
+// Work = (item group, chunk); every (item, chunk) writes one partial (scratch laid out [chunk][entry])
 // {e_lj, e_coul} per state into `scratch`, and frozen_finalize_kernel adds a item's chunks in order -- one extra record
 // per entry for the host's ordered sum.  Items: PairItem of ONE residue type (the engine checks), unordered, orthorhombic.
 // ------------------------------------------------------------------------------------------
@@ -820,7 +829,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
     constexpr int NREG = NTY * NST;
     extern __shared__ __attribute__((aligned(16))) char s_coul[];     // (coul_last_row + 1) x 48 B
     __shared__ double2 s_pair[kMaxTypes * kMaxTypes];
-    for (int i = threadIdx.x; i < (bx.coul_last_row + 1) * 3; i += kPairBlock)
+    for (int i = threadIdx.x; i < (bx.coul_last_row + 1) * kCoulRowVec; i += kPairBlock)
         reinterpret_cast<double2 *>(s_coul)[i] = reinterpret_cast<const double2 *>(coul_tab_g)[i];
     const int nt = tp.n_types;
     for (int i = threadIdx.x; i < nt * nt; i += kPairBlock) s_pair[i] = pair_tab[i];
@@ -923,7 +932,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                 if (any_below) {   // r < 0.5 A for some lane: rare slow path
 #pragma unroll
                     for (int s = 0; s < NREG; ++s)
-                        if (r2[s] < 0.25) g[s] = coul_slow(r2[s], bx.alpha, false);
+                        if (r2[s] < kCoulSlowBelow) g[s] = coul_slow(r2[s], bx.alpha, false);
                 }
 #pragma unroll
                 for (int s = 0; s < NREG; ++s) acc[s] = fma(qj, g[s], acc[s]);
@@ -981,7 +990,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                         if (any_below) {
 #pragma unroll
                             for (int s = 0; s < NREG; ++s)
-                                if (ok && r2[s] < 0.25) g[s] = coul_slow(r2[s], bx.alpha, false);
+                                if (ok && r2[s] < kCoulSlowBelow) g[s] = coul_slow(r2[s], bx.alpha, false);
                         }
 #pragma unroll
                         for (int s = 0; s < NREG; ++s) acc[s] = ok ? fma(qj, g[s], acc[s]) : acc[s];
@@ -1008,7 +1017,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                 double ec = 0.0;
 #pragma unroll
                 for (int s = 0; s < NTY; ++s) ec = fma(rq[s], acc[st * NTY + s], ec);
-                scratch[((size_t)item_id * NST + st) * n_chunks + chunk] = make_double2(elj[st], ec);
+                scratch[(size_t)chunk * ((size_t)n_items * NST) + ((size_t)item_id * NST + st)] = make_double2(elj[st], ec);   // [chunk][entry]: the lanes' stores coalesce
             }
         }
     }
@@ -1019,7 +1028,17 @@ __global__ void frozen_finalize_kernel(const double2 *__restrict__ scratch, int 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_entries) return;
     double a = 0.0, b = 0.0;
-    for (int c = 0; c < n_chunks; ++c) { const double2 p = scratch[(size_t)i * n_chunks + c]; a += p.x; b += p.y; }
+    // the adds keep chunk order; the loads of 16 chunks are in flight together (one at a time this was a 69-link latency
+    // chain: 20 us for a kernel that moves 3 MB)
+    int c = 0;
+    for (; c + 16 <= n_chunks; c += 16) {
+        double2 p[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) p[k] = scratch[(size_t)(c + k) * n_entries + i];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { a += p[k].x; b += p[k].y; }
+    }
+    for (; c < n_chunks; ++c) { const double2 p = scratch[(size_t)c * n_entries + i]; a += p.x; b += p.y; }
     extra[i] = make_double2(a, b);
 }
 

@@ -27,6 +27,9 @@ python bench.py --host-threads 2 --no-cpu-baseline > $out/bench_spce_T2.json 2> 
 python tools/chain_speed.py --blocks 2 --steps 1500 > $out/chain_speed.txt 2>&1
 for wl in spce co2_gcmc framework_water; do python tools/bench_kernels.py --replicas 2048 --reps 5 --workload $wl > $out/k_${wl}_R2048.json; done
 python tools/bench_kernels.py --replicas 4096 --reps 5 --workload co2_gcmc > $out/k_co2_gcmc_R4096.json
+# the same launch groups with the acceptance on the device (the k sweep decides and commits: the farm's default)
+for wl in spce framework_water; do python tools/bench_kernels.py --replicas 2048 --reps 5 --workload $wl --decide > $out/k_${wl}_R2048_decide.json; done
+python tools/bench_kernels.py --replicas 4096 --reps 5 --workload co2_gcmc --decide > $out/k_co2_gcmc_R4096_decide.json
 find $out -name '*kernel_trace.csv' -delete
 find $out -name '*counter_collection.csv' -size +2M -delete
 du -a $out | sort -n | tail -5
