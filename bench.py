@@ -332,19 +332,21 @@ WORKLOADS = {
     # device_build: the engine keeps the molecules' frames and builds the trial geometry itself (no host mirror, no candidate
     # rows staged; measured round 3, SPC/E: 1 / 2 / 6 host threads 5.25 / 7.02 / 7.41 M host-built, 7.24 / 7.31 / 7.32 M
     # device-built -- one host thread per GPU then keeps the GPU busy)
-    # device_accept: the engine also applies the acceptance rule behind the k sweep and commits accepted candidates in the same
-    # workgroup (mgpu_move_trial_decide_submit): no commit launch, no second upload, no host commit phase.  Host threads,
-    # measured with it (round 3, 16-CPU box; drivers x team): SPC/E 1 x 2 / 1 x 4 / 2 x 2 / 3 x 2 = 7.59 / 7.60 / 7.34 / 7.33 M
-    # (GPU-bound: one driver); CO2 1 x 4 / 2 x 2 / 3 x 2 / 2 x 4 = 13.4 / 21.9 / 21.5 / 19.9 M; framework + water 1 x 4 / 2 x 2 /
-    # 3 x 2 / 2 x 4 = 3.7 / 6.27 / 6.12 / 4.71 M -- two drivers with a team of two; larger teams lose to their fork / join.
-    "spce": dict(replicas=8192, lanes=4, drivers=1, threads=4, device_build=1, device_accept=1, config="metric workload: 10 125-atom SPC/E box (configs[1] recipe at 15^3)"),
+    # device_accept (opt-in, --device-accept 1): the engine also applies the acceptance rule behind the k sweep and commits
+    # accepted candidates in the same workgroup (mgpu_move_trial_decide_submit): no commit launch, no second upload, no host
+    # commit phase.  The DEFAULT keeps the rule in the Fortran driver, as BASELINE.json's north star asks ("the sequential
+    # Metropolis acceptance loop stays on the host in Fortran").  Host threads, measured round 3 on a 16-CPU box (drivers x
+    # team; host rule / device rule, M accepted moves/s): SPC/E 1 x 2 7.39 / 7.59, 1 x 4 7.36 / 7.60, 2 x 2 7.35 / 7.34;
+    # CO2 2 x 2 19.0-19.8 / 21.9, 3 x 2 19.6-20.0 / 21.5, 2 x 4 16.7 / 19.9; framework + water 2 x 2 5.3-6.0 / 6.27,
+    # 3 x 2 5.8-6.05 / 6.12, 2 x 4 5.4 / 4.7 -- two drivers with a team of two; larger teams lose to their fork / join.
+    "spce": dict(replicas=8192, lanes=4, drivers=1, threads=4, device_build=1, device_accept=0, config="metric workload: 10 125-atom SPC/E box (configs[1] recipe at 15^3)"),
     # the grand-canonical boxes are small (a few hundred atoms): per lane step the fixed host costs (OpenMP regions, HIP calls)
     # weigh as much as the kernels, so they run MANY chains (measured round 3, co2_gcmc, one driver thread: 2048 x 2 lanes
     # 5.4 M, 8192 x 4 6.6 M, 8192 x 2 11.2 M, 16384 x 2 13.7 M accepted moves/s) and TWO host driver threads sharing four
     # lanes (the SPC/E box is GPU-bound and gains nothing from a second driver)
-    "co2_gcmc": dict(replicas=16384, lanes=4, drivers=2, threads=4, device_build=1, device_accept=1, config="configs[2]: GCMC of CO2 in a 50 A box, insertion / deletion at one fugacity"),
-    "framework_water": dict(replicas=8192, lanes=4, drivers=2, threads=4, device_build=1, device_accept=1, config="configs[3] stand-in: 2208-atom framework + 4-site water, full move set"),
-    "co2_isotherm": dict(replicas=16384, lanes=4, drivers=2, threads=4, device_build=1, device_accept=1, config="configs[4]: 8 fugacity points dealt over the ranks"),
+    "co2_gcmc": dict(replicas=16384, lanes=4, drivers=2, threads=4, device_build=1, device_accept=0, config="configs[2]: GCMC of CO2 in a 50 A box, insertion / deletion at one fugacity"),
+    "framework_water": dict(replicas=8192, lanes=4, drivers=2, threads=4, device_build=1, device_accept=0, config="configs[3] stand-in: 2208-atom framework + 4-site water, full move set"),
+    "co2_isotherm": dict(replicas=16384, lanes=4, drivers=2, threads=4, device_build=1, device_accept=0, config="configs[4]: 8 fugacity points dealt over the ranks"),
 }
 
 

@@ -334,6 +334,9 @@ def test_device_decided_trials_commit_the_same_state(system, built):
             ca, fa = A_.get_frames(r, ta)
             cb, fb = B_.get_frames(r, ta)
             assert np.array_equal(ca, cb) and np.array_equal(fa, fb)
+    # the device has committed: nothing is left to commit "from the lane's resident rows"
+    with pytest.raises(Exception):
+        B_.commit_lane(0, rep, t, m, kinds, np.ones(R, np.int32))
     # a second candidate on a replica is refused (the workgroups commit independently)
     with pytest.raises(Exception):
         if built:

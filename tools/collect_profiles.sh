@@ -13,6 +13,8 @@ for wl in spce co2_gcmc framework_water; do
   cp $src/bench_${wl}_under_rocprof.json $dst/bench_${wl}_under_rocprof.json
   cp $src/bench_${wl}.json $dst/bench_${wl}.json
 done
+for wl in spce co2_gcmc framework_water; do cp $src/bench_${wl}_device_accept.json $dst/bench_${wl}_device_accept.json; done
+cp $src/pmc_decide/pmc_kernels_co2_gcmc_r03.txt $dst/pmc_kernels_co2_gcmc_device_accept.txt
 cp $src/bench_co2_isotherm.json $dst/bench_co2_isotherm.json
 cp $src/bench_driver_format.json $dst/bench_driver_format_steps20_warmup5.json
 cp $src/bench_spce_T2.json $dst/bench_spce_host_threads2.json

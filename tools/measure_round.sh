@@ -24,6 +24,11 @@ python bench.py --workload co2_gcmc > $out/bench_co2_gcmc.json 2> $out/bench_co2
 python bench.py --workload framework_water > $out/bench_framework_water.json 2> $out/bench_framework_water.err
 python bench.py --workload co2_isotherm > $out/bench_co2_isotherm.json 2> $out/bench_co2_isotherm.err
 python bench.py --host-threads 2 --no-cpu-baseline > $out/bench_spce_T2.json 2> $out/bench_spce_T2.err
+# opt-in: the acceptance rule and the commit on the device (the k sweep decides)
+for wl in spce co2_gcmc framework_water; do
+  python bench.py --workload $wl --device-accept 1 --no-cpu-baseline > $out/bench_${wl}_device_accept.json 2> $out/bench_${wl}_device_accept.err
+done
+PMC_EXTRA=--decide bash tools/pmc_passes.sh $out/pmc_decide r03 4096 2 co2_gcmc > $out/pmc_co2_decide.log 2>&1
 python tools/chain_speed.py --blocks 2 --steps 1500 > $out/chain_speed.txt 2>&1
 for wl in spce co2_gcmc framework_water; do python tools/bench_kernels.py --replicas 2048 --reps 5 --workload $wl > $out/k_${wl}_R2048.json; done
 python tools/bench_kernels.py --replicas 4096 --reps 5 --workload co2_gcmc > $out/k_co2_gcmc_R4096.json

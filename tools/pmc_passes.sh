@@ -13,7 +13,7 @@ nsplit=${4:-}
 wl=${5:-spce}
 if [ -n "$nsplit" ]; then export MGPU_PAIR_NSPLIT=$nsplit; fi   # the engine constant the bench's engine uses at its replica count
 mkdir -p "$out"
-export PMC_EXTRA=${PMC_EXTRA---decide}    # the bench's default path: the k sweep decides and commits (PMC_EXTRA= for the separate commit launch)
+export PMC_EXTRA=${PMC_EXTRA-}    # PMC_EXTRA=--decide profiles the opt-in path (the k sweep decides and commits) instead of k sweep + commit launch
 export TMPDIR=/tmp
 run() {  # name, counters
     rocprofv3 --pmc $2 --kernel-trace --output-format csv -d "$out/${wl}_$1" -o "$1" -- python3 tools/bench_kernels.py --workload $wl --reps 3 --replicas $repl $PMC_EXTRA > "$out/${wl}_$1.log" 2>&1
