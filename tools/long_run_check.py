@@ -23,19 +23,28 @@ def main():
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--gcmc", action="store_true", help="CO2 in the 50 A box with insertion / deletion instead of SPC/E NVT")
     ap.add_argument("--host-build", action="store_true", help="trial moves built by the Fortran driver from its mirror (default: on the device)")
+    ap.add_argument("--device-accept", action="store_true", help="the k sweep applies the acceptance rule and commits (mfarm_configure(2))")
+    ap.add_argument("--framework", action="store_true", help="4-site water in the 2208-atom framework, full move set (with --gcmc semantics)")
     a = ap.parse_args()
-    if a.gcmc:
+    if a.framework:
+        s = synth.framework_water_box()
+        V = float(abs(np.linalg.det(s.box_matrix)))
+        farm = FortranFarm(s, a.replicas, seed=5, translation_step=0.5, rotation_step=0.5, n_threads=4, n_lanes=a.lanes,
+                           mol_capacity=[1, 200], gcmc=dict(p_translation=0.25, p_rotation=0.25, fugacity=40.0 / V),
+                           device_build=not a.host_build, device_accept=a.device_accept)
+        keys = ("non_coulomb", "coulomb", "recip_coulomb", "ewald_self", "intra_coulomb")
+    elif a.gcmc:
         s = synth.co2_box(64, seed=13)
         V = 50.0 ** 3
         fug = np.geomspace(20.0, 160.0, 8)[np.arange(a.replicas) % 8] / V
         farm = FortranFarm(s, a.replicas, seed=5, translation_step=1.0, rotation_step=0.6, n_threads=8, n_lanes=a.lanes,
                            mol_capacity=[400], gcmc=dict(p_translation=0.25, p_rotation=0.25, fugacity=fug),
-                           device_build=not a.host_build)
+                           device_build=not a.host_build, device_accept=a.device_accept)
         keys = ("non_coulomb", "coulomb", "recip_coulomb", "ewald_self", "intra_coulomb")
     else:
         s = synth.spce_box(15)
         farm = FortranFarm(s, a.replicas, seed=5, translation_step=0.3, rotation_step=0.3, n_threads=8, n_lanes=a.lanes,
-                           device_build=not a.host_build)
+                           device_build=not a.host_build, device_accept=a.device_accept)
         keys = ("non_coulomb", "coulomb", "recip_coulomb")
     t0 = time.perf_counter()
     acc = farm.run(a.steps)
@@ -51,7 +60,8 @@ def main():
         A = eng.structure_factor(r)
         eng.init_structure_factor(r, True)
         worst_a = max(worst_a, float(np.max(np.abs(A - eng.structure_factor(r)))))
-    print(f"{'GCMC CO2' if a.gcmc else 'SPC/E 10125 atoms'} ({'host' if a.host_build else 'device'}-built moves): {a.replicas} chains x {a.steps} steps on {a.lanes} lanes, "
+    print(f"{'framework + water GCMC' if a.framework else ('GCMC CO2' if a.gcmc else 'SPC/E 10125 atoms')} ({'host' if a.host_build else 'device'}-built moves, "
+          f"{'device' if a.device_accept else 'host'} rule): {a.replicas} chains x {a.steps} steps on {a.lanes} lanes, "
           f"{farm.trials} trials, {acc} accepted in {el:.1f} s ({acc / el:.3e} accepted/s); over {len(sample)} sampled chains: "
           f"max |running - recomputed energy| = {worst_e:.3e} K, max |A - S(k)| = {worst_a:.3e}, largest |E| = {big:.3e} K")
     farm.close()
