@@ -115,6 +115,7 @@ struct Lane {
     // A trial whose acceptance is decided (and whose accepted candidates are committed) on the device: the flags arrive
     // with the energies; the engine's host mirrors (counts, range flags) follow when the lane is next synchronised
     int decided_n = 0;                        // candidates of such a trial not yet folded into the mirrors (0 = none)
+    int decided_wait_n = 0;                   // ... whose outcomes the caller has not collected yet (mgpu_trial_decide_wait)
     size_t decided_at = 0;                    // byte offset of the flags in h_out
     hipEvent_t commit_staged_ev = nullptr;                    // recorded behind the H2D copies that read h_commit
     bool commit_staged = false;
@@ -1579,6 +1580,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
         for (int c = 0; c < n; ++c) ln.mark[replica[c]] = -1;
         if (twice) return set_error(MGPU_ERR_INVALID_ARG, "trial_decide_submit: more than one candidate for a replica");
     }
+    ln.decided_wait_n = 0;
     ln.dirty = true;
     ln.last_trial_built = false;
     int frame_at = 0;
@@ -1880,6 +1882,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
                             (int *)((double *)ln.d_out.p + acc_at), decide->temperature};
         if ((rc = launch_recip(e, ln, d_rit, n, n1_max, site_stride, false, e->d_A, d_un, d_uo, nullptr, nullptr, &da))) return rc;
         ln.decided_n = n;
+        ln.decided_wait_n = n;
         ln.decided_at = acc_at * sizeof(double);
     }
     HIP_TRY(hipMemcpyAsync(ln.h_out.p, ln.d_out.p, out_doubles * sizeof(double), hipMemcpyDeviceToHost, ln.stream));
@@ -1901,7 +1904,10 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
 static int trial_wait_impl(mgpu_engine *e, Lane &ln, double *old_energy, double *new_energy, int ncomp, int *accepted = nullptr) {
     const int n = ln.n_submitted;
     if (n == 0) return set_error(MGPU_ERR_STATE, "trial_wait: nothing was submitted on this lane");
-    if (accepted && ln.decided_n != n) return set_error(MGPU_ERR_STATE, "trial_decide_wait: the lane's trial was not submitted with an acceptance test");
+    // (a drain in between -- mgpu_synchronize or any synchronous entry point -- has already folded the outcomes into the
+    // engine's mirrors; the flags are still in the result block)
+    if (accepted && ln.decided_wait_n != n) return set_error(MGPU_ERR_STATE, "trial_decide_wait: the lane's trial was not submitted with an acceptance test");
+    ln.decided_wait_n = 0;
     ln.n_submitted = 0;
     const size_t flags_at = ln.decided_at;
     int rc = sync_lane(e, ln);

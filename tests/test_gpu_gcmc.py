@@ -1,13 +1,24 @@
 """Mixed grand-canonical batches on the GPU (mgpu_gcmc_trial_submit / _wait / mgpu_commit_submit)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
 from maniac_mc_amd import synth
 from maniac_mc_amd._lib import MGPU_CREATION, MGPU_DELETION, MGPU_MOVE
+from maniac_mc_amd._lib import check
 from maniac_mc_amd.engine import Engine
 from tests.test_gpu_parity import amp_close, close
 
 pytestmark = pytest.mark.gpu
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _dp(a):
+    return np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))
 
 
 def test_mixed_gcmc_batch_matches_oracle(refcpu_mod):
@@ -334,6 +345,18 @@ def test_device_decided_trials_commit_the_same_state(system, built):
             ca, fa = A_.get_frames(r, ta)
             cb, fb = B_.get_frames(r, ta)
             assert np.array_equal(ca, cb) and np.array_equal(fa, fb)
+    # a drain between submit and wait folds the outcomes into the engine's counts; the wait still returns the flags
+    if built:
+        nm0 = B_.num_molecules(0, ta)
+        au1 = np.array([0.5]); m1 = np.array([0], np.int32)
+        check(B_.L.mgpu_move_trial_decide_submit(B_.h, C.c_int(0), C.c_int(1), _ip(np.array([0], np.int32)), _ip(np.array([ta], np.int32)),
+                                                 _ip(m1), _ip(np.array([3], np.int32)), _dp(np.array([[0.3, 0.6, 0.2, 0.1, 0.7]])),
+                                                 C.c_double(0.8), C.c_double(0.7), _dp(au1), _dp(np.array([1e300])), C.c_double(T)))
+        B_.synchronize()
+        assert B_.num_molecules(0, ta) == nm0 + 1
+        o1 = np.zeros((1, 5)); n1_ = np.zeros((1, 5)); a1 = np.zeros(1, np.int32)
+        check(B_.L.mgpu_trial_decide_wait(B_.h, C.c_int(0), _dp(o1), _dp(n1_), _ip(a1)))
+        assert a1[0] == 1
     # the device has committed: nothing is left to commit "from the lane's resident rows"
     with pytest.raises(Exception):
         B_.commit_lane(0, rep, t, m, kinds, np.ones(R, np.int32))
