@@ -338,15 +338,16 @@ WORKLOADS = {
     # Metropolis acceptance loop stays on the host in Fortran").  Host threads, measured round 3 on a 16-CPU box (drivers x
     # team; host rule / device rule, M accepted moves/s): SPC/E 1 x 2 7.39 / 7.59, 1 x 4 7.36 / 7.60, 2 x 2 7.35 / 7.34;
     # CO2 2 x 2 19.0-19.8 / 21.9, 3 x 2 19.6-20.0 / 21.5, 2 x 4 16.7 / 19.9; framework + water 2 x 2 5.3-6.0 / 6.27,
-    # 3 x 2 5.8-6.05 / 6.12, 2 x 4 5.4 / 4.7 -- two drivers with a team of two; larger teams lose to their fork / join.
+    # 3 x 2 5.8-6.05 / 6.12, 2 x 4 5.4 / 4.7 -- teams of two (larger teams lose to their fork / join); two drivers are
+    # 82 % busy at the CO2 box and fall behind on a slow host (15.1 M on one box), three have margin: default 3 x 2 there.
     "spce": dict(replicas=8192, lanes=4, drivers=1, threads=4, device_build=1, device_accept=0, config="metric workload: 10 125-atom SPC/E box (configs[1] recipe at 15^3)"),
     # the grand-canonical boxes are small (a few hundred atoms): per lane step the fixed host costs (OpenMP regions, HIP calls)
     # weigh as much as the kernels, so they run MANY chains (measured round 3, co2_gcmc, one driver thread: 2048 x 2 lanes
     # 5.4 M, 8192 x 4 6.6 M, 8192 x 2 11.2 M, 16384 x 2 13.7 M accepted moves/s) and TWO host driver threads sharing four
     # lanes (the SPC/E box is GPU-bound and gains nothing from a second driver)
-    "co2_gcmc": dict(replicas=16384, lanes=4, drivers=2, threads=4, device_build=1, device_accept=0, config="configs[2]: GCMC of CO2 in a 50 A box, insertion / deletion at one fugacity"),
-    "framework_water": dict(replicas=8192, lanes=4, drivers=2, threads=4, device_build=1, device_accept=0, config="configs[3] stand-in: 2208-atom framework + 4-site water, full move set"),
-    "co2_isotherm": dict(replicas=16384, lanes=4, drivers=2, threads=4, device_build=1, device_accept=0, config="configs[4]: 8 fugacity points dealt over the ranks"),
+    "co2_gcmc": dict(replicas=16384, lanes=4, drivers=3, threads=6, device_build=1, device_accept=0, config="configs[2]: GCMC of CO2 in a 50 A box, insertion / deletion at one fugacity"),
+    "framework_water": dict(replicas=8192, lanes=4, drivers=3, threads=6, device_build=1, device_accept=0, config="configs[3] stand-in: 2208-atom framework + 4-site water, full move set"),
+    "co2_isotherm": dict(replicas=16384, lanes=4, drivers=3, threads=6, device_build=1, device_accept=0, config="configs[4]: 8 fugacity points dealt over the ranks"),
 }
 
 
@@ -379,6 +380,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-timing", type=int, default=1, choices=[0, 1],
+                    help="0 (diagnostic): no HIP events on the launches of the timed region -- the per-launch figures of the roofline "
+                         "block are then empty; shows what the event bookkeeping costs a host-bound workload")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of the 1-core reference leg")
     ap.add_argument("--cpu-all-cores-budget", type=float, default=6.0,
                     help="seconds of the labelled all-core OpenMP leg of the C restatement (0: skip; SPC/E workload only)")
@@ -522,7 +526,7 @@ def main():
         return 2.0 * (c["trial_translations"] + c["trial_rotations"]) + c["trial_creations"] + c["trial_deletions"]
 
     # profiling on BEFORE the warm-up: the first event-carrying dispatch of a stream costs ~7 ms once
-    eng.profile_enable(True)
+    eng.profile_enable(bool(args.kernel_timing))
     farm.run(args.warmup)
     # Declared, untimed settle phase: the timed region may be as short as 20 steps (~5 ms), far below the time
     # the GPU clocks, the OpenMP team and the host caches need to reach their steady state; run the same step
@@ -597,6 +601,8 @@ def main():
     # the kernels of different lanes share the CUs, which raises throughput but stretches every kernel's own
     # duration; this gives the kernel's un-shared time for comparison.
     iso_us = None
+    if not args.kernel_timing:
+        eng.profile_enable(True)           # the isolated legs below are timed either way
     if rank == 0 and args.host == "fortran" and wl == "spce":
         rng = np.random.default_rng(5)
         n_l = max(1, R // farm.n_lanes)
