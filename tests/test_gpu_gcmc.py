@@ -266,8 +266,10 @@ def _decide_host(old, new, u, pref, T):
     return ((x >= 1.0) | (u <= x)).astype(np.int32)
 
 
-@pytest.mark.parametrize("system", ["co2", "framework_water"])
-@pytest.mark.parametrize("built", [False, True], ids=["host_rows", "device_built"])
+@pytest.mark.parametrize("system,built", [("co2", False), ("co2", True), ("framework_water", False), ("framework_water", True),
+                                          ("mixture_triclinic", False)],
+                         ids=["co2-host_rows", "co2-device_built", "framework_water-host_rows", "framework_water-device_built",
+                              "mixture_triclinic-host_rows"])
 def test_device_decided_trials_commit_the_same_state(system, built):
     """mgpu_*_trial_decide_submit: the k sweep's workgroup applies the acceptance rule and commits.  Two engines run the
     same scripted grand-canonical steps, one candidate per replica and step: engine A the classic way (trial, decision
@@ -276,6 +278,10 @@ def test_device_decided_trials_commit_the_same_state(system, built):
     if system == "co2":
         s = synth.co2_box(20, seed=4)
         ta, caps = 0, [40]
+    elif system == "mixture_triclinic":
+        # two active species in a tilted cell: the 27-image pair sweep, single-state items, the general reciprocal matrix
+        s = synth.mixture_box(seed=4, tilt=(1.5, -0.8, 0.6))
+        ta, caps = 0, [30, 20]
     else:
         s = synth.framework_water_box(n_water=12, n_frame=300, L=24.0, seed=7)
         ta, caps = 1, [1, 30]
@@ -296,7 +302,7 @@ def test_device_decided_trials_commit_the_same_state(system, built):
     A_, B_ = engines
     rng = np.random.default_rng(21)
     L = np.diag(s.box_matrix)
-    V = float(np.prod(L))
+    V = float(abs(np.linalg.det(s.box_matrix)))
     n1 = int(s.topo.atoms_in_res[ta])
     tmpl = s.all_sites(ta)[0] - s.all_sites(ta)[0].mean(axis=0)
     rep = np.arange(R, dtype=np.int32)
@@ -325,7 +331,7 @@ def test_device_decided_trials_commit_the_same_state(system, built):
             rows = np.zeros((R, n1, 3))
             for r in range(R):
                 if move[r] == 3:
-                    rows[r] = tmpl + (s.bounds_lo + L * u5[r, :3])
+                    rows[r] = tmpl + (s.bounds_lo + u5[r, :3] @ s.box_matrix)      # create_molecule.f90:183-184 (rows = cell vectors)
                 else:
                     rows[r] = cur[r][m[r]] + (u5[r, :3] - 0.5) * (0.8 if move[r] <= 2 else 0.0)
             oa, na = A_.gcmc_trial(rep, t, m, kinds, rows)
