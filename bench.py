@@ -340,7 +340,9 @@ WORKLOADS = {
     # CO2 2 x 2 19.0-19.8 / 21.9, 3 x 2 19.6-20.0 / 21.5, 2 x 4 16.7 / 19.9; framework + water 2 x 2 5.3-6.0 / 6.27,
     # 3 x 2 5.8-6.05 / 6.12, 2 x 4 5.4 / 4.7 -- teams of two (larger teams lose to their fork / join); two drivers are
     # 82 % busy at the CO2 box and fall behind on a slow host (15.1 M on one box), three have margin: default 3 x 2 there.
-    "spce": dict(replicas=8192, lanes=4, drivers=1, threads=4, device_build=1, device_accept=0, config="metric workload: 10 125-atom SPC/E box (configs[1] recipe at 15^3)"),
+    # 16384 chains on four lanes (engine nsplit 1: a lane step is 4096 fused moves = one work unit per resident wave, each a
+    # whole sweep): 8192 / 16384 / 32768 chains 7.34 / 7.56 / 7.52 M on one box (round 3)
+    "spce": dict(replicas=16384, lanes=4, drivers=1, threads=4, device_build=1, device_accept=0, config="metric workload: 10 125-atom SPC/E box (configs[1] recipe at 15^3)"),
     # the grand-canonical boxes are small (a few hundred atoms): per lane step the fixed host costs (OpenMP regions, HIP calls)
     # weigh as much as the kernels, so they run MANY chains (measured round 3, co2_gcmc, one driver thread: 2048 x 2 lanes
     # 5.4 M, 8192 x 4 6.6 M, 8192 x 2 11.2 M, 16384 x 2 13.7 M accepted moves/s) and TWO host driver threads sharing four

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 sha256sum maniac_mc_amd/libmaniac_hip.so > $out/lib_sha256.txt
 python -m pytest tests -m gpu -x -q > $out/pytest.log 2>&1 || { tail -80 $out/pytest.log; exit 1; }
 tail -3 $out/pytest.log
-bash tools/pmc_passes.sh $out/pmc r03 2048 2 spce > $out/pmc_spce.log 2>&1
+bash tools/pmc_passes.sh $out/pmc r03 4096 1 spce > $out/pmc_spce.log 2>&1   # the default bench: 16384 chains on 4 lanes, engine nsplit 1
 bash tools/pmc_passes.sh $out/pmc r03 4096 2 co2_gcmc > $out/pmc_co2.log 2>&1
 bash tools/pmc_passes.sh $out/pmc r03 2048 4 framework_water > $out/pmc_fw.log 2>&1
 mkdir -p profiles/r03
@@ -32,6 +32,7 @@ PMC_EXTRA=--decide bash tools/pmc_passes.sh $out/pmc_decide r03 4096 2 co2_gcmc 
 python tools/chain_speed.py --blocks 2 --steps 1500 > $out/chain_speed.txt 2>&1
 for wl in spce co2_gcmc framework_water; do python tools/bench_kernels.py --replicas 2048 --reps 5 --workload $wl > $out/k_${wl}_R2048.json; done
 python tools/bench_kernels.py --replicas 4096 --reps 5 --workload co2_gcmc > $out/k_co2_gcmc_R4096.json
+MGPU_PAIR_NSPLIT=1 python tools/bench_kernels.py --replicas 4096 --reps 5 --workload spce > $out/k_spce_R4096_nsplit1.json   # the default bench's launch shape
 # the same launch groups with the acceptance on the device (the k sweep decides and commits: the farm's default)
 for wl in spce framework_water; do python tools/bench_kernels.py --replicas 2048 --reps 5 --workload $wl --decide > $out/k_${wl}_R2048_decide.json; done
 python tools/bench_kernels.py --replicas 4096 --reps 5 --workload co2_gcmc --decide > $out/k_co2_gcmc_R4096_decide.json
