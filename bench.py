@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 fp64 lanes x 2 flop x 2.4 GHz (spec)
 FP64_SUSTAINED_TFLOPS = 61.0    # tools/probe_fma.hip on MI355X: what back-to-back v_fma_f64 sustains (clock under load)
 FLOP_PER_PAIR = 64.0            # ~64 fp64 flops per site-atom pair term incl. erfc (the ALGORITHMIC flop count)
-PMC_DIR = os.path.join("profiles", "r03")
+PMC_DIR = os.path.join("profiles", "r04")
 
 
 def lib_sha256():
@@ -327,6 +327,103 @@ def cpu_baseline_gcmc(system, t_act, p_move, translation_step, rotation_step, fu
             "trial_moves_per_s": trials / el, "ns_per_dE_eval": el / max(1, evals) * 1e9, "acceptance": accepted / max(1, trials)}
 
 
+
+def replicas_sweep(system, counts, device, host_threads, seconds, t_step, r_step):
+    """Throughput against the number of chains a GPU holds (same SPC/E step, same Fortran farm, device-built moves, the
+    rule in Fortran): a farm of R chains advances in lock step, so few chains mean few candidates per launch and the
+    step is a host <-> device latency chain, not arithmetic."""
+    from maniac_mc_amd.fortran_host import FortranFarm
+    out = []
+    for R in counts:
+        lanes = 1 if R < 16 else (2 if R < 512 else 4)
+        farm = FortranFarm(system, R, device=device, seed=77, translation_step=t_step, rotation_step=r_step, p_translation=0.5,
+                           n_threads=max(1, min(host_threads, 2 if R < 512 else 4)), n_lanes=lanes, n_drivers=1, device_build=True)
+        try:
+            farm.run(20)
+            chunk = 50
+            farm.run(chunk)
+            farm.eng.synchronize()
+            steps = acc = 0
+            t0 = time.perf_counter()
+            while True:
+                acc += farm.run(chunk)
+                steps += chunk
+                farm.eng.synchronize()
+                el = time.perf_counter() - t0
+                if el >= seconds:
+                    break
+            out.append({"replicas": R, "lanes": farm.n_lanes, "value": acc / el, "unit": "accepted MC moves/s",
+                        "trial_moves_per_s": steps * R / el, "steps": steps, "us_per_step": el / steps * 1e6,
+                        "per_chain_steps_per_s": steps / el, "engine_nsplit_note": "engine constant of this replica count"})
+        finally:
+            farm.close()
+    return out
+
+
+def single_chain_leg(system, device, t_step, r_step, steps=4000, k=8):
+    """ONE chain of the same box through the single-chain drop-in (mc_chain.f90 -> mgpu_chain_window: one kernel launch per
+    window of up to k speculative steps, the launch also decides and commits): what a user with one chain gets."""
+    import shutil
+    import tempfile
+    from maniac_mc_amd import io_maniac, run
+    tmp = tempfile.mkdtemp(prefix="bench_chain_")
+    try:
+        files = io_maniac.write_input_files(system, os.path.join(tmp, "in"), nb_block=1, nb_step=steps, translation_step=t_step,
+                                            rotation_step_angle=r_step, translation_proba=0.5, rotation_proba=0.5,
+                                            masses=[15.9994, 1.008], atom_names=["OW", "HW"])
+        res = run.run_simulation(*files, os.path.join(tmp, "out") + "/", seed=5, device=device, speculate=k)
+        c = res["counters"]
+        acc = int(c[1] + c[3] + c[5] + c[7])
+        return {"replicas": 1, "driver": f"mc_chain.f90, one launch per window of up to {k} steps (mgpu_chain_window)",
+                "value": acc / res["mc_seconds"], "unit": "accepted MC moves/s", "steps": steps,
+                "per_chain_steps_per_s": steps / res["mc_seconds"], "us_per_step": res["mc_seconds"] / steps * 1e6,
+                "windows": int(res["chain_windows"][0]), "steps_left_to_the_host": int(res["chain_windows"][1]),
+                "note": "Monte Carlo loop alone (initial energy and output files excluded); the chain writes the reference's files"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def config_legs(args, device):
+    """BASELINE.json configs[2]-[4] as short self-timed legs: child processes of this one, one after the other (this
+    process has closed its farm; a child is an ordinary `bench.py --workload ...` run and prints its own JSON line)."""
+    import subprocess
+    out = {}
+    for wl in ("co2_gcmc", "framework_water", "co2_isotherm"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", str(args.config_steps), "--warmup", "20",
+               "--sustained-steps", "0", "--configs", "0", "--replicas-sweep", "", "--cpu-budget", "1.0", "--cpu-all-cores-budget", "0",
+               "--device", str(device)]
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        t0 = time.perf_counter()
+        env = {k: v for k, v in os.environ.items() if k not in ("OMP_PLACES", "OMP_PROC_BIND")}
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not line:
+                out[wl] = {"error": (p.stderr or p.stdout)[-400:], "returncode": p.returncode}
+                continue
+            d = json.loads(line[-1])
+        except Exception as exc:
+            out[wl] = {"error": str(exc)}
+            continue
+        r = d["roofline"]
+        roof = {k: r.get(k) for k in ("bound", "basis", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us")}
+        if r.get("measured"):
+            # the k sweep only reads A(k): the fraction on the bytes the counters saw is the one that means something
+            roof.update({k: r["measured"][k] for k in ("basis", "achieved", "frac")})
+            roof["algorithmic"] = {"achieved": r.get("achieved"), "frac": r.get("frac"), "basis": "algorithmic_bytes (52 Nk per evaluation)"}
+        if r.get("isolated"):
+            roof["isolated_frac"] = r["isolated"].get("frac")
+        out[wl] = {"baseline_config": d["config"]["baseline_config"], "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
+                   "steps": d["steps"], "ms_per_step": d["ms_per_step"], "timed_region_s": d["timed_region_s"],
+                   "replicas_per_gpu": d["config"]["replicas_per_gpu"], "acceptance": d["acceptance"],
+                   "trial_moves_per_s": d["trial_moves_per_s"], "ns_per_dE_eval": d["ns_per_dE_eval"], "roofline": roof,
+                   "cpu_baseline": d.get("cpu_baseline"), "leg_seconds": time.perf_counter() - t0}
+        if "isotherm" in d:
+            out[wl]["isotherm_mean_N"] = [round(pt["mean_N"], 2) for pt in d["isotherm"]]
+    return out
+
+
 WORKLOADS = {
     # name: default chains per GPU, lanes, what BASELINE.json calls it
     # device_build: the engine keeps the molecules' frames and builds the trial geometry itself (no host mirror, no candidate
@@ -385,8 +482,8 @@ def main():
     ap.add_argument("--kernel-timing", type=int, default=1, choices=[0, 1],
                     help="0 (diagnostic): no HIP events on the launches of the timed region -- the per-launch figures of the roofline "
                          "block are then empty; shows what the event bookkeeping costs a host-bound workload")
-    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of the 1-core reference leg")
-    ap.add_argument("--cpu-all-cores-budget", type=float, default=6.0,
+    ap.add_argument("--cpu-budget", type=float, default=4.0, help="seconds of the 1-core reference leg")
+    ap.add_argument("--cpu-all-cores-budget", type=float, default=2.0,
                     help="seconds of the labelled all-core OpenMP leg of the C restatement (0: skip; SPC/E workload only)")
     ap.add_argument("--settle-s", type=float, default=0.5,
                     help="untimed settle phase after the warm-up steps, seconds of the same step (0: none)")
@@ -404,9 +501,25 @@ def main():
                     help="no GPU work: every rank reports its placement (device, host threads, fugacity points) and "
                          "rank 0 prints the rank-ordered table gathered over the process group")
     ap.add_argument("--dump-counts", default=None, help="directory: every rank writes its chains' final molecule counts (tests)")
+    ap.add_argument("--configs", type=int, default=None, choices=[0, 1],
+                    help="1: after the headline workload, time the other BASELINE.json configs (co2_gcmc, framework_water, "
+                         "co2_isotherm) as short self-timed legs (child processes of this one, one after the other) and put them "
+                         "into the same JSON line as `configs` (default: 1 for the default single-GPU SPC/E run)")
+    ap.add_argument("--config-steps", type=int, default=300, help="steps of each `configs` leg")
+    ap.add_argument("--replicas-sweep", default=None,
+                    help="comma-separated chain counts: after the headline region, the same SPC/E step with that many chains per "
+                         "GPU (`replicas_sweep` in the JSON line: throughput against chain count), plus the single-chain driver "
+                         "(mc_chain.f90, one launch per window); default 1,8,64,512,4096 for the default single-GPU SPC/E run, "
+                         "'' for none")
+    ap.add_argument("--sweep-seconds", type=float, default=0.4, help="timed seconds per point of --replicas-sweep")
     args = ap.parse_args()
 
     wl = args.workload
+    default_run = wl == "spce" and args.replicas is None and args.gpus <= 1 and args.host == "fortran" and not args.dry_run
+    if args.configs is None:
+        args.configs = 1 if default_run else 0
+    if args.replicas_sweep is None:
+        args.replicas_sweep = "1,8,64,512,4096" if default_run else ""
     if args.replicas is None:
         args.replicas = WORKLOADS[wl]["replicas"]
     if args.lanes is None:
@@ -662,7 +775,7 @@ def main():
             fresh = bool(pmc) and not pmc["stale"] and pmc.get("valu_instr_per_eval") is not None
             job_tflops = evals_rank * flop_eval / elapsed / 1e12
             launch_tflops = evals_rank * flop_eval / (ms_pair * 1e-3) / 1e12 if ms_pair else None
-            roof = {"bound": "valu", "bound_note": "fp64 vector issue (the contract's hbm / mfma do not apply: measured HBM-side "
+            roof = {"bound": "valu", "basis": "algorithmic_flops", "bound_note": "fp64 vector issue (the contract's hbm / mfma do not apply: measured HBM-side "
                                                    "traffic is a fraction of the algorithmic bytes and there is no MFMA-shaped work; SURVEY 8(d))",
                     "kernel": "pair_frozen_kernel<4,...> (framework box: 64 candidates in the lanes of a wave against chunks of 32 framework atoms "
                               "held as scalars, then each lane's own adsorbates; frozen_finalize_kernel adds the chunk partials)" if wl == "framework_water"
@@ -712,7 +825,7 @@ def main():
             fresh = bool(pmc) and not pmc["stale"] and pmc.get("hbm_bytes_per_eval") is not None
             gbs = bytes_k_eval * evals_rank / (ms_rec * 1e-3) / 1e9 if ms_rec else None
             k_item_bytes = pmc["hbm_bytes_per_eval"] * pmc["evals"] / pmc["candidates"] if fresh and pmc.get("candidates") else 0.0
-            roof = {"bound": "hbm", "kernel": ("recip_rows_kernel<false,true,true> (k sweep: old and new reciprocal energy of every candidate from one pass "
+            roof = {"bound": "hbm", "basis": "algorithmic_bytes", "kernel": ("recip_rows_kernel<false,true,true> (k sweep: old and new reciprocal energy of every candidate from one pass "
                                                "over A(k); its workgroup then applies the acceptance rule and commits an accepted candidate -- a second "
                                                "pass A <- A + delta -- so avg_launch_us covers sweep AND commit)") if args.device_accept else
                                               "recip_rows_kernel<false,true> (k sweep: old and new reciprocal energy of every candidate from one pass over A(k))",
@@ -738,6 +851,15 @@ def main():
                                           "and is only read by the k sweep: a third of the 52 Nk algorithmic figure) over the same time"} if iso_gc else None),
                     "job_frac": evals_rank * (bytes_pair_eval + bytes_k_eval) / elapsed / 1e9 / HBM_PEAK_GBS,
                     "job_frac_note": "all evaluations x (36 N + 52 Nk) algorithmic bytes / timed_region_s / HBM peak"}
+            # The k sweep only READS A(k) (32 B per +-kz pair): the bytes it really moves are a third of the 52 Nk
+            # algorithmic figure, so the algorithmic rate can exceed the HBM peak.  Where the committed PMC summary is of
+            # THIS build, `measured` carries the rate on the bytes the counters saw, and that is the fraction to read.
+            if fresh and ms_rec and pmc.get("candidates"):
+                cand_per_launch = (tot_trials / world) / max(1, n_rec)
+                m_gbs = k_item_bytes * cand_per_launch / (us(ms_rec, n_rec) * 1e-6) / 1e9
+                roof["measured"] = {"basis": "measured_traffic", "achieved": m_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": m_gbs / HBM_PEAK_GBS, "bytes_per_candidate": k_item_bytes,
+                                    "candidates_per_launch": cand_per_launch, "avg_launch_us": us(ms_rec, n_rec)}
         roof["kernels"] = kernels
         out = {
             "metric": "MC moves/sec", "value": tot_acc / elapsed, "unit": "accepted MC moves/s",
@@ -783,6 +905,18 @@ def main():
                                "bytes_per_rank": int(hist.nbytes + 24), "per": "block (= the timed region)"}
         if timers0 is not None:
             out["host_seconds"] = {k: v - timers0[k] for k, v in timers1.items()}   # timed region only
+    farm.close()
+    if rank == 0:
+        # GPU legs first, CPU baselines last (short), so that whoever samples the GPU from outside sees it busy
+        if world == 1 and args.replicas_sweep and wl == "spce" and args.host == "fortran":
+            pts = [int(x) for x in args.replicas_sweep.split(",") if x.strip()]
+            out["replicas_sweep"] = replicas_sweep(system, pts, device, args.host_threads, args.sweep_seconds, t_step, r_step)
+            try:
+                out["single_chain"] = single_chain_leg(system, device, t_step, r_step)
+            except Exception as exc:                       # an extra leg must never take the bench line down
+                out["single_chain"] = {"error": str(exc)}
+        if world == 1 and args.configs:
+            out["configs"] = config_legs(args, device)
         if world == 1 and not args.no_cpu_baseline:
             if wl == "spce":
                 out["cpu_baseline"] = cpu_baseline(system, t_step, r_step, budget_s=args.cpu_budget,
@@ -791,7 +925,6 @@ def main():
                 f_cpu = fug_one if fug_one is not None else float(fug_grid[ISOTHERM_POINTS // 2])
                 out["cpu_baseline"] = cpu_baseline_gcmc(system, t_act, p_move, t_step, r_step, f_cpu, budget_s=args.cpu_budget)
         print(json.dumps(out))
-    farm.close()
     if dist is not None:
         dist.destroy_process_group()
 

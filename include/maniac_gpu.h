@@ -61,13 +61,13 @@ extern "C" {
  *                               chunk partials are summed in chunk order, so results are reproducible per value)
  *   MGPU_PAIR_FUSE_MAX=<n>      largest molecule whose trial moves sweep old + new state in one pass (default 3; 4 and
  *                               5 select kernels of up to 256 VGPRs at half the occupancy: measured slower)
- *   MGPU_DEFER_COMMIT=1         a commit from a lane's resident rows is not launched but folded into the lane's
- *                               next trial (one kernel applies it and sweeps k for the new candidates); bitwise the
- *                               same results, measured no faster than the two launches
- * Threading rule: one host thread drives an engine at a time; lanes must hold disjoint replicas while their
- * trials / commits are in flight; every synchronous entry point that reads or rewrites replica state -- the
- * mgpu_replica_* / structure-factor / system-energy calls and the synchronous candidate calls
- * (mgpu_pair / recip / intra / trial_energy_candidates, mgpu_commit_candidates) -- drains all lanes first. */
+ * Threading rule: the per-lane asynchronous entry points (mgpu_*_submit, mgpu_*_wait, mgpu_commit_submit,
+ * mgpu_lane_site_buffer) may be called concurrently from different host threads on DIFFERENT lanes -- one thread per
+ * lane at a time (the farm runs up to three driver threads that way); lanes must hold disjoint replicas while their
+ * trials / commits are in flight.  Everything else is single-threaded: engine creation / destruction, the
+ * mgpu_replica_* / structure-factor / system-energy calls, the synchronous candidate calls (mgpu_pair / recip / intra /
+ * trial_energy_candidates, mgpu_commit_candidates), mgpu_synchronize and the profile calls must not run while another
+ * thread is inside any engine call; those that read or rewrite replica state drain all lanes first. */
 
 /* candidate kinds for the reciprocal-space update, ewald_energy.f90:241-256 */
 #define MGPU_MOVE 0      /* A += sum q (phi_new - phi_old)   translation / rotation */
@@ -315,8 +315,10 @@ int mgpu_trial_decide_wait(mgpu_engine *e, int lane, double *old_energy, double 
  * candidate rows directly in *sites and then passes that same pointer as `sites` to mgpu_trial_submit /
  * mgpu_gcmc_trial_submit on this lane (with at most n_max candidates and the same site_stride) saves the engine's copy
  * of the rows into its staging block (measured: 590 KB per lane step at 8192 CO2 candidates).  The pointer stays
- * valid until the engine is destroyed or the function is called again for the lane with a larger size; the rows may be
- * rewritten once the lane's trial has been waited for.  Replaces nothing in the reference (its candidates live in
+ * valid until the engine is destroyed or the function is called again for the lane with a larger size -- the engine
+ * never regrows a lent block on its own: a later trial on the lane that would not fit it (more candidates, a larger
+ * stride) fails with MGPU_ERR_STATE instead.  The block is sized for n_max candidates in every submit form (host rows,
+ * device-built rows, acceptance records).  The rows may be rewritten once the lane's trial has been waited for.  Replaces nothing in the reference (its candidates live in
  * primary%mol_com / site_offset, src/simulation_state.f90:115-116). */
 int mgpu_lane_site_buffer(mgpu_engine *e, int lane, int n_max, int site_stride, double **sites);
 int mgpu_trial_submit(mgpu_engine *e, int lane, int n_candidates, const int *replica, const int *t,
@@ -341,6 +343,47 @@ int mgpu_gcmc_trial_wait(mgpu_engine *e, int lane, double *old_energy, double *n
 int mgpu_replica_replace_molecule(mgpu_engine *e, int replica, int t, int m_dst, int m_src);
 /* Overwrite the molecule count of a replica's residue type (no coordinates touched). */
 int mgpu_replica_set_num_molecules(mgpu_engine *e, int replica, int t, int n_mol);
+
+/* ------------------------------------------------------------------------------------------
+ * Single-chain windows: ONE kernel launch per window of trial steps of one Markov chain
+ * ---------------------------------------------------------------------------------------- */
+
+/* MonteCarloLoop (src/monte_carlo.f90:40-86) advances ONE chain one step at a time, and one step at a time a GPU is a
+ * latency chain (upload, launches, download, synchronise, commit launch: 50-65 us for ~10 us of arithmetic).  A host that
+ * draws the next n steps in the reference's random-number order ASSUMING every one of them is rejected holds n trials of
+ * the SAME state (mc_chain.f90, run_window); mgpu_chain_window evaluates all of them in one launch, applies
+ * mc_acceptance_probability (src/monte_carlo_utils.f90:184-226) to them IN ORDER with the host's own acceptance draws
+ * accept_u[c] and prefactors accept_pref[c] (1 for a translation / rotation; phi V / N for an insertion, N = the count
+ * after it; (N + 1) / (phi V) for a deletion, N = the count after it -- create_molecule.f90:64, delete_molecule.f90:73),
+ * and commits the FIRST accepted step on the device (A(k) += delta, coordinates, count -- AcceptMove and the Accept* of
+ * create_molecule.f90:100-112 / delete_molecule.f90:100-142).  Candidates are read from, and results written to, pinned
+ * host memory by the kernel itself; the call returns as soon as the results are there, while the commit still runs
+ * (every later call is ordered behind it).
+ *   kind[c]     MGPU_MOVE / MGPU_CREATION / MGPU_DELETION; m[c] ignored for creations (appended)
+ *   link[c]     -1: an ordinary step.  >= 0 (deletions only): the reference's deletion AS WRITTEN (SURVEY F3,
+ *               monte_carlo_utils.f90:301-309): the step's new reciprocal energy is the creation-kind energy of row
+ *               link[c] -- the molecule RemoveMolecule moves into the slot -- and accepting it adds that molecule's terms
+ *               to A(k).  -2: such an energy-only companion row (creation kind; never decided, never committed).
+ *   sites       [n][site_stride][3] candidate sites (unused for deletions)
+ *   recip_energy  the chain's running energy%recip_coulomb: ComputeOldEnergy's value for insertions / deletions
+ *               (monte_carlo_utils.f90:366-372)
+ *   old_energy / new_energy   [n][5] as mgpu_gcmc_trial_wait returns them (every row, decided or not)
+ *   first_accepted   index of the step the device accepted and committed, -1: none
+ *   undecided   -1, or the index of a step the device left to the host: its draw lies within the engine's relative
+ *               margin (16 ulp; mgpu_chain_set_margin) of its acceptance probability, or the probability is not a number.
+ *               The device's exp (OCML) and the host's (glibc) may differ in the last bits there; the device stops at
+ *               such a step -- nothing at or after it is committed -- and the host decides it with its own exp from the
+ *               energies returned.  Every decision the device takes is therefore the host's decision.
+ * mgpu_chain_window_capacity: the largest n (0: the one-launch path does not apply -- triclinic box, per-k reciprocal
+ * form, active molecules of more than 5 sites -- use mgpu_gcmc_trial_submit / wait).  Lane 0's stream carries the launch:
+ * no trial may be in flight on lane 0. */
+int mgpu_chain_window_capacity(const mgpu_engine *e, int *max_candidates);
+int mgpu_chain_window(mgpu_engine *e, int replica, int n, const int *t, const int *m, const int *kind, const int *link,
+                      const double *sites, int site_stride, const double *accept_u, const double *accept_pref,
+                      double temperature, double recip_energy, double *old_energy, double *new_energy,
+                      int *first_accepted, int *undecided);
+int mgpu_chain_set_margin(mgpu_engine *e, double relative_margin);
+int mgpu_chain_get_stats(const mgpu_engine *e, long long *windows, long long *undecided);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement

@@ -29,7 +29,8 @@ EXPORTS = [
     "mgpu_recip_energy_candidates", "mgpu_self_energy", "mgpu_intra_energy_candidates",
     "mgpu_trial_energy_candidates", "mgpu_commit_candidates", "mgpu_trial_submit", "mgpu_trial_wait",
     "mgpu_commit_submit", "mgpu_lane_site_buffer", "mgpu_replica_set_frames", "mgpu_replica_get_frames", "mgpu_move_trial_submit", "mgpu_move_trial_decide_submit", "mgpu_gcmc_trial_decide_submit", "mgpu_trial_decide_wait", "mgpu_gcmc_trial_submit", "mgpu_gcmc_trial_wait", "mgpu_replica_replace_molecule",
-    "mgpu_replica_set_num_molecules", "mgpu_synchronize", "mgpu_profile_enable", "mgpu_profile_reset",
+    "mgpu_replica_set_num_molecules", "mgpu_chain_window_capacity", "mgpu_chain_window", "mgpu_chain_set_margin",
+    "mgpu_chain_get_stats", "mgpu_synchronize", "mgpu_profile_enable", "mgpu_profile_reset",
     "mgpu_profile_get",
 ]
 

@@ -74,8 +74,11 @@ struct Lane {
     hipStream_t stream = nullptr;
     DevBuf d_items, d_items2, d_sites, d_partials, d_out;
     HostBuf h_in, h_commit, h_out;   // pinned staging: trial inputs, commit inputs, results
+    bool h_in_lent = false;          // h_in.p was handed to the caller (mgpu_lane_site_buffer): it must never be freed under them
     struct Pending { int kernel; hipEvent_t a, b; };
     std::vector<Pending> pending;
+    struct Occupancy { const void *kernel; size_t lds; int blocks; };
+    std::vector<Occupancy> occ;      // resident_blocks() cache
     // profiling state is per lane: lanes may be driven by different host threads (one thread per lane at a time)
     std::vector<hipEvent_t> ev_pool;
     ProfileSlot prof[MGPU_KERNEL_COUNT];
@@ -99,19 +102,7 @@ struct Lane {
     std::vector<char> cand_ok;                                // per candidate: its sites are within the fast fold's range
     std::vector<int> build_kind;                              // candidate kinds of a device-built trial
     std::vector<double> h_lj, h_cc;                           // pair energies of the trial being collected
-    // A commit of the lane's last trial that has been accepted by the host but not launched: the lane's next
-    // trial_submit folds it into its k sweep (trial_k_kernel); anything else that needs the engine's state flushes it
-    // with the stand-alone commit kernel first.  The previous trial's staging block lives on in d_prev meanwhile.
-    struct Deferred {
-        bool active = false;
-        int n = 0, stride = 0, n1_max = 1;
-        AcceptBits bits{};
-        const RecipItem *d_items = nullptr;
-        const double *d_sites = nullptr;
-        std::vector<int> replica;             // replica of every candidate of that trial
-    } deferred;
-    DevBuf d_prev;                            // the staging block the deferred commit still reads
-    std::vector<int> mark;                    // [n_replicas] scratch: replica -> deferred candidate index
+    std::vector<int> mark;                    // [n_replicas] scratch of the one-candidate-per-replica check
     // A trial whose acceptance is decided (and whose accepted candidates are committed) on the device: the flags arrive
     // with the energies; the engine's host mirrors (counts, range flags) follow when the lane is next synchronised
     int decided_n = 0;                        // candidates of such a trial not yet folded into the mirrors (0 = none)
@@ -121,7 +112,7 @@ struct Lane {
     bool commit_staged = false;
     void release() {
         if (commit_staged_ev) { (void)hipEventDestroy(commit_staged_ev); commit_staged_ev = nullptr; }
-        d_items.release(); d_items2.release(); d_sites.release(); d_partials.release(); d_out.release(); d_prev.release();
+        d_items.release(); d_items2.release(); d_sites.release(); d_partials.release(); d_out.release();
         d_scratch.release();
         h_in.release(); h_commit.release(); h_out.release();
     }
@@ -174,7 +165,6 @@ struct mgpu_engine {
     int pair_fuse_max = kMaxFusedSites;   // largest molecule whose trial moves are fused (MGPU_PAIR_FUSE_MAX: up to kMaxFusedSitesWide)
     bool pair_fast_fold = true;      // two-instruction minimum-image fold where the atoms' range allows it (MGPU_PAIR_EXACT_FOLD=1: off)
     bool recip_force_per_k = false;  // MGPU_RECIP_PER_K=1: per-k reciprocal kernel even where the row form fits (tests)
-    bool defer_commits = false;      // MGPU_DEFER_COMMIT=1: resident-row commits ride in the lane's next k sweep (trial_k_kernel)
     double *d_res_q = nullptr;
     int *d_res_atype = nullptr;
     // frozen residues (inactive, n1 >= 64): site_perm[t][a] = position of the caller's site a in the engine's
@@ -213,6 +203,19 @@ struct mgpu_engine {
            &d_partials = lanes[0].d_partials, &d_out = lanes[0].d_out;
     HostBuf &h_out = lanes[0].h_out;
     HostBuf h_stage;
+    // single-chain windows (mgpu_chain_window): pinned, host-coherent blocks the kernel reads its candidates from and
+    // writes its results to (no copies, no stream synchronisation: the host polls the tag), and device scratch
+    struct Chain {
+        ChainCand *h_cand[2] = {nullptr, nullptr};   // alternate per window: the commit of window w still reads block w & 1
+        double *h_out = nullptr;                     // [kChainMaxCand][10] energies | first, undecided
+        unsigned long long *h_tag = nullptr;
+        ChainResult *d_res = nullptr;
+        double2 *d_part = nullptr;
+        int *d_ticket = nullptr;
+        unsigned long long seq = 0;
+        double margin = 16.0 * 2.220446049250313e-16;   // relative band around the acceptance probability left to the host's exp
+        long long windows = 0, undecided = 0;
+    } chain;
     // profiling
     bool profiling = false;
 };
@@ -256,6 +259,7 @@ int prof_collect(mgpu_engine *e, Lane &ln) {
 }
 
 void finish_decided(mgpu_engine *e, Lane &ln);
+void frozen_changed(mgpu_engine *e, int replica, int t);
 int sync_lane(mgpu_engine *e, Lane &ln) {
     HIP_TRY(hipStreamSynchronize(ln.stream));
     ln.dirty = false;
@@ -266,9 +270,7 @@ int sync_stream(mgpu_engine *e) { return sync_lane(e, e->lanes[0]); }
 // The synchronous entry points that read or rewrite replica state (coordinates, counts, A(k)) on lane 0's stream or
 // the null stream first drain EVERY lane: the lanes' streams are non-blocking, so work still queued on lanes 1-3
 // would otherwise race with them.
-int flush_all_deferred(mgpu_engine *e);
 int sync_all_lanes(mgpu_engine *e) {
-    if (int rc = flush_all_deferred(e)) return rc;
     // lane 0 doubles as the synchronous path's stream (those entry points synchronise it themselves before they
     // return); the other lanes only carry work queued by the asynchronous entry points, which mark them dirty
     for (auto &ln : e->lanes)
@@ -290,10 +292,23 @@ void finish_decided(mgpu_engine *e, Lane &ln) {
         if (items[c].kind == MGPU_CREATION) e->h_nmol[idx] += 1;
         if (items[c].kind == MGPU_DELETION) e->h_nmol[idx] -= 1;
         if (items[c].kind != MGPU_DELETION && !(c < (int)ln.cand_ok.size() && ln.cand_ok[c])) e->in_range[idx] = 0;
+        frozen_changed(e, items[c].replica, items[c].t);
     }
     // the rows were consumed by the device's commit: nothing is left to commit "from the lane's resident rows"
     ln.last_trial_n = 0;
     ln.d_trial_items = nullptr;
+}
+
+// The sites or the count of a frozen (framework) residue type changed on one replica: it no longer equals the reference
+// copy pair_frozen_kernel sweeps (replica 0's); a change of replica 0 itself invalidates the reference for everyone.
+void frozen_changed(mgpu_engine *e, int replica, int t) {
+    if (!e->frozen[t]) return;
+    auto clear = [&](int r) {
+        char &f = e->frozen_same[(size_t)r * e->tp.n_res + t];
+        if (f) { e->frozen_diff[t] += 1; f = 0; }
+    };
+    if (replica == 0) for (int r = 0; r < e->n_replicas; ++r) clear(r);
+    else clear(replica);
 }
 
 int check_candidate(const mgpu_engine *e, int c, int replica, int t, int m, bool need_resident) {
@@ -344,7 +359,7 @@ int engine_nsplit(const mgpu_engine *e) {
         const int cap = e->tp.cap[t], n1 = e->tp.n1[t];
         units += e->tp.site_major[t] ? cap * ((n1 + 63) / 64) : n1 * ((cap + 63) / 64);
     }
-    int cap_split = 16;
+    int cap_split = 64;
     if (e->n_replicas >= 256) {
         int want = std::max(1, e->n_cu * 64 / e->n_replicas);
         // Short work units (the grand-canonical boxes: a few dozen units per item, and a launch carries 1.5 items per
@@ -404,16 +419,18 @@ int upload_sites(mgpu_engine *e, const double *sites, int n_rows, int site_strid
     return upload_sites(e->lanes[0], sites, n_rows, site_stride);
 }
 
-// resident workgroups per CU of a pair-sweep instantiation (asked of the runtime once per instantiation)
+// resident workgroups per CU of a pair-sweep instantiation: asked of the runtime once per (lane, instantiation, LDS
+// size) -- a lane is driven by one host thread at a time and belongs to one engine (one device, one Coulomb table), so
+// the cache needs no lock and never serves another engine's value
 template <auto Kernel>
-int resident_blocks(size_t dyn_lds) {
-    static int nb = 0;
-    if (nb == 0) {
-        int v = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, Kernel, kPairBlock, dyn_lds) != hipSuccess || v < 1) v = 1;
-        nb = std::min(v, 4);
-    }
-    return nb;
+int resident_blocks(Lane &ln, size_t dyn_lds) {
+    const void *key = (const void *)Kernel;
+    for (const auto &o : ln.occ)
+        if (o.kernel == key && o.lds == dyn_lds) return o.blocks;
+    int v = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, Kernel, kPairBlock, dyn_lds) != hipSuccess || v < 1) v = 1;
+    ln.occ.push_back({key, dyn_lds, std::min(v, 4)});
+    return ln.occ.back().blocks;
 }
 
 // launch the pair sweep + finalize for items already on the device; results land in d_lj / d_c.
@@ -452,7 +469,7 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
     // flat kernels: as many workgroups per CU as their registers and the LDS tables allow
 #define MGPU_LAUNCH_FLAT_1(NS, FU, FW)                                                                                  \
     do {                                                                                                               \
-        const int nb = resident_blocks<&pair_flat_kernel<NS, FU, FW>>(e->coul_bytes);                                  \
+        const int nb = resident_blocks<&pair_flat_kernel<NS, FU, FW>>(ln, e->coul_bytes);                                  \
         const int grid_f = std::max(1, std::min((n_work + kPairWaves - 1) / kPairWaves, e->n_cu * nb));               \
         hipExtLaunchKernelGGL((pair_flat_kernel<NS, FU, FW>), dim3(grid_f), dim3(kPairBlock), e->coul_bytes, ln.stream, a, b, 0, \
                               e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab,   \
@@ -534,7 +551,7 @@ int launch_frozen(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items
     if (rc) return rc;
 #define MGPU_LAUNCH_FROZEN_1(NS, FU, FW)                                                                                \
     do {                                                                                                               \
-        const int nb = resident_blocks<&pair_frozen_kernel<NS, FU, FW>>(e->coul_bytes);                                \
+        const int nb = resident_blocks<&pair_frozen_kernel<NS, FU, FW>>(ln, e->coul_bytes);                                \
         const int grid_f = std::max(1, std::min((n_work + kPairWaves - 1) / kPairWaves, e->n_cu * nb));               \
         hipExtLaunchKernelGGL((pair_frozen_kernel<NS, FU, FW>), dim3(grid_f), dim3(kPairBlock), e->coul_bytes, ln.stream, a, b, 0, \
                               e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab,   \
@@ -636,53 +653,6 @@ int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items
     else MGPU_LAUNCH_RECIP(false, false);
 #undef MGPU_LAUNCH_RECIP
     rc = prof_end(e, ln, slot, a, b);
-    if (rc) return rc;
-    HIP_TRY(hipGetLastError());
-    return MGPU_OK;
-}
-
-// Launch a lane's deferred commit with the stand-alone kernel (only the candidates whose bit is set in `bits`).
-int launch_deferred(mgpu_engine *e, Lane &ln, const AcceptBits &bits) {
-    const Lane::Deferred &d = ln.deferred;
-    return launch_recip(e, ln, d.d_items, d.n, d.n1_max, d.stride, true, e->d_A, nullptr, nullptr, &bits, d.d_sites);
-}
-int flush_deferred(mgpu_engine *e, Lane &ln) {
-    if (!ln.deferred.active) return MGPU_OK;
-    ln.deferred.active = false;
-    ln.dirty = true;
-    return launch_deferred(e, ln, ln.deferred.bits);
-}
-int flush_all_deferred(mgpu_engine *e) {
-    for (auto &ln : e->lanes)
-        if (int rc = flush_deferred(e, ln)) return rc;
-    return MGPU_OK;
-}
-
-// LDS of trial_k_kernel: phase tables of four site sets, one XY table, charges, site coordinates, row table
-size_t trial_k_lds_bytes(const mgpu_engine *e, int n1_max) {
-    const int ktot = e->kmax[0] + e->kmax[1] + e->kmax[2] + 3;
-    return (size_t)4 * n1_max * ktot * sizeof(double2) + (size_t)e->n_rrows * (2 * n1_max * sizeof(double2) + sizeof(RecipRow)) +
-           (size_t)(2 + 12) * n1_max * sizeof(double);
-}
-constexpr int kTrialKMaxTasks = kBlock * 8;     // tasks per launch the fused kernel's registers hold (8 per thread)
-
-// Deferred commit + k sweep of the lane's new trial in one launch (trial_k_kernel)
-int launch_trial_k(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items, int n1_max, int site_stride,
-                   const int *d_pend_idx, double *d_u_new, double *d_u_old) {
-    const Lane::Deferred &d = ln.deferred;
-    const size_t lds = trial_k_lds_bytes(e, n1_max);
-    hipEvent_t a = nullptr, b = nullptr;
-    int rc = prof_begin(e, ln, MGPU_KERNEL_RECIP, &a, &b);
-    if (rc) return rc;
-#define MGPU_LAUNCH_TRIAL_K(NT)                                                                                         \
-    hipExtLaunchKernelGGL((trial_k_kernel<NT>), dim3(n_items), dim3(kBlock), lds, ln.stream, a, b, 0, e->tp, e->bx, e->d_pos, \
-                          e->d_nmol, e->d_res_q, e->d_trj, e->d_tw, e->n_rtasks, e->d_rrows, e->n_rrows, e->d_A, d_items,  \
-                          (const double *)ln.d_sites.p, site_stride, d.d_items, d.d_sites, d.stride, d_pend_idx, n1_max,  \
-                          d_u_new, d_u_old)
-    if (e->n_rtasks <= kBlock * 5) MGPU_LAUNCH_TRIAL_K(5);
-    else MGPU_LAUNCH_TRIAL_K(8);
-#undef MGPU_LAUNCH_TRIAL_K
-    rc = prof_end(e, ln, MGPU_KERNEL_RECIP, a, b);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return MGPU_OK;
@@ -885,7 +855,6 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     e->pair_fast_fold = std::getenv("MGPU_PAIR_EXACT_FOLD") == nullptr;
     if (const char *ov = std::getenv("MGPU_PAIR_FUSE_MAX")) e->pair_fuse_max = std::max(1, std::min(std::atoi(ov), kMaxFusedSitesWide));
     e->recip_force_per_k = std::getenv("MGPU_RECIP_PER_K") != nullptr;
-    e->defer_commits = std::getenv("MGPU_DEFER_COMMIT") != nullptr;
 
     BoxDev &bx = e->bx;
     for (int d = 0; d < 3; ++d) {
@@ -1064,6 +1033,10 @@ int mgpu_engine_destroy(mgpu_engine *e) {
                     (void *)e->d_tw, (void *)e->d_kslot, (void *)e->d_rrows, (void *)e->d_atom_ty, (void *)e->d_com, (void *)e->d_off})
         if (p) (void)hipFree(p);
     e->h_stage.release();
+    for (void *p : {(void *)e->chain.h_cand[0], (void *)e->chain.h_cand[1], (void *)e->chain.h_out, (void *)e->chain.h_tag})
+        if (p) (void)hipHostFree(p);
+    for (void *p : {(void *)e->chain.d_res, (void *)e->chain.d_part, (void *)e->chain.d_ticket})
+        if (p) (void)hipFree(p);
     for (auto &ln : e->lanes) {
         ln.release();
         for (auto &p : ln.pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -1192,16 +1165,23 @@ int mgpu_replica_set_frames(mgpu_engine *e, int replica, int t, int n_mol, const
     const Topo &tp = e->tp;
     const int n1 = tp.n1[t], cap = tp.cap[t];
     std::vector<double> sites((size_t)n_mol * n1 * 3);
+    // "tight": every centre in the cell and every offset's Euclidean norm within 0.24 of the SHORTEST edge -- a bound no
+    // rotation about a Cartesian axis can break (trial_build_kernel rotates offsets; a per-component bound would let a
+    // rotated component grow by sqrt(2) and mix axes of different lengths)
     bool tight = true;
+    const double r_max = 0.24 * std::min(e->bx.L[0], std::min(e->bx.L[1], e->bx.L[2]));
     for (int m = 0; m < n_mol; ++m) {
         for (int d = 0; d < 3; ++d)
             tight = tight && std::fabs(com[(size_t)m * 3 + d] - e->bx.ctr[d]) <= 0.5 * e->bx.L[d];
-        for (int a = 0; a < n1; ++a)
+        for (int a = 0; a < n1; ++a) {
+            double o2 = 0.0;
             for (int d = 0; d < 3; ++d) {
                 const double o = off[((size_t)m * n1 + a) * 3 + d];
                 sites[((size_t)m * n1 + a) * 3 + d] = com[(size_t)m * 3 + d] + o;
-                tight = tight && std::fabs(o) <= 0.24 * e->bx.L[d];
+                o2 += o * o;
             }
+            tight = tight && o2 <= r_max * r_max;
+        }
     }
     if ((rc = mgpu_replica_set_molecules(e, replica, t, n_mol, sites.data()))) return rc;
     if (!e->d_com) {
@@ -1344,6 +1324,7 @@ int mgpu_replica_replace_molecule(mgpu_engine *e, int replica, int t, int m_dst,
     if ((rc = use_device(e))) return rc;
     if ((rc = sync_all_lanes(e))) return rc;
     e->frames_ok[(size_t)replica * tp.n_res + t] = 0;       // a slot copy of the sites only
+    frozen_changed(e, replica, t);
     const int n1 = tp.n1[t];
     for (int d = 0; d < 3; ++d) {
         double *base = e->d_pos + ((size_t)replica * 3 + d) * tp.n_cap_atoms + tp.seg_off[t];
@@ -1568,7 +1549,6 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     int rc;
     if (decide) {
         if (!(decide->temperature > 0.0)) return set_error(MGPU_ERR_INVALID_ARG, "trial_decide_submit: temperature must be positive");
-        if ((rc = flush_deferred(e, ln))) return rc;
         // one candidate per replica: the workgroups commit independently
         if ((int)ln.mark.size() != e->n_replicas) ln.mark.assign(e->n_replicas, -1);
         bool twice = false;
@@ -1600,7 +1580,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     ln.h_trial_items = nullptr;
     const size_t site_bytes = (size_t)n * site_stride * 3 * sizeof(double);
     const size_t pit_cap = 2 * (size_t)n * sizeof(PairItem), rit_bytes = (size_t)n * sizeof(RecipItem);
-    const size_t iit_cap = (size_t)n * sizeof(PairItem) + (size_t)n * sizeof(int);       // intra items | pend_idx
+    const size_t iit_cap = (size_t)n * sizeof(PairItem);       // intra items
     // device-built trials append [move codes (n ints) | uniforms (5 n doubles)] behind everything else, 8-byte aligned
     const size_t build_at = (site_bytes + pit_cap + rit_bytes + iit_cap + 7) & ~(size_t)7;
     const size_t build_mv = ((size_t)n * sizeof(int) + 7) & ~(size_t)7;
@@ -1613,6 +1593,10 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     if (sites && sites == ln.h_in.p && dec_at + dec_bytes > ln.h_in.bytes)
         return set_error(MGPU_ERR_INVALID_ARG, "trial_decide_submit: the lane's site buffer is too small for the acceptance records "
                                                "(mgpu_lane_site_buffer sizes it for them)");
+    // a block lent to the caller is never regrown behind their back (they keep the pointer for the farm's lifetime)
+    if (ln.h_in_lent && dec_at + dec_bytes > ln.h_in.bytes)
+        return set_error(MGPU_ERR_STATE, "trial_submit: this trial needs a larger staging block than the one lent out by "
+                                         "mgpu_lane_site_buffer; call it again with the larger size first");
     if ((rc = ln.h_in.reserve(dec_at + dec_bytes))) return rc;
     double *h_sites = (double *)ln.h_in.p;
     PairItem *pit = (PairItem *)((char *)ln.h_in.p + site_bytes);
@@ -1785,46 +1769,8 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
         }
     }
     if (scratch_records && (rc = ln.d_scratch.reserve(scratch_records * sizeof(double2)))) return rc;
-    // A deferred commit of this lane rides in this trial's k sweep when every new candidate sits on its own replica
-    // and the row-form kernel applies; otherwise it is launched on its own first.
-    bool fused_k = false;
-    int *pend_idx = (int *)((char *)iit + iit_bytes);
-    const size_t pend_bytes = (size_t)n * sizeof(int);
-    if (ln.deferred.active) {
-        Lane::Deferred &d = ln.deferred;
-        const int n1_both = std::max(n1_max, d.n1_max);
-        bool ok = recip_by_rows(e, n1_both) && e->n_rtasks <= kTrialKMaxTasks && trial_k_lds_bytes(e, n1_both) <= 64 * 1024;
-        if ((int)ln.mark.size() != e->n_replicas) ln.mark.assign(e->n_replicas, -1);
-        if (ok) {
-            for (int i = 0; i < d.n; ++i)
-                if ((d.bits.w[i >> 5] >> (i & 31)) & 1u) ln.mark[d.replica[i]] = i;
-            for (int c = 0; c < n && ok; ++c) {
-                const int mk = ln.mark[replica[c]];
-                if (mk == -2) ok = false;                  // second candidate on a replica
-                pend_idx[c] = mk >= 0 ? mk : -1;
-                ln.mark[replica[c]] = -2;
-            }
-            // accepted candidates without a successor on their replica: committed by the stand-alone kernel
-            AcceptBits orphans{};
-            bool any_orphan = false;
-            for (int i = 0; i < d.n; ++i)
-                if (((d.bits.w[i >> 5] >> (i & 31)) & 1u) && ln.mark[d.replica[i]] == i) {
-                    orphans.w[i >> 5] |= 1u << (i & 31);
-                    any_orphan = true;
-                }
-            for (int i = 0; i < d.n; ++i) ln.mark[d.replica[i]] = -1;
-            for (int c = 0; c < n; ++c) ln.mark[replica[c]] = -1;
-            if (ok) {
-                // the previous trial's staging block stays alive in d_prev while this trial fills d_sites
-                std::swap(ln.d_sites, ln.d_prev);
-                if (any_orphan && (rc = launch_deferred(e, ln, orphans))) return rc;
-                fused_k = true;
-            }
-        }
-        if (!ok && (rc = flush_deferred(e, ln))) return rc;
-    }
-    // one staging block [sites | pair items (2n slots) | recip items | intra items | pend_idx] -> one H2D copy
-    const size_t in_bytes = site_bytes + pit_cap + rit_bytes + iit_bytes + (fused_k ? pend_bytes : 0);
+    // one staging block [sites | pair items (2n slots) | recip items | intra items] -> one H2D copy
+    const size_t in_bytes = site_bytes + pit_cap + rit_bytes + iit_bytes;
     if ((rc = ln.d_sites.reserve(dec_at + dec_bytes))) return rc;
     if ((rc = ln.d_out.reserve(out_doubles * sizeof(double)))) return rc;
     if ((rc = ln.h_out.reserve(out_doubles * sizeof(double)))) return rc;
@@ -1845,17 +1791,10 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     const PairItem *d_pit = (const PairItem *)((char *)ln.d_sites.p + site_bytes);
     const RecipItem *d_rit = (const RecipItem *)((char *)ln.d_sites.p + site_bytes + pit_cap);
     const PairItem *d_iit = (const PairItem *)((char *)ln.d_sites.p + site_bytes + pit_cap + rit_bytes);
-    const int *d_pend_idx = (const int *)((const char *)d_iit + iit_bytes);
     double2 *d_part = (double2 *)ln.d_out.p;
     double *d_uo = (double *)ln.d_out.p + 2 * (size_t)n_partials, *d_un = d_uo + n, *d_in = d_un + n;
-    // Kernel order.  With a deferred commit: [commit + k sweep] first (the pair sweep and the intra kernel must see
-    // the committed coordinates), then the pair sweep.  Without: pair sweep first, k sweep second (the order the
-    // stand-alone commit of the other lane overlaps best with; k sweep first was measured 10 % slower there).
-    if (fused_k) {
-        if ((rc = launch_trial_k(e, ln, d_rit, n, std::max(n1_max, ln.deferred.n1_max), site_stride, d_pend_idx, d_un, d_uo)))
-            return rc;
-        ln.deferred.active = false;
-    }
+    // Kernel order: pair sweep first, k sweep second (the order the stand-alone commit of the other lanes overlaps best
+    // with; k sweep first was measured 10 % slower there).
     size_t scratch_at = 0;
     for (const Seg &sg : segs) {
         const bool fb = seg_batched(sg);
@@ -1869,7 +1808,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
             scratch_at += (size_t)sg.n_items * (sg.fused ? 2 : 1) * n_chunks_f;
         }
     }
-    if (!decide && !fused_k && (rc = launch_recip(e, ln, d_rit, n, n1_max, site_stride, false, e->d_A, d_un, d_uo)))
+    if (!decide && (rc = launch_recip(e, ln, d_rit, n, n1_max, site_stride, false, e->d_A, d_un, d_uo)))
         return rc;
     if (n_intra) {
         hipLaunchKernelGGL(intra_kernel, dim3((n_intra + 63) / 64), dim3(64), 0, ln.stream, e->tp, e->bx, e->d_pos, e->d_res_q,
@@ -1959,7 +1898,6 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
     const size_t site_bytes = sites ? (size_t)n * site_stride * 3 * sizeof(double) : 0;
     if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "commit_submit: wait for the lane's trial first");
     ln.dirty = true;
-    if ((rc = flush_deferred(e, ln))) return rc;
     // committing a device-built trial from its resident rows: the rows carry the candidates' frames
     const bool built = !sites && reuse_sites && ln.last_trial_built && n == ln.last_trial_n;
     if (built) site_stride = ln.last_trial_stride;
@@ -2028,18 +1966,8 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
             bits.w[c >> 5] |= 1u << (c & 31);
         }
         if (!same) return set_error(MGPU_ERR_INVALID_ARG, "commit_submit: candidates differ from the lane's last trial");
-        if (e->defer_commits && !built) {
-            // not launched: the lane's next trial_submit applies it inside its k sweep (any other call flushes it)
-            Lane::Deferred &d = ln.deferred;
-            d.active = true;
-            d.n = n; d.stride = site_stride; d.n1_max = ln.trial_n1_max;
-            d.bits = bits;
-            d.d_items = ln.d_trial_items;
-            d.d_sites = (const double *)ln.d_sites.p;
-            d.replica.assign(replica, replica + n);
-        } else if ((rc = launch_recip(e, ln, ln.d_trial_items, n, ln.trial_n1_max, site_stride, true, e->d_A, nullptr, nullptr, &bits))) {
+        if ((rc = launch_recip(e, ln, ln.d_trial_items, n, ln.trial_n1_max, site_stride, true, e->d_A, nullptr, nullptr, &bits)))
             return rc;
-        }
         // applied once: a second commit_submit(sites = NULL) must not find these rows "resident" again
         ln.last_trial_n = 0;
         ln.d_trial_items = nullptr;
@@ -2062,6 +1990,9 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
     }
     for (size_t i = 0; i < new_counts.size(); i += 2) e->h_nmol[new_counts[i]] = new_counts[i + 1];
     for (int idx : range_lost) e->in_range[idx] = 0;
+    if (e->any_frozen)
+        for (int c = 0; c < n; ++c)
+            if (accept[c]) frozen_changed(e, replica[c], t[c]);
     return MGPU_OK;
 }
 
@@ -2073,7 +2004,7 @@ static int check_lane(const mgpu_engine *e, int lane) {
 
 static size_t trial_staging_bytes(int n, int site_stride) {
     return (size_t)n * site_stride * 3 * sizeof(double) + 2 * (size_t)n * sizeof(PairItem) + (size_t)n * sizeof(RecipItem) +
-           (size_t)n * sizeof(PairItem) + (size_t)n * sizeof(int) + 16 + (size_t)n * sizeof(DecideItem);   // + acceptance records
+           (size_t)n * sizeof(PairItem) + 16 + (size_t)n * sizeof(DecideItem);   // + acceptance records
 }
 
 int mgpu_lane_site_buffer(mgpu_engine *e, int lane, int n_max, int site_stride, double **sites) {
@@ -2087,7 +2018,11 @@ int mgpu_lane_site_buffer(mgpu_engine *e, int lane, int n_max, int site_stride, 
     ln.last_trial_n = 0;
     ln.d_trial_items = nullptr;
     ln.h_trial_items = nullptr;
-    if ((rc = ln.h_in.reserve(trial_staging_bytes(n_max, site_stride)))) return rc;
+    // sized for the largest trial shape the lane accepts for n_max candidates: host rows of site_stride sites, or
+    // device-built rows [sites | com | offsets] with their move codes and uniform numbers, acceptance records included
+    const size_t built = trial_staging_bytes(n_max, 2 * site_stride + 1) + ((size_t)n_max * sizeof(int) + 8) + (size_t)5 * n_max * sizeof(double) + 16;
+    if ((rc = ln.h_in.reserve(std::max(trial_staging_bytes(n_max, site_stride), built)))) return rc;
+    ln.h_in_lent = true;
     *sites = (double *)ln.h_in.p;
     return MGPU_OK;
 }
@@ -2220,6 +2155,176 @@ int mgpu_commit_candidates(mgpu_engine *e, int n, const int *replica, const int 
     return sync_stream(e);
 }
 
+
+// ---- single-chain windows --------------------------------------------------------------------
+
+// largest window the engine accepts, 0 where the one-launch path does not apply (triclinic box, molecules of more than
+// kMaxFusedSitesWide sites among the active types, per-k reciprocal form)
+static int chain_max_candidates(const mgpu_engine *e) {
+    if (e->bx.triclinic) return 0;
+    int n1_max = 1;
+    for (int t = 0; t < e->tp.n_res; ++t) {
+        if (!e->is_active[t]) continue;
+        if (e->tp.n1[t] > kMaxFusedSitesWide || e->tp.site_major[t]) return 0;
+        n1_max = std::max(n1_max, e->tp.n1[t]);
+    }
+    if (!recip_by_rows(e, n1_max)) return 0;
+    if (e->coul_bytes > 64 * 1024) return 0;
+    // the resolving workgroup stages every split partial of the window in LDS: 2 entries per candidate at most
+    const int by_lds = (int)((size_t)64 * 1024 / ((size_t)2 * e->pair_nsplit * sizeof(double2)));
+    return std::max(0, std::min(kChainMaxCand, by_lds));
+}
+
+int mgpu_chain_window_capacity(const mgpu_engine *e, int *max_candidates) {
+    if (!e || !max_candidates) return set_error(MGPU_ERR_INVALID_ARG, "chain_window_capacity: null argument");
+    *max_candidates = chain_max_candidates(e);
+    return MGPU_OK;
+}
+
+int mgpu_chain_set_margin(mgpu_engine *e, double relative_margin) {
+    if (!e || !(relative_margin >= 0.0)) return set_error(MGPU_ERR_INVALID_ARG, "chain_set_margin: bad argument");
+    e->chain.margin = relative_margin;
+    return MGPU_OK;
+}
+
+int mgpu_chain_get_stats(const mgpu_engine *e, long long *windows, long long *undecided) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    if (windows) *windows = e->chain.windows;
+    if (undecided) *undecided = e->chain.undecided;
+    return MGPU_OK;
+}
+
+int mgpu_chain_window(mgpu_engine *e, int replica, int n, const int *t, const int *m, const int *kind, const int *link,
+                      const double *sites, int site_stride, const double *accept_u, const double *accept_pref,
+                      double temperature, double recip_energy, double *old_energy, double *new_energy, int *first_accepted,
+                      int *undecided) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    if (!t || !m || !kind || !link || !sites || !accept_u || !accept_pref || !old_energy || !new_energy || !first_accepted || !undecided)
+        return set_error(MGPU_ERR_INVALID_ARG, "chain_window: null argument");
+    const int n_max = chain_max_candidates(e);
+    if (n_max == 0) return set_error(MGPU_ERR_STATE, "chain_window: not available for this engine (mgpu_chain_window_capacity)");
+    if (n < 1 || n > n_max) return set_error(MGPU_ERR_INVALID_ARG, "chain_window: window size out of range");
+    if (replica < 0 || replica >= e->n_replicas) return set_error(MGPU_ERR_INVALID_ARG, "chain_window: replica out of range");
+    if (!(temperature > 0.0)) return set_error(MGPU_ERR_INVALID_ARG, "chain_window: temperature must be positive");
+    int rc = use_device(e);
+    if (rc) return rc;
+    Lane &ln = e->lanes[0];
+    if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "chain_window: lane 0 still holds an un-waited trial");
+    mgpu_engine::Chain &ch = e->chain;
+    if (!ch.h_tag) {
+        for (auto &p : ch.h_cand) HIP_TRY(hipHostMalloc((void **)&p, sizeof(ChainCand) * kChainMaxCand, hipHostMallocCoherent));
+        HIP_TRY(hipHostMalloc((void **)&ch.h_out, sizeof(double) * (10 * kChainMaxCand + 2), hipHostMallocCoherent));
+        HIP_TRY(hipHostMalloc((void **)&ch.h_tag, 64, hipHostMallocCoherent));
+        *ch.h_tag = 0;
+        HIP_TRY(hipMalloc((void **)&ch.d_res, sizeof(ChainResult) * kChainMaxCand));
+        HIP_TRY(hipMalloc((void **)&ch.d_part, sizeof(double2) * 2 * kChainMaxCand * (size_t)e->pair_nsplit));
+        HIP_TRY(hipMalloc((void **)&ch.d_ticket, sizeof(int)));
+        HIP_TRY(hipMemset(ch.d_ticket, 0, sizeof(int)));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    // ---- the window's candidate records, written straight into the pinned block the kernel reads
+    ChainArgs g{};
+    ChainCand *cand = ch.h_cand[(ch.seq + 1) & 1];
+    bool fast = replica_in_range(e, replica);
+    char cand_ok[kChainMaxCand];
+    int n1_max = 1, n_ent = 0;
+    for (int c = 0; c < n; ++c) {
+        const int k = kind[c];
+        if (k < MGPU_MOVE || k > MGPU_DELETION) return set_error(MGPU_ERR_INVALID_ARG, "chain_window: unknown candidate kind");
+        if (t[c] < 0 || t[c] >= e->tp.n_res) return set_error(MGPU_ERR_INVALID_ARG, "chain_window: residue type out of range");
+        const int n1 = e->tp.n1[t[c]];
+        if (n1 > site_stride || n1 > kMaxFusedSitesWide || e->tp.site_major[t[c]])
+            return set_error(MGPU_ERR_INVALID_ARG, "chain_window: molecule too large for the one-launch path");
+        const size_t idx = (size_t)replica * e->tp.n_res + t[c];
+        if (e->d_com && e->frames_ok[idx])
+            return set_error(MGPU_ERR_STATE, "chain_window: this replica holds molecule frames (mgpu_replica_set_frames)");
+        const int lk = link[c];
+        if (lk < -2 || lk >= n) return set_error(MGPU_ERR_INVALID_ARG, "chain_window: bad link");
+        if (lk >= 0 && (k != MGPU_DELETION || link[lk] != -2 || kind[lk] != MGPU_CREATION || t[lk] != t[c]))
+            return set_error(MGPU_ERR_INVALID_ARG, "chain_window: an as-written deletion links to an energy-only creation row of its type");
+        if (lk == -2 && k != MGPU_CREATION) return set_error(MGPU_ERR_INVALID_ARG, "chain_window: energy-only rows are creation-kind");
+        const int mc = (k == MGPU_CREATION) ? -1 : m[c];
+        if ((rc = check_candidate(e, c, replica, t[c], mc, k != MGPU_CREATION))) return rc;
+        if (k == MGPU_CREATION && lk != -2 && e->h_nmol[idx] >= e->tp.cap[t[c]])
+            return set_error(MGPU_ERR_CAPACITY, "chain_window: residue type is at mol_capacity");
+        n1_max = std::max(n1_max, n1);
+        ChainCand &cd = cand[c];
+        cd.t = t[c]; cd.m = mc; cd.kind = k; cd.link = lk;
+        cd.u = accept_u[c]; cd.pref = accept_pref[c]; cd.self = k == MGPU_MOVE ? 0.0 : e->self_of_type[t[c]];
+        cd.pad = 0.0;
+        const double *row = sites + (size_t)c * site_stride * 3;
+        cand_ok[c] = 1;
+        if (k != MGPU_DELETION) {
+            // the engine's site order for a frozen type is not the caller's: such types are inactive and never move
+            if (e->frozen[t[c]]) return set_error(MGPU_ERR_INVALID_ARG, "chain_window: frozen residue types do not move");
+            std::memcpy(&cd.sites[0][0], row, (size_t)n1 * 3 * sizeof(double));
+            cand_ok[c] = sites_in_range(e, row, n1) ? 1 : 0;
+            if (lk != -2) fast = fast && cand_ok[c];
+        }
+        g.ent_old_of[c] = g.ent_new_of[c] = -1;
+        if (lk == -2) continue;
+        if (k != MGPU_CREATION) { g.ent_old_of[c] = (signed char)n_ent; g.ent_c[n_ent] = (unsigned char)c; g.ent_new[n_ent] = 0; ++n_ent; }
+        if (k != MGPU_DELETION) { g.ent_new_of[c] = (signed char)n_ent; g.ent_c[n_ent] = (unsigned char)c; g.ent_new[n_ent] = 1; ++n_ent; }
+    }
+    const int nsplit = e->pair_nsplit;
+    const size_t lds = std::max(std::max(e->coul_bytes, recip_rows_lds_bytes(e, n1_max)), (size_t)n_ent * nsplit * sizeof(double2));
+    if (lds > 64 * 1024) return set_error(MGPU_ERR_CAPACITY, "chain_window: the window does not fit the LDS budget");
+    ch.seq += 1;
+    g.cand = cand; g.res = ch.d_res; g.partials = ch.d_part; g.ticket = ch.d_ticket;
+    g.host_out = ch.h_out; g.host_tag = ch.h_tag; g.seq = ch.seq;
+    g.n = n; g.n_ent = n_ent; g.nsplit = nsplit; g.replica = replica;
+    g.temperature = temperature; g.e_recip = recip_energy; g.margin = ch.margin;
+    const int grid = n + (n_ent * nsplit + kPairWaves - 1) / kPairWaves;
+    const bool ff = fast && e->pair_fast_fold;
+    ln.dirty = true;
+    ln.last_trial_n = 0;
+    ln.d_trial_items = nullptr;
+    ln.h_trial_items = nullptr;
+#define MGPU_LAUNCH_CHAIN(FL, FW)                                                                                          \
+    hipLaunchKernelGGL((chain_window_kernel<FL, FW>), dim3(grid), dim3(kChainBlock), lds, ln.stream, e->tp, e->bx, e->d_pos, e->d_nmol, \
+                       e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab, e->d_trj, e->d_tw, e->n_rtasks, e->d_rrows, e->n_rrows, \
+                       e->d_A, g)
+    if (e->pair_flat) { if (ff) MGPU_LAUNCH_CHAIN(true, true); else MGPU_LAUNCH_CHAIN(true, false); }
+    else { if (ff) MGPU_LAUNCH_CHAIN(false, true); else MGPU_LAUNCH_CHAIN(false, false); }
+#undef MGPU_LAUNCH_CHAIN
+    HIP_TRY(hipGetLastError());
+    // ---- wait for the tag: the results are in host memory when it shows this window's number
+    {
+        volatile unsigned long long *tag = ch.h_tag;
+        long long spins = 0;
+        while (*tag != ch.seq) {
+            __builtin_ia32_pause();
+            if (++spins >= 20000 && (spins % 4096) == 0) {
+                // long past any window's run time: make sure the stream is still alive
+                const hipError_t q = hipStreamQuery(ln.stream);
+                if (q == hipSuccess && *tag != ch.seq) return set_error(MGPU_ERR_HIP, "chain_window: the kernel finished without publishing its results");
+                if (q != hipSuccess && q != hipErrorNotReady) return set_error(MGPU_ERR_HIP, std::string("chain_window: ") + hipGetErrorString(q));
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    for (int c = 0; c < n; ++c) {
+        std::memcpy(old_energy + 5 * (size_t)c, ch.h_out + 10 * (size_t)c, 5 * sizeof(double));
+        std::memcpy(new_energy + 5 * (size_t)c, ch.h_out + 10 * (size_t)c + 5, 5 * sizeof(double));
+    }
+    const int *hi = (const int *)(ch.h_out + 10 * (size_t)n);
+    const int first = hi[0], und = hi[1];
+    *first_accepted = first;
+    *undecided = und;
+    ch.windows += 1;
+    if (und >= 0) ch.undecided += 1;
+    if (first >= 0) {
+        // the device is committing candidate `first` behind the tag: the host mirrors follow
+        const size_t idx = (size_t)replica * e->tp.n_res + t[first];
+        if (kind[first] == MGPU_CREATION) e->h_nmol[idx] += 1;
+        if (kind[first] == MGPU_DELETION) e->h_nmol[idx] -= 1;
+        if (kind[first] != MGPU_DELETION && !cand_ok[first]) e->in_range[idx] = 0;
+        // (an as-written deletion moves resident atoms only: the range flag stands)
+        frozen_changed(e, replica, t[first]);
+    }
+    return MGPU_OK;
+}
+
 // ---- static energy ---------------------------------------------------------------------------
 
 int mgpu_system_energy(mgpu_engine *e, int replica, double out[6]) {
@@ -2286,7 +2391,7 @@ int mgpu_synchronize(mgpu_engine *e) {
     if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
     int rc = use_device(e);
     if (rc) return rc;
-    return sync_all_lanes(e);            // launches any deferred commit first
+    return sync_all_lanes(e);
 }
 
 int mgpu_profile_enable(mgpu_engine *e, int on) {

@@ -188,15 +188,9 @@ int build_coulomb_table(double alpha, double s_max, std::vector<CoulRow> &rows, 
             // subtraction is exact), and t = ds * 64 / 2^e on a row of octave e: scale c_i by (64 / 2^e)^i, a power of two
             CoulRow &row = rows[(size_t)o * per_oct + q];
             const int sh = kCoulM - (kCoulEmin + o);
-#if MGPU_COUL_M == 8
-            for (int i = 0; i < 3; ++i) row.c[i] = (double)ldexpl(tc[i], sh * i);
-            row.c3 = (float)ldexpl(tc[3], sh * 3);
-            row.c4 = (float)ldexpl(tc[4], sh * 4);
-#else
             for (int i = 0; i < 5; ++i) row.c[i] = (double)ldexpl(tc[i], sh * i);
             row.c5 = (float)ldexpl(tc[5], sh * 5);
-            row.c6 = kCoulDeg >= 6 ? (float)ldexpl(tc[kCoulDeg >= 6 ? 6 : 5], sh * 6) : 0.0f;
-#endif
+            row.c6 = (float)ldexpl(tc[6], sh * 6);
         }
     return MGPU_OK;
 }
@@ -217,14 +211,8 @@ double coulomb_table_eval_host(const std::vector<CoulRow> &rows, int idx_base, d
     std::memcpy(&a, &ab, 8);
     const double t = s - a;
     const CoulRow &r = rows[row];
-#if MGPU_COUL_M == 8
-    double p = std::fma((double)r.c4, t, (double)r.c3);
-    for (int i = 2; i >= 0; --i) p = std::fma(p, t, r.c[i]);
-#else
-    double p = (double)r.c5;
-    if (kCoulDeg >= 6) p = std::fma((double)r.c6, t, (double)r.c5);
+    double p = std::fma((double)r.c6, t, (double)r.c5);
     for (int i = 4; i >= 0; --i) p = std::fma(p, t, r.c[i]);
-#endif
     return p;
 }
 

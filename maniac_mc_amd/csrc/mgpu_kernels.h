@@ -39,7 +39,7 @@ constexpr int kBlock = 256;       // threads per workgroup = 4 waves, one per SI
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kSiteChunk = 32;    // candidate sites staged in LDS per pass (generic path)
 #ifndef MGPU_PAIR_BLOCK
-#define MGPU_PAIR_BLOCK (MGPU_COUL_M >= 7 ? 1024 : 512)   // 128 rows per octave: one workgroup per CU shares the (larger) table
+#define MGPU_PAIR_BLOCK 512
 #endif
 #ifndef MGPU_PAIR_MINWAVES
 #define MGPU_PAIR_MINWAVES 4   // <= 128 VGPRs: two 8-wave workgroups per CU (measured best, tools/bench_kernels.py)
@@ -201,25 +201,15 @@ __device__ __forceinline__ double coul_lds(double s, const char *__restrict__ ta
     const double s0 = __hiloint2double(hi & ~kMant, 0);                  // the row's first s: low mantissa bits cleared
     const double t = s - s0;                                             // exact; rows are expanded in it
     const double2 *r = reinterpret_cast<const double2 *>(tab + __umul24(row, (unsigned)sizeof(CoulRow)));
-#if MGPU_COUL_M == 8
-    const double2 c01 = r[0], c2f = r[1];
-    double p = fma((double)__int_as_float(__double2hiint(c2f.y)), t, (double)__int_as_float(__double2loint(c2f.y)));
-    p = fma(p, t, c2f.x);
-    p = fma(p, t, c01.y);
-    p = fma(p, t, c01.x);
-    return p;
-#else
     const double2 c01 = r[0], c23 = r[1], c4f = r[2];
     const double c5 = (double)__int_as_float(__double2loint(c4f.y));
-    double p = c5;
-    if constexpr (kCoulDeg >= 6) p = fma((double)__int_as_float(__double2hiint(c4f.y)), t, c5);
+    double p = fma((double)__int_as_float(__double2hiint(c4f.y)), t, c5);
     p = fma(p, t, c4f.x);
     p = fma(p, t, c23.y);
     p = fma(p, t, c23.x);
     p = fma(p, t, c01.y);
     p = fma(p, t, c01.x);
     return p;
-#endif
 }
 
 // r < 0.5 A (never reached by a physical configuration): direct evaluation.  GUARD: CoulombEnergy's
@@ -270,38 +260,24 @@ __device__ __forceinline__ void pair_term(double dx, double dy, double dz, const
 // ComputeOldEnergy and ComputeNewEnergy (monte_carlo_utils.f90:380-395 / :275-330); each state's sums are
 // formed exactly as the unfused sweep forms them, and the work unit writes two partials {old, new}.
 // ------------------------------------------------------------------------------------------
-template <int NS, bool ORDERED, bool TRI, bool FUSED = false, bool FASTW = false>
-__global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MGPU_PAIR_MINWAVES) void pair_sweep_kernel(
-    Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
+// One work unit (item, split) of the pair sweep, executed by ONE WAVE: every nsplit-th unit of the item's replica, one
+// partial {e_lj, e_coul} per state into partials[w * NST ...].  cand_sites / site_stride: the candidate rows (row it.src);
+// s_coul / s_pair: the workgroup's LDS copies of the Coulomb table and the pair table; w_site / w_sty: this wave's LDS slab
+// (NS = 0 only).  Shared by pair_sweep_kernel and chain_window_kernel.
+template <int NS, bool ORDERED, bool TRI, bool FUSED, bool FASTW>
+__device__ __forceinline__ void pair_sweep_item(
+    const Topo &tp, const BoxDev &bx, const double *__restrict__ pos, const int *__restrict__ nmol,
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
-    const char *__restrict__ coul_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
-    int site_stride, int nsplit, int n_work, double2 *__restrict__ partials) {
+    const char *__restrict__ s_coul, const double2 *__restrict__ s_pair, double *__restrict__ w_site, int *__restrict__ w_sty,
+    const PairItem it, const double *__restrict__ cand_sites, int site_stride, int split, int nsplit, int lane,
+    double2 *__restrict__ partials, int w) {
     static_assert(!FUSED || (NS > 0 && !ORDERED && !TRI), "the fused old + new sweep is a register-site, unordered, orthorhombic path");
     static_assert(!FASTW || (NS > 0 && !ORDERED && !TRI), "the two-instruction fold is a register-site, unordered, orthorhombic path");
     constexpr int NTY = NS > 0 ? NS : 1;                  // sites of the molecule (charge / type per site)
     constexpr int NST = FUSED ? 2 : 1;                    // states swept together (old, new)
     constexpr int NREG = NTY * NST;                       // register-resident sites: state-major, [state][site]
-    constexpr int NSLAB = NS > 0 ? 1 : kPairWaves * kSiteChunk;
-    extern __shared__ __attribute__((aligned(16))) char s_coul[];     // (coul_last_row + 1) x 48 B
-    __shared__ double2 s_pair[kMaxTypes * kMaxTypes];
-    __shared__ double s_site[NSLAB * 4];
-    __shared__ int s_sty[NSLAB];
-
-    for (int i = threadIdx.x; i < (bx.coul_last_row + 1) * kCoulRowVec; i += kPairBlock)
-        reinterpret_cast<double2 *>(s_coul)[i] = reinterpret_cast<const double2 *>(coul_tab_g)[i];
     const int nt = tp.n_types;
-    for (int i = threadIdx.x; i < nt * nt; i += kPairBlock) s_pair[i] = pair_tab[i];
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n_waves = gridDim.x * kPairWaves;
-    double *w_site = s_site + (NS > 0 ? 0 : wave * kSiteChunk * 4);
-    int *w_sty = s_sty + (NS > 0 ? 0 : wave * kSiteChunk);
-
-    for (int w = blockIdx.x * kPairWaves + wave; w < n_work; w += n_waves) {
-        const int item_id = w / nsplit, split = w - item_id * nsplit;
-        const PairItem it = items[item_id];
+    {
         const double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
         const double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
         const int *nm_r = nmol + it.replica * tp.n_res;
@@ -545,6 +521,39 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
     }
 }
 
+template <int NS, bool ORDERED, bool TRI, bool FUSED = false, bool FASTW = false>
+__global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MGPU_PAIR_MINWAVES) void pair_sweep_kernel(
+    Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
+    const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
+    const char *__restrict__ coul_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
+    int site_stride, int nsplit, int n_work, double2 *__restrict__ partials) {
+    constexpr int NST = FUSED ? 2 : 1;
+    constexpr int NSLAB = NS > 0 ? 1 : kPairWaves * kSiteChunk;
+    extern __shared__ __attribute__((aligned(16))) char s_coul[];     // (coul_last_row + 1) x 48 B
+    __shared__ double2 s_pair[kMaxTypes * kMaxTypes];
+    __shared__ double s_site[NSLAB * 4];
+    __shared__ int s_sty[NSLAB];
+
+    for (int i = threadIdx.x; i < (bx.coul_last_row + 1) * kCoulRowVec; i += kPairBlock)
+        reinterpret_cast<double2 *>(s_coul)[i] = reinterpret_cast<const double2 *>(coul_tab_g)[i];
+    const int nt = tp.n_types;
+    for (int i = threadIdx.x; i < nt * nt; i += kPairBlock) s_pair[i] = pair_tab[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_waves = gridDim.x * kPairWaves;
+    double *w_site = s_site + (NS > 0 ? 0 : wave * kSiteChunk * 4);
+    int *w_sty = s_sty + (NS > 0 ? 0 : wave * kSiteChunk);
+
+    for (int w = blockIdx.x * kPairWaves + wave; w < n_work; w += n_waves) {
+        const int item_id = w / nsplit, split = w - item_id * nsplit;
+        const PairItem it = items[item_id];
+        pair_sweep_item<NS, ORDERED, TRI, FUSED, FASTW>(tp, bx, pos, nmol, res_q, res_atype, pair_tab, s_coul, s_pair, w_site, w_sty, it,
+                                                        cand_sites, site_stride, split, nsplit, lane, partials, w);
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------
 // Flat pair sweep: the same sums as pair_sweep_kernel's register-site path (NS > 0, unordered, orthorhombic), organised
@@ -568,35 +577,22 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
 // Semantics per pair term are those of pair_sweep_kernel: LJ inside the cutoff for epsilon != 0 (energy_utils.f90:417-424),
 // erfc(alpha r)/r for every distance where both charges are at least 1e-10 in magnitude (energy_utils.f90:427-432).
 // ------------------------------------------------------------------------------------------
+// One work unit (item, split) of the flat sweep, executed by ONE WAVE; partials[w * NST ...] receives its partials.  s_grp: the
+// workgroup's LDS copy of the frozen residues' group records; w_plane: this wave's LDS slab of kFlatMaxPlanes records.
+// Shared by pair_flat_kernel and chain_window_kernel.
 template <int NS, bool FUSED, bool FASTW>
-__global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MGPU_PAIR_MINWAVES) void pair_flat_kernel(
-    Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
-    const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
-    const char *__restrict__ coul_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
-    int site_stride, int nsplit, int n_work, double2 *__restrict__ partials, int skip_frozen) {
+__device__ __forceinline__ void pair_flat_item(
+    const Topo &tp, const BoxDev &bx, const double *__restrict__ pos, const int *__restrict__ nmol,
+    const double *__restrict__ res_q, const int *__restrict__ res_atype, const char *__restrict__ s_coul,
+    const double2 *__restrict__ s_pair, const int4 *__restrict__ s_grp, int4 *__restrict__ w_plane, const PairItem it,
+    const double *__restrict__ cand_sites, int site_stride, int split, int nsplit, int lane, int skip_frozen,
+    double2 *__restrict__ partials, int w) {
     static_assert(NS > 0, "register sites only");
     constexpr int NTY = NS;
     constexpr int NST = FUSED ? 2 : 1;
     constexpr int NREG = NTY * NST;
-    extern __shared__ __attribute__((aligned(16))) char s_coul[];     // (coul_last_row + 1) x 48 B
-    __shared__ double2 s_pair[kMaxTypes * kMaxTypes];
-    __shared__ int4 s_grp[kMaxGrp];                       // group records of the frozen residues
-    __shared__ int4 s_plane[kPairWaves * kFlatMaxPlanes]; // per wave: the plane table of its current work unit
-
-    if (threadIdx.x < kMaxGrp) s_grp[threadIdx.x] = make_int4(tp.grp_start[threadIdx.x], tp.grp_cnt[threadIdx.x], tp.grp_ty[threadIdx.x], 0);
-    for (int i = threadIdx.x; i < (bx.coul_last_row + 1) * kCoulRowVec; i += kPairBlock)
-        reinterpret_cast<double2 *>(s_coul)[i] = reinterpret_cast<const double2 *>(coul_tab_g)[i];
     const int nt = tp.n_types;
-    for (int i = threadIdx.x; i < nt * nt; i += kPairBlock) s_pair[i] = pair_tab[i];
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n_waves = gridDim.x * kPairWaves;
-
-    for (int w = blockIdx.x * kPairWaves + wave; w < n_work; w += n_waves) {
-        const int item_id = w / nsplit, split = w - item_id * nsplit;
-        const PairItem it = items[item_id];
+    {
         const double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
         const double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
         const int *nm_r = nmol + it.replica * tp.n_res;
@@ -644,7 +640,6 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
         // ---- plane table of this work unit, built by the lanes in parallel (lane l = plane l of the replica, residue
         //      types in order): {first slot, atoms, excluded-molecule flag | dummy molecule << 1, first unit}.  A plane =
         //      site a2 of every molecule of a plane-major type, or one atom-type group of one molecule of a frozen type.
-        int4 *w_plane = s_plane + wave * kFlatMaxPlanes;
         int e_off = 0, e_cnt = 0, e_flags = 0;
         {
             int first = 0;                                           // planes before residue type i
@@ -800,6 +795,37 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
             const double a = wave_sum(elj[st]), b = wave_sum(ec);
             if (lane == 0) partials[(size_t)w * NST + st] = make_double2(a, b);
         }
+    }
+}
+
+template <int NS, bool FUSED, bool FASTW>
+__global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MGPU_PAIR_MINWAVES) void pair_flat_kernel(
+    Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
+    const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
+    const char *__restrict__ coul_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
+    int site_stride, int nsplit, int n_work, double2 *__restrict__ partials, int skip_frozen) {
+    constexpr int NST = FUSED ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) char s_coul[];     // (coul_last_row + 1) x 48 B
+    __shared__ double2 s_pair[kMaxTypes * kMaxTypes];
+    __shared__ int4 s_grp[kMaxGrp];                       // group records of the frozen residues
+    __shared__ int4 s_plane[kPairWaves * kFlatMaxPlanes]; // per wave: the plane table of its current work unit
+
+    if (threadIdx.x < kMaxGrp) s_grp[threadIdx.x] = make_int4(tp.grp_start[threadIdx.x], tp.grp_cnt[threadIdx.x], tp.grp_ty[threadIdx.x], 0);
+    for (int i = threadIdx.x; i < (bx.coul_last_row + 1) * kCoulRowVec; i += kPairBlock)
+        reinterpret_cast<double2 *>(s_coul)[i] = reinterpret_cast<const double2 *>(coul_tab_g)[i];
+    const int nt = tp.n_types;
+    for (int i = threadIdx.x; i < nt * nt; i += kPairBlock) s_pair[i] = pair_tab[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_waves = gridDim.x * kPairWaves;
+
+    for (int w = blockIdx.x * kPairWaves + wave; w < n_work; w += n_waves) {
+        const int item_id = w / nsplit, split = w - item_id * nsplit;
+        const PairItem it = items[item_id];
+        pair_flat_item<NS, FUSED, FASTW>(tp, bx, pos, nmol, res_q, res_atype, s_coul, s_pair, s_grp, s_plane + wave * kFlatMaxPlanes, it,
+                                         cand_sites, site_stride, split, nsplit, lane, skip_frozen, partials, w);
     }
 }
 
@@ -1061,37 +1087,21 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x));
 }
 
-#ifndef MGPU_PHASE_SINCOSPI
-#define MGPU_PHASE_SINCOSPI 0
-#endif
-// Fractional coordinate f = reciprocal^T r along one axis: ComputeAtomPhase's theta is 2 pi f (ewald_phase.f90:41-64;
-// the same sum in the same association order, without the final factor).
+// Fractional phase theta = 2 pi (reciprocal^T r) along one axis: ComputeAtomPhase (ewald_phase.f90:41-64), the same sum
+// in the same association order.
 __device__ __forceinline__ double atom_phase(const BoxDev &bx, int axis, double x, double y, double z) {
     double acc = 0.0;
     acc = acc + bx.rcp[0 * 3 + axis] * x;
     acc = acc + bx.rcp[1 * 3 + axis] * y;
     acc = acc + bx.rcp[2 * 3 + axis] * z;
-#if MGPU_PHASE_SINCOSPI
-    return acc;
-#else
     return kTwoPi * acc;
-#endif
 }
 
-// exp(i k theta), theta = 2 pi f: dcos / dsin of the rounded product k * theta, as ComputePhaseFactors1D
-// (ewald_phase.f90:100-109) -- the default.  MGPU_PHASE_SINCOSPI = 1 evaluates the same phase as sincospi(2 k f) instead
-// (exact argument reduction: k f is rounded once, the doubling is exact, sincospi reduces modulo 2; a third of the
-// instructions of sincos() and 20 SGPRs fewer; both forms carry one rounding of the phase, <= 4e-15 rad at the k of a
-// 50 A box, and differ from each other by that much: < 1e-9 K on a reciprocal energy, every parity test passes with
-// it).  Measured on MI355X (round 3, 2048 items per launch): k sweep 27.4 vs 27.3 us at the SPC/E box, 30.8 vs 31.0 us at
-// the CO2 box -- the table phase is not what the k sweep waits for, so the reference's own form stays.
+// exp(i k theta): dcos / dsin of the rounded product k * theta, as ComputePhaseFactors1D (ewald_phase.f90:100-109).
+// (sincospi(2 k f) -- a third of the instructions -- was measured in round 3 and changed nothing: LABNOTES.md.)
 __device__ __forceinline__ double2 phase_entry(double theta, int k) {
     double s, c;
-#if MGPU_PHASE_SINCOSPI
-    sincospi(2.0 * ((double)k * theta), &s, &c);      // theta is the fractional coordinate f here
-#else
     sincos((double)k * theta, &s, &c);
-#endif
     return make_double2(c, s);
 }
 
@@ -1292,23 +1302,11 @@ struct AcceptBits {
 #define MGPU_COMMIT_MINWAVES 5  // the commit needs 76 VGPRs: five workgroups per CU (measured 26.8 -> 24.7 us at the SPC/E box, 17.2 -> 16.0 us
                                 // at the framework box; the k sweep at five: 25.8 -> 28.8 us, it spills below 125 VGPRs)
 #endif
-#ifndef MGPU_RECIP_EARLY_LOAD
-#define MGPU_RECIP_EARLY_LOAD 0   // bit 0 (k sweep) / bit 1 (commit): request the first chunk of A(k) before the phase tables (see below)
-#endif
-// Phase 3 of recip_rows_kernel: a thread's tasks are taken in chunks; with MGPU_RECIP_PIPELINE two chunks are in flight
-// (the next chunk's A(k), weights and task words are requested before the current chunk's arithmetic).  Measured on
-// MI355X, round 3 (k sweep, us per launch: SPC/E box 2048 items / CO2 box 4096 / framework box 2048):
-//   one chunk of 5 (round 2)      25.8 / 47.0 / 21.7      one chunk of 3     26.1 / 42.3 / 17.7
-//   one chunk of 4                28.7 / 44.0 / 19.8      pipelined, 2 + 2   25.7 / 40.8 / 18.2   <- default
-//   pipelined, 3 + 3 (spills)     38.4 / 67.6 / 20.9
-// A thread visits its tasks in ascending order whatever the chunking, so the sums are the same bits.
-#ifndef MGPU_RECIP_PIPELINE
-#define MGPU_RECIP_PIPELINE 1
-#endif
-#ifndef MGPU_RECIP_TASK_CHUNK
-#define MGPU_RECIP_TASK_CHUNK 2
-#endif
-constexpr int kRecipTaskChunk = MGPU_RECIP_TASK_CHUNK;   // tasks a thread requests ahead of their use
+// Phase 3: a thread's tasks are taken in chunks of kRecipTaskChunk with TWO chunks in flight (the next chunk's A(k),
+// weights and task words are requested before the current chunk's arithmetic).  A thread visits its tasks in ascending
+// order whatever the chunking, so the sums are the same bits.  (Round-3 measurements of the alternatives -- one chunk of
+// 3 / 4 / 5, pipelined 3 + 3, A(k) requested before the tables, cache prefetch, staggered starts: LABNOTES.md.)
+constexpr int kRecipTaskChunk = 2;
 
 // Acceptance decided on the device (recip_rows_kernel<false, true, true>): the k sweep's workgroup is the last kernel of a
 // candidate's trial, so once its two reciprocal energies are summed thread 0 has everything mc_acceptance_probability
@@ -1355,6 +1353,218 @@ __device__ inline bool decide_candidate(const DecideItem &d, const DecideArgs &g
     return x >= 1.0 || d.u <= x;
 }
 
+// ---- the row-form update in pieces (shared by recip_rows_kernel and chain_window_kernel).  All of them are executed by
+//      the first kBlock threads of a workgroup (`tid` < kBlock: `active`); every thread of the workgroup must reach the
+//      barriers inside.
+// LDS view of one item: 1-D tables [nss][ktot] | XY [n_rows][nss] | charges [n1] | rows [n_rows]
+struct RecipLds {
+    double2 *tab, *xy;
+    double *q;
+    RecipRow *rows;
+    int n1, nss, ktot, kofs1, kofs2;
+    bool use_new, use_old, two_sets;
+};
+// site-states: the new sites and the old sites of a move (2 n1); an insertion, a deletion or A += S(sites) carries ONE set
+// (n1) -- half the table entries, XY products and inner-loop terms.  kind 5 (chain windows only): the reference's
+// deletion as written: A gains the terms of the sites in the candidate row, the coordinates lose slot m.
+__device__ __forceinline__ RecipLds recip_lds_view(const Topo &tp, const BoxDev &bx, const RecipItem &it, int n_rows, double2 *s_tab) {
+    RecipLds v;
+    v.use_new = (it.kind == 0 /*MOVE*/ || it.kind == 1 /*CREATION*/ || it.kind == 4 /*FOURIER_ADD*/ || it.kind == 5 /*DELETION as written*/);
+    v.use_old = (it.kind == 0 /*MOVE*/ || it.kind == 2 /*DELETION*/);
+    v.two_sets = v.use_new && v.use_old;
+    v.n1 = tp.n1[it.t];
+    v.nss = v.two_sets ? 2 * v.n1 : v.n1;
+    v.kofs1 = bx.kmax[0] + 1;
+    v.kofs2 = bx.kmax[0] + bx.kmax[1] + 2;
+    v.ktot = bx.kmax[0] + bx.kmax[1] + bx.kmax[2] + 3;
+    v.tab = s_tab;
+    v.xy = s_tab + v.nss * v.ktot;
+    v.q = reinterpret_cast<double *>(v.xy + n_rows * v.nss);
+    v.rows = reinterpret_cast<RecipRow *>(v.q + v.n1);
+    return v;
+}
+
+// phases 1 and 2 (two workgroup barriers inside).  cand_row = the item's candidate row (new sites), unused without one
+__device__ __forceinline__ void recip_rows_tables(const Topo &tp, const BoxDev &bx, const double *__restrict__ pos,
+                                                  const double *__restrict__ res_q, const RecipRow *__restrict__ rows, int n_rows,
+                                                  const RecipItem &it, const double *__restrict__ cand_row, const RecipLds &v,
+                                                  int tid, bool active) {
+    const double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
+    const double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
+    const int n1 = v.n1, nss = v.nss, ktot = v.ktot;
+    if (active) {
+        for (int r = tid; r < n_rows; r += kBlock) v.rows[r] = rows[r];
+        // phase 1: entry (s, axis, k >= 0) at tab[s * ktot + kofs[axis] + k]; s = set * n1 + a with both sets, s = a with one
+        // (set 0 = the new sites, set 1 = the old ones)
+        for (int e = tid; e < nss * ktot; e += kBlock) {
+            const int s = e / ktot, kk = e - s * ktot;
+            const int set = v.two_sets ? (s >= n1 ? 1 : 0) : (v.use_old ? 1 : 0), a = s - (s >= n1 ? n1 : 0);
+            const int axis = (kk >= v.kofs2) ? 2 : (kk >= v.kofs1 ? 1 : 0);
+            const int k0 = axis == 2 ? v.kofs2 : (axis == 1 ? v.kofs1 : 0);
+            // with no set at all (MGPU_NONE: the energy of A as it is) the entries are zero and phase 3 adds nothing
+            const bool used = v.use_new || v.use_old;
+            double x = 0.0, y = 0.0, z = 0.0;
+            if (used) {
+                if (set == 0) {
+                    const double *c = cand_row + (size_t)a * 3;
+                    x = c[0]; y = c[1]; z = c[2];
+                } else {
+                    const int j = atom_slot(tp, it.t, it.m, a);
+                    x = px[j]; y = py[j]; z = pz[j];
+                }
+            }
+            v.tab[e] = used ? phase_entry(atom_phase(bx, axis, x, y, z), kk - k0) : make_double2(0.0, 0.0);
+        }
+        for (int a = tid; a < n1; a += kBlock) v.q[a] = res_q[it.t * tp.max_atom + a];
+    }
+    __syncthreads();
+    // phase 2: XY[row][s] = (+q for the new sites, -q for the old ones) * X[kx] * Y[ky]   (ewald_energy.f90:241-256)
+    if (active) {
+        for (int e = tid; e < n_rows * nss; e += kBlock) {
+            const int row = e / nss, s = e - row * nss;
+            const int set = v.two_sets ? (s >= n1 ? 1 : 0) : (v.use_old ? 1 : 0), a = s - (s >= n1 ? n1 : 0);
+            double2 xy = make_double2(0.0, 0.0);
+            if (v.use_new || v.use_old) {
+                const RecipRow r = v.rows[row];
+                const double2 *t = v.tab + s * ktot;
+                const int aky = r.ky < 0 ? -r.ky : r.ky;
+                double2 Y = t[v.kofs1 + aky];
+                if (r.ky < 0) Y.y = -Y.y;
+                xy = cmul(t[r.kx], Y);
+                const double q = set == 0 ? v.q[a] : -v.q[a];
+                xy.x *= q; xy.y *= q;
+            }
+            v.xy[e] = xy;
+        }
+    }
+    __syncthreads();
+}
+
+// phase 3: one pass over the replica's A(k) by the first kBlock threads.  STORE = false: acc += ff W |A + delta|^2 and, with
+// BOTH, acc0 += ff W |A|^2 (the reference's ComputeOldEnergy call, delta = 0); STORE = true: A <- A + delta.
+// A(k) (32 contiguous bytes per task, the bulk of the kernel's memory traffic), ff*W and the task words of a whole chunk
+// are requested before any of them is used; none of the addresses depends on a load.
+template <bool STORE, bool BOTH>
+__device__ __forceinline__ void recip_rows_pass(const RecipLds &v, const int *__restrict__ trj, const double2 *__restrict__ tw, int n_tasks,
+                                                double2 *__restrict__ A, int tid, double &acc, double &acc0) {
+    struct Chunk {
+        int rj[kRecipTaskChunk];
+        double2 Ap[kRecipTaskChunk], Am[kRecipTaskChunk], w[kRecipTaskChunk];
+    };
+    const int nss = v.nss, ktot = v.ktot;
+    auto load_chunk = [&](Chunk &ch, int t0) {
+#pragma unroll
+        for (int c = 0; c < kRecipTaskChunk; ++c) {
+            const int t = t0 + c * kBlock;
+            const bool in = t < n_tasks;
+            ch.rj[c] = in ? trj[t] : 0;                                // filler: row 0, j 0, nothing present
+            ch.Ap[c] = in ? A[2 * t] : make_double2(0.0, 0.0);
+            ch.Am[c] = in ? A[2 * t + 1] : make_double2(0.0, 0.0);
+            ch.w[c] = (in && !STORE) ? tw[t] : make_double2(0.0, 0.0);
+        }
+    };
+    const double2 *zt = v.tab + v.kofs2;
+    // the tasks of one chunk: a thread's tasks are visited in ascending order whatever the chunk size, so the sums do
+    // not depend on it
+    auto compute_chunk = [&](const Chunk &ch, int t0) {
+#pragma unroll
+        for (int c = 0; c < kRecipTaskChunk; ++c) {
+            const double2 *xy = v.xy + ((ch.rj[c] >> 8) & 0xfffff) * nss;
+            const double2 *z = zt + (ch.rj[c] & 0xff);
+            double sac = 0.0, sbd = 0.0, sad = 0.0, sbc = 0.0;
+            for (int s = 0; s < nss; ++s) {
+                const double2 p = xy[s], q = z[s * ktot];
+                sac = fma(p.x, q.x, sac);
+                sbd = fma(p.y, q.y, sbd);
+                sad = fma(p.x, q.y, sad);
+                sbc = fma(p.y, q.x, sbc);
+            }
+            const double wp = ch.w[c].x, wm = ch.w[c].y;
+            // explicit fma forms: every kernel that forms these sums must produce the same bits, and a contraction left to
+            // the compiler may pick a different product to fuse in a different kernel
+            if (BOTH && !STORE) acc0 += fma(wp, fma(ch.Ap[c].x, ch.Ap[c].x, ch.Ap[c].y * ch.Ap[c].y), wm * fma(ch.Am[c].x, ch.Am[c].x, ch.Am[c].y * ch.Am[c].y));
+            const double npx = ch.Ap[c].x + (sac - sbd), npy = ch.Ap[c].y + (sad + sbc);
+            const double nmx = ch.Am[c].x + (sac + sbd), nmy = ch.Am[c].y + (sbc - sad);
+            if (STORE) {
+                const int t = t0 + c * kBlock;
+                if (t < n_tasks) {        // absent members stay zero
+                    A[2 * t] = (ch.rj[c] & kTaskHasP) ? make_double2(npx, npy) : make_double2(0.0, 0.0);
+                    A[2 * t + 1] = (ch.rj[c] & kTaskHasM) ? make_double2(nmx, nmy) : make_double2(0.0, 0.0);
+                }
+            } else {
+                acc += fma(wp, fma(npx, npx, npy * npy), wm * fma(nmx, nmx, nmy * nmy));   // ewald_energy.f90:259-266
+            }
+        }
+    };
+    constexpr int kStride = kBlock * kRecipTaskChunk;
+    // two chunks in flight: the next chunk's A(k) is requested before the current one is consumed
+    Chunk ch0, ch1;
+    int t0 = tid;
+    if (t0 < n_tasks) load_chunk(ch0, t0);
+    while (t0 < n_tasks) {
+        const int t1 = t0 + kStride;
+        if (t1 < n_tasks) load_chunk(ch1, t1);
+        compute_chunk(ch0, t0);
+        if (t1 >= n_tasks) break;
+        const int t2 = t1 + kStride;
+        if (t2 < n_tasks) load_chunk(ch0, t2);
+        compute_chunk(ch1, t1);
+        t0 = t2;
+    }
+}
+
+// The coordinate / frame / count part of a commit (every read of the old coordinates happened before the first barrier
+// of recip_rows_tables).  it.m / it.aux are final here (see recip_commit_target).
+__device__ __forceinline__ void recip_commit_tail(const Topo &tp, double *__restrict__ pos, int *__restrict__ nmol, const RecipItem &it,
+                                                  const double *__restrict__ cand_row, int tid) {
+    double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
+    double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
+    const int n1 = tp.n1[it.t];
+    if (it.kind == 0 || it.kind == 1) {
+        if (tid < n1) {
+            const double *c = cand_row + (size_t)tid * 3;
+            const int j = atom_slot(tp, it.t, it.m, tid);
+            px[j] = c[0]; py[j] = c[1]; pz[j] = c[2];
+        }
+    } else if (it.kind == 2 || it.kind == 5) {
+        const int last = it.aux;          // swap-with-last, delete_molecule.f90:107-114: slot m <- slot (new count)
+        if (tid < n1 && last != it.m) {
+            const int j = atom_slot(tp, it.t, it.m, tid), jl = atom_slot(tp, it.t, last, tid);
+            px[j] = px[jl]; py[j] = py[jl]; pz[j] = pz[jl];
+        }
+    }
+    // molecule frames, where the engine keeps them: a device-built move / insertion writes its com and offsets back,
+    // a deletion moves the last molecule's frame with its sites
+    if (tp.com) {
+        const size_t rep3 = (size_t)it.replica * 3;
+        double *fcom = tp.com + rep3 * tp.n_mol_slots + tp.mol_off[it.t];
+        double *foff = tp.off + rep3 * tp.n_cap_atoms;
+        if ((it.kind == 0 || it.kind == 1) && it.frame > 0) {
+            const double *fr = cand_row + (size_t)it.frame * 3;
+            if (tid < 3) fcom[(size_t)tid * tp.n_mol_slots + it.m] = fr[tid];
+            if (tid < n1) {
+                const int j = atom_slot(tp, it.t, it.m, tid);
+                for (int d = 0; d < 3; ++d) foff[(size_t)d * tp.n_cap_atoms + j] = fr[(1 + tid) * 3 + d];
+            }
+        } else if ((it.kind == 2 || it.kind == 5) && it.aux != it.m) {
+            const int last = it.aux;
+            if (tid < 3) fcom[(size_t)tid * tp.n_mol_slots + it.m] = fcom[(size_t)tid * tp.n_mol_slots + last];
+            if (tid < n1) {
+                const int j = atom_slot(tp, it.t, it.m, tid), jl = atom_slot(tp, it.t, last, tid);
+                for (int d = 0; d < 3; ++d) foff[(size_t)d * tp.n_cap_atoms + j] = foff[(size_t)d * tp.n_cap_atoms + jl];
+            }
+        }
+    }
+    if (tid == 0 && (it.kind == 1 || it.kind == 2 || it.kind == 5)) nmol[it.replica * tp.n_res + it.t] = it.aux;
+}
+// a trial's item carries no target slot / new count: take them from the replica's live count
+__device__ __forceinline__ void recip_commit_target(const Topo &tp, const int *__restrict__ nmol, RecipItem &it) {
+    if (it.kind != 1 && it.kind != 2 && it.kind != 5) return;
+    const int nm = nmol[it.replica * tp.n_res + it.t];
+    if (it.kind == 1) { it.m = nm; it.aux = nm + 1; }     // appended (monte_carlo.f90:63, create_molecule.f90:64)
+    else it.aux = nm - 1;                                 // swap-with-last target
+}
+
 template <bool COMMIT, bool BOTH, bool DECIDE = false>
 __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_MINWAVES) void recip_rows_kernel(
     Topo tp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
@@ -1370,169 +1580,23 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
     RecipItem it = items[blockIdx.x];
     if (COMMIT && use_accept) {
         if (!((accept.w[blockIdx.x >> 5] >> (blockIdx.x & 31)) & 1u)) return;        // uniform per workgroup
-        if (it.kind != 0) {
-            // the trial's item carries no target slot / new count: take them from the replica's live count
-            const int nm = nmol[it.replica * tp.n_res + it.t];
-            if (it.kind == 1) { it.m = nm; it.aux = nm + 1; }     // appended (monte_carlo.f90:63, create_molecule.f90:64)
-            else it.aux = nm - 1;                                 // swap-with-last target
-        }
+        recip_commit_target(tp, nmol, it);
     }
-    // site-states: the new sites and the old sites of a move (2 n1); an insertion, a deletion or A += S(sites) carries
-    // ONE set (n1) -- half the table entries, XY products and inner-loop terms
-    const bool use_new = (it.kind == 0 /*MOVE*/ || it.kind == 1 /*CREATION*/ || it.kind == 4 /*FOURIER_ADD*/);
-    const bool use_old = (it.kind == 0 /*MOVE*/ || it.kind == 2 /*DELETION*/);
-    const bool two_sets = use_new && use_old;
-    const int n1 = tp.n1[it.t], nss = two_sets ? 2 * n1 : n1;
-    const int kofs[3] = {0, bx.kmax[0] + 1, bx.kmax[0] + bx.kmax[1] + 2};
-    const int ktot = bx.kmax[0] + bx.kmax[1] + bx.kmax[2] + 3;
-    double2 *s_xy = s_tab + nss * ktot;
-    double *s_q = reinterpret_cast<double *>(s_xy + n_rows * nss);
-    RecipRow *s_rows = reinterpret_cast<RecipRow *>(s_q + n1);
-    double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
-    double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
+    const double *cand_row = cand_sites + (size_t)(it.src < 0 ? 0 : it.src) * site_stride * 3;
+    const RecipLds v = recip_lds_view(tp, bx, it, n_rows, s_tab);
     double2 *A = A_base + (size_t)it.replica * bx.n_slots;
+    const int tid = threadIdx.x;
 
-    for (int r = threadIdx.x; r < n_rows; r += kBlock) s_rows[r] = rows[r];
-
-    // A(k) (32 contiguous bytes per task, the bulk of the kernel's memory traffic), ff*W and the task words of a
-    // whole chunk are requested before any of them is used; none of the addresses depends on a load.
-    // (MGPU_RECIP_EARLY_LOAD = 1 requests the first chunk -- all of a thread's tasks at the bench size -- HERE, before
-    // the phase tables are built, so that the memory round trip would run under the sincos / XY phases.  Measured on
-    // MI355X, 2048 items: k sweep 27.3 -> 35.0 us, commit 25.2 -> 27.5 us: holding 65 VGPRs of loaded data across the
-    // sincos phase spills 37 dwords under the 128-VGPR cap that keeps every item's workgroup resident.
-    // Round 3, same idea without the registers and without the lock step, all measured slower or equal and removed again:
-    // touching one dword per 128-byte line of A(k) right after the coordinate loads so that HBM fills L2 / Infinity Cache
-    // under the table phases (k sweep 27.0 -> 32.8 us at the SPC/E box, 32.0 -> 41.3 us at the CO2 box; commit 27.4 ->
-    // 31.3 / 33.9 -> 37.4 us: loads return in order, so the touches delay everything behind them); starting the four
-    // workgroups that share a CU 0.5 / 1.2 / 3 us apart (s_sleep) so that they sit in different phases (27.2 -> 27.5 /
-    // 29.8 / 35.4 us); sincospi phase tables (a third of the table phase's instructions: 27.4 vs 27.3 us).)
-    struct Chunk {
-        int rj[kRecipTaskChunk];
-        double2 Ap[kRecipTaskChunk], Am[kRecipTaskChunk], w[kRecipTaskChunk];
-    };
-    Chunk ch0;
-    auto load_chunk = [&](Chunk &ch, int t0, auto store) {             // store: the chunk feeds the commit pass (no weights)
-#pragma unroll
-        for (int c = 0; c < kRecipTaskChunk; ++c) {
-            const int t = t0 + c * kBlock;
-            const bool in = t < n_tasks;
-            ch.rj[c] = in ? trj[t] : 0;                                // filler: row 0, j 0, nothing present
-            ch.Ap[c] = in ? A[2 * t] : make_double2(0.0, 0.0);
-            ch.Am[c] = in ? A[2 * t + 1] : make_double2(0.0, 0.0);
-            ch.w[c] = (in && !decltype(store)::value) ? tw[t] : make_double2(0.0, 0.0);
-        }
-    };
-    constexpr std::integral_constant<bool, COMMIT> kStore{};
-    constexpr bool kEarly = ((MGPU_RECIP_EARLY_LOAD) >> (COMMIT ? 1 : 0)) & 1;
-    if constexpr (kEarly) load_chunk(ch0, threadIdx.x, kStore);
-
-    // phase 1: entry (s, axis, k >= 0) at s_tab[s * ktot + kofs[axis] + k]; s = set * n1 + a with both sets, s = a with one
-    // (set 0 = the new sites, set 1 = the old ones)
-    for (int e = threadIdx.x; e < nss * ktot; e += kBlock) {
-        const int s = e / ktot, kk = e - s * ktot;
-        const int set = two_sets ? (s >= n1 ? 1 : 0) : (use_old ? 1 : 0), a = s - (s >= n1 ? n1 : 0);
-        const int axis = (kk >= kofs[2]) ? 2 : (kk >= kofs[1] ? 1 : 0);
-        // with no set at all (MGPU_NONE: the energy of A as it is) the entries are zero and phase 3 adds nothing
-        const bool used = use_new || use_old;
-        double x = 0.0, y = 0.0, z = 0.0;
-        if (used) {
-            if (set == 0) {
-                const double *c = cand_sites + ((size_t)it.src * site_stride + a) * 3;
-                x = c[0]; y = c[1]; z = c[2];
-            } else {
-                const int j = atom_slot(tp, it.t, it.m, a);
-                x = px[j]; y = py[j]; z = pz[j];
-            }
-        }
-        s_tab[e] = used ? phase_entry(atom_phase(bx, axis, x, y, z), kk - kofs[axis]) : make_double2(0.0, 0.0);
-    }
-    for (int a = threadIdx.x; a < n1; a += kBlock) s_q[a] = res_q[it.t * tp.max_atom + a];
-    __syncthreads();
-
-    // phase 2: XY[row][s] = (+q for the new sites, -q for the old ones) * X[kx] * Y[ky]   (ewald_energy.f90:241-256)
-    for (int e = threadIdx.x; e < n_rows * nss; e += kBlock) {
-        const int row = e / nss, s = e - row * nss;
-        const int set = two_sets ? (s >= n1 ? 1 : 0) : (use_old ? 1 : 0), a = s - (s >= n1 ? n1 : 0);
-        double2 v = make_double2(0.0, 0.0);
-        if (use_new || use_old) {
-            const RecipRow r = s_rows[row];
-            const double2 *t = s_tab + s * ktot;
-            const int aky = r.ky < 0 ? -r.ky : r.ky;
-            double2 Y = t[kofs[1] + aky];
-            if (r.ky < 0) Y.y = -Y.y;
-            v = cmul(t[r.kx], Y);
-            const double q = set == 0 ? s_q[a] : -s_q[a];
-            v.x *= q; v.y *= q;
-        }
-        s_xy[e] = v;
-    }
-    __syncthreads();
-
-    const double2 *zt = s_tab + kofs[2];
+    recip_rows_tables(tp, bx, pos, res_q, rows, n_rows, it, cand_row, v, tid, true);
     double acc = 0.0, acc0 = 0.0;
-    // the tasks of one chunk: a thread's tasks are visited in ascending order whatever the chunk size, so the sums do
-    // not depend on it
-    auto compute_chunk = [&](const Chunk &ch, int t0, auto store) {
-#pragma unroll
-        for (int c = 0; c < kRecipTaskChunk; ++c) {
-            const double2 *xy = s_xy + ((ch.rj[c] >> 8) & 0xfffff) * nss;
-            const double2 *z = zt + (ch.rj[c] & 0xff);
-            double sac = 0.0, sbd = 0.0, sad = 0.0, sbc = 0.0;
-            for (int s = 0; s < nss; ++s) {
-                const double2 p = xy[s], q = z[s * ktot];
-                sac = fma(p.x, q.x, sac);
-                sbd = fma(p.y, q.y, sbd);
-                sad = fma(p.x, q.y, sad);
-                sbc = fma(p.y, q.x, sbc);
-            }
-            const double wp = ch.w[c].x, wm = ch.w[c].y;
-            // explicit fma forms: the deferred-commit kernel must produce the same bits, and a contraction left to the
-            // compiler may pick a different product to fuse in a different kernel
-            if (BOTH && !decltype(store)::value) acc0 += fma(wp, fma(ch.Ap[c].x, ch.Ap[c].x, ch.Ap[c].y * ch.Ap[c].y), wm * fma(ch.Am[c].x, ch.Am[c].x, ch.Am[c].y * ch.Am[c].y));
-            const double npx = ch.Ap[c].x + (sac - sbd), npy = ch.Ap[c].y + (sad + sbc);
-            const double nmx = ch.Am[c].x + (sac + sbd), nmy = ch.Am[c].y + (sbc - sad);
-            if (decltype(store)::value) {
-                const int t = t0 + c * kBlock;
-                if (t < n_tasks) {        // absent members stay zero
-                    A[2 * t] = (ch.rj[c] & kTaskHasP) ? make_double2(npx, npy) : make_double2(0.0, 0.0);
-                    A[2 * t + 1] = (ch.rj[c] & kTaskHasM) ? make_double2(nmx, nmy) : make_double2(0.0, 0.0);
-                }
-            } else {
-                acc += fma(wp, fma(npx, npx, npy * npy), wm * fma(nmx, nmx, nmy * nmy));   // ewald_energy.f90:259-266
-            }
-        }
-    };
-    constexpr int kStride = kBlock * kRecipTaskChunk;
-#if MGPU_RECIP_PIPELINE
-    // two chunks in flight: the next chunk's A(k) is requested before the current one is consumed
-    {
-        Chunk ch1;
-        int t0 = threadIdx.x;
-        if (!kEarly && t0 < n_tasks) load_chunk(ch0, t0, kStore);
-        while (t0 < n_tasks) {
-            const int t1 = t0 + kStride;
-            if (t1 < n_tasks) load_chunk(ch1, t1, kStore);
-            compute_chunk(ch0, t0, kStore);
-            if (t1 >= n_tasks) break;
-            const int t2 = t1 + kStride;
-            if (t2 < n_tasks) load_chunk(ch0, t2, kStore);
-            compute_chunk(ch1, t1, kStore);
-            t0 = t2;
-        }
-    }
-#else
-    for (int t0 = threadIdx.x; t0 < n_tasks; t0 += kStride) {
-        if (!kEarly || t0 != (int)threadIdx.x) load_chunk(ch0, t0, kStore);
-        compute_chunk(ch0, t0, kStore);
-    }
-#endif
+    recip_rows_pass<COMMIT, BOTH>(v, trj, tw, n_tasks, A, tid, acc, acc0);
 
     if (!COMMIT) {
         acc = wave_sum(acc);
         if (BOTH) acc0 = wave_sum(acc0);
-        if ((threadIdx.x & 63) == 0) { s_red[2 * (threadIdx.x >> 6)] = acc; s_red[2 * (threadIdx.x >> 6) + 1] = acc0; }
+        if ((tid & 63) == 0) { s_red[2 * (tid >> 6)] = acc; s_red[2 * (tid >> 6) + 1] = acc0; }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             double u = 0.0, u0 = 0.0;
             for (int wv = 0; wv < kWavesPerBlock; ++wv) { u += s_red[2 * wv]; u0 += s_red[2 * wv + 1]; }
             const double e_new = u * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;   // ewald_energy.f90:272
@@ -1549,272 +1613,12 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
     if constexpr (DECIDE) {
         __syncthreads();
         if (!s_flag) return;                                          // uniform per workgroup
-        if (it.kind != 0) {
-            // as the commit by accept mask: target slot / new count from the replica's live count
-            const int nm = nmol[it.replica * tp.n_res + it.t];
-            if (it.kind == 1) { it.m = nm; it.aux = nm + 1; }
-            else it.aux = nm - 1;
-        }
+        recip_commit_target(tp, nmol, it);
         // A <- A + delta from the tables still in LDS: the stand-alone commit's pass (same sums, same bits); this
         // workgroup has just read the replica's A(k), so the second read comes from L2 / the Infinity Cache
-        constexpr std::true_type kYes{};
-        for (int t0 = threadIdx.x; t0 < n_tasks; t0 += kStride) {
-            load_chunk(ch0, t0, kYes);
-            compute_chunk(ch0, t0, kYes);
-        }
+        recip_rows_pass<true, false>(v, trj, tw, n_tasks, A, tid, acc, acc0);
     }
-    if (COMMIT || DECIDE) {
-        // every read of the old coordinates happened before the first barrier
-        if (it.kind == 0 || it.kind == 1) {
-            if (threadIdx.x < n1) {
-                const double *c = cand_sites + ((size_t)it.src * site_stride + threadIdx.x) * 3;
-                const int j = atom_slot(tp, it.t, it.m, threadIdx.x);
-                px[j] = c[0]; py[j] = c[1]; pz[j] = c[2];
-            }
-        } else if (it.kind == 2) {
-            const int last = it.aux;          // swap-with-last, delete_molecule.f90:107-114
-            if (threadIdx.x < n1 && last != it.m) {
-                const int j = atom_slot(tp, it.t, it.m, threadIdx.x), jl = atom_slot(tp, it.t, last, threadIdx.x);
-                px[j] = px[jl]; py[j] = py[jl]; pz[j] = pz[jl];
-            }
-        }
-        // molecule frames, where the engine keeps them: a device-built move / insertion writes its com and offsets back,
-        // a deletion moves the last molecule's frame with its sites
-        if (tp.com) {
-            const size_t rep3 = (size_t)it.replica * 3;
-            double *fcom = tp.com + rep3 * tp.n_mol_slots + tp.mol_off[it.t];
-            double *foff = tp.off + rep3 * tp.n_cap_atoms;
-            if ((it.kind == 0 || it.kind == 1) && it.frame > 0) {
-                const double *fr = cand_sites + ((size_t)it.src * site_stride + it.frame) * 3;
-                if (threadIdx.x < 3) fcom[(size_t)threadIdx.x * tp.n_mol_slots + it.m] = fr[threadIdx.x];
-                if (threadIdx.x < n1) {
-                    const int j = atom_slot(tp, it.t, it.m, threadIdx.x);
-                    for (int d = 0; d < 3; ++d) foff[(size_t)d * tp.n_cap_atoms + j] = fr[(1 + threadIdx.x) * 3 + d];
-                }
-            } else if (it.kind == 2 && it.aux != it.m) {
-                const int last = it.aux;
-                if (threadIdx.x < 3) fcom[(size_t)threadIdx.x * tp.n_mol_slots + it.m] = fcom[(size_t)threadIdx.x * tp.n_mol_slots + last];
-                if (threadIdx.x < n1) {
-                    const int j = atom_slot(tp, it.t, it.m, threadIdx.x), jl = atom_slot(tp, it.t, last, threadIdx.x);
-                    for (int d = 0; d < 3; ++d) foff[(size_t)d * tp.n_cap_atoms + j] = foff[(size_t)d * tp.n_cap_atoms + jl];
-                }
-            }
-        }
-        if (threadIdx.x == 0 && (it.kind == 1 || it.kind == 2)) nmol[it.replica * tp.n_res + it.t] = it.aux;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Deferred commit + k sweep of a lane's NEXT trial in one launch (row form), one workgroup per candidate of the
-// new trial.  The host accepted some candidates of the lane's previous trial but did not launch their commit:
-// the workgroup of the new candidate on the same replica applies it --
-//   delta_prev(k) of the previous accepted move and delta_cur(k) of the new candidate are both formed from phase
-//   tables built in ONE pass (four site sets: candidate new / old, previous new / old); then ONE pass over A(k):
-//   A <- A + delta_prev (stored, coordinates / count of the replica updated exactly as the stand-alone commit does),
-//   u_old = sum ff W |A|^2 and u_new = sum ff W |A + delta_cur|^2 on the updated A
-// -- so A(k) crosses HBM once per trial (read) plus once per accepted move (write) and the commit costs neither a
-// launch nor a second latency chain.  The arithmetic per k is the stand-alone kernels' (A + delta_prev formed the same
-// way, energies from the stored value), so results are bitwise those of commit launch + k sweep.  The previous
-// trial's items and site rows are still resident in the lane's other staging buffer.  Every candidate of the new
-// trial must sit on a different replica (the host checks it); accepted previous candidates whose replica has no new
-// candidate are committed by the stand-alone kernel.  The "old" sites of the new candidate are read BEFORE the
-// coordinate update and patched where the previous move touched the same slot (it moved / created that molecule,
-// or its swap-with-last filled that slot).  NT = tasks per thread the registers hold (n_tasks <= 256 NT).
-// ------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(kBlock, 2) void trial_k_kernel(
-    Topo tp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
-    const int *__restrict__ trj, const double2 *__restrict__ tw, int n_tasks, const RecipRow *__restrict__ rows, int n_rows,
-    double2 *__restrict__ A_base, const RecipItem *__restrict__ items, const double *__restrict__ cand_sites, int site_stride,
-    const RecipItem *__restrict__ pend_items, const double *__restrict__ pend_sites, int pend_stride,
-    const int *__restrict__ pend_idx, int n1_max, double *__restrict__ u_new, double *__restrict__ u_old) {
-    extern __shared__ double2 s_tab[];
-    __shared__ double s_red[2 * kWavesPerBlock];
-
-    const RecipItem it = items[blockIdx.x];
-    const int pi = pend_idx[blockIdx.x];
-    const bool has_pend = pi >= 0;
-    RecipItem pit = has_pend ? pend_items[pi] : RecipItem{it.replica, it.t, -1, 3 /*NONE*/, -1, 0};
-    int pend_last = -1;                                      // deletion: the slot that moves into pit.m
-    if (has_pend && pit.kind != 0) {
-        const int nm = nmol[pit.replica * tp.n_res + pit.t];  // live count BEFORE the previous move is applied
-        if (pit.kind == 1) { pit.m = nm; pit.aux = nm + 1; }  // appended (monte_carlo.f90:63, create_molecule.f90:64)
-        else { pit.aux = nm - 1; pend_last = nm - 1; }        // swap-with-last target
-    }
-    const int n1c = tp.n1[it.t], n1p = tp.n1[pit.t];
-    const int kofs[3] = {0, bx.kmax[0] + 1, bx.kmax[0] + bx.kmax[1] + 2};
-    const int ktot = bx.kmax[0] + bx.kmax[1] + bx.kmax[2] + 3;
-    // LDS: phase tables of the four site sets [set][site][ktot] | XY [row][2 n1] | charges (cur, prev) | sites | rows
-    double2 *s_xy = s_tab + 4 * n1_max * ktot;
-    double *s_q = reinterpret_cast<double *>(s_xy + n_rows * 2 * n1_max);       // [2][n1_max]
-    double *s_site = s_q + 2 * n1_max;                       // [4 sets][n1_max][3]: cur new, cur old, pend new, pend old
-    RecipRow *s_rows = reinterpret_cast<RecipRow *>(s_site + 12 * n1_max);
-    double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
-    double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
-    double2 *A = A_base + (size_t)it.replica * bx.n_slots;
-    const bool c_new = (it.kind == 0 || it.kind == 1), c_old = (it.kind == 0 || it.kind == 2);
-    const bool p_new = has_pend && (pit.kind == 0 || pit.kind == 1), p_old = has_pend && (pit.kind == 0 || pit.kind == 2);
-    // where the candidate's "old" sites come from once the previous move is applied
-    int old_src = 0, old_slot = it.m;                        // 0: resident slot old_slot, 1: the previous move's new sites
-    if (has_pend && c_old && pit.t == it.t && it.m == pit.m) {
-        if (pit.kind == 2) old_slot = pend_last; else old_src = 1;
-    }
-
-    // A(k), weights and task words of this thread's tasks: requested first, used last (nothing below depends on them)
-    int rj[NT];
-    double2 Ap[NT], Am[NT], w[NT];
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-        const int t = threadIdx.x + c * kBlock;
-        const bool in = t < n_tasks;
-        rj[c] = in ? trj[t] : 0;
-        Ap[c] = in ? A[2 * t] : make_double2(0.0, 0.0);
-        Am[c] = in ? A[2 * t + 1] : make_double2(0.0, 0.0);
-        w[c] = in ? tw[t] : make_double2(0.0, 0.0);
-    }
-
-    for (int r = threadIdx.x; r < n_rows; r += kBlock) s_rows[r] = rows[r];
-    // ---- every site coordinate this workgroup needs, read before anything is written
-    for (int e = threadIdx.x; e < 4 * n1_max; e += kBlock) {
-        const int set = e / n1_max, a = e - set * n1_max;
-        double x = 0.0, y = 0.0, z = 0.0;
-        if (set == 0 && c_new && a < n1c) {
-            const double *c = cand_sites + ((size_t)it.src * site_stride + a) * 3;
-            x = c[0]; y = c[1]; z = c[2];
-        } else if (set == 1 && c_old && a < n1c) {
-            if (old_src == 1) {
-                const double *c = pend_sites + ((size_t)pit.src * pend_stride + a) * 3;
-                x = c[0]; y = c[1]; z = c[2];
-            } else {
-                const int j = atom_slot(tp, it.t, old_slot, a);
-                x = px[j]; y = py[j]; z = pz[j];
-            }
-        } else if (set == 2 && p_new && a < n1p) {
-            const double *c = pend_sites + ((size_t)pit.src * pend_stride + a) * 3;
-            x = c[0]; y = c[1]; z = c[2];
-        } else if (set == 3 && p_old && a < n1p) {
-            const int j = atom_slot(tp, pit.t, pit.m, a);
-            x = px[j]; y = py[j]; z = pz[j];
-        }
-        s_site[e * 3 + 0] = x; s_site[e * 3 + 1] = y; s_site[e * 3 + 2] = z;
-    }
-    for (int a = threadIdx.x; a < 2 * n1_max; a += kBlock) {
-        const int which = a / n1_max, aa = a - which * n1_max;
-        const int t = which == 0 ? it.t : pit.t;
-        s_q[a] = aa < tp.n1[t] ? res_q[t * tp.max_atom + aa] : 0.0;
-    }
-    __syncthreads();
-
-    // coordinates / count of the previous move, exactly as the stand-alone commit (all reads of old coordinates are
-    // behind the barrier)
-    if (has_pend) {
-        if (pit.kind == 0 || pit.kind == 1) {
-            if (threadIdx.x < n1p) {
-                const double *c = s_site + (2 * n1_max + threadIdx.x) * 3;
-                const int j = atom_slot(tp, pit.t, pit.m, threadIdx.x);
-                px[j] = c[0]; py[j] = c[1]; pz[j] = c[2];
-            }
-        } else if (pit.kind == 2) {
-            if (threadIdx.x < n1p && pend_last != pit.m) {     // swap-with-last, delete_molecule.f90:107-114
-                const int j = atom_slot(tp, pit.t, pit.m, threadIdx.x), jl = atom_slot(tp, pit.t, pend_last, threadIdx.x);
-                px[j] = px[jl]; py[j] = py[jl]; pz[j] = pz[jl];
-            }
-        }
-        if (threadIdx.x == 0 && (pit.kind == 1 || pit.kind == 2)) nmol[pit.replica * tp.n_res + pit.t] = pit.aux;
-    }
-
-    // phase 1, all four sets at once: entry (set, a, axis, k >= 0) at s_tab[(set * n1_max + a) * ktot + kofs[axis] + k]
-    for (int e = threadIdx.x; e < 4 * n1_max * ktot; e += kBlock) {
-        const int sa = e / ktot, kk = e - sa * ktot;
-        const int set = sa / n1_max, a = sa - set * n1_max;
-        const int axis = (kk >= kofs[2]) ? 2 : (kk >= kofs[1] ? 1 : 0);
-        const bool used = (set == 0 ? c_new : set == 1 ? c_old : set == 2 ? p_new : p_old) && a < (set < 2 ? n1c : n1p);
-        if (!used) { s_tab[e] = make_double2(0.0, 0.0); continue; }
-        const double *c = s_site + sa * 3;
-        s_tab[e] = phase_entry(atom_phase(bx, axis, c[0], c[1], c[2]), kk - kofs[axis]);
-    }
-    __syncthreads();
-
-    // phase 2 for the (new, old) pair of sets starting at set0: XY[row][which * n1 + a]
-    auto build_xy = [&](int set0, int n1, bool use_new, bool use_old, const double *q) {
-        const int nss = 2 * n1;
-        for (int e = threadIdx.x; e < n_rows * nss; e += kBlock) {
-            const int row = e / nss, s = e - row * nss;
-            const int which = s >= n1 ? 1 : 0, a = s - which * n1;
-            double2 v = make_double2(0.0, 0.0);
-            if (which == 0 ? use_new : use_old) {
-                const RecipRow r = s_rows[row];
-                const double2 *tb = s_tab + ((set0 + which) * n1_max + a) * ktot;
-                const int aky = r.ky < 0 ? -r.ky : r.ky;
-                double2 Y = tb[kofs[1] + aky];
-                if (r.ky < 0) Y.y = -Y.y;
-                v = cmul(tb[r.kx], Y);
-                const double qa = which == 0 ? q[a] : -q[a];
-                v.x *= qa; v.y *= qa;
-            }
-            s_xy[e] = v;
-        }
-        __syncthreads();
-    };
-    // the four sums of one task over the site-states of a set pair, in the stand-alone kernels' order
-    auto task_sums = [&](int rjc, int set0, int n1, double &sac, double &sbd, double &sad, double &sbc) {
-        const double2 *xy = s_xy + ((rjc >> 8) & 0xfffff) * 2 * n1;
-        const double2 *z = s_tab + set0 * n1_max * ktot + kofs[2] + (rjc & 0xff);
-        sac = 0.0; sbd = 0.0; sad = 0.0; sbc = 0.0;
-        for (int which = 0; which < 2; ++which)
-            for (int a = 0; a < n1; ++a) {
-                const double2 p = xy[which * n1 + a], q = z[(which * n1_max + a) * ktot];
-                sac = fma(p.x, q.x, sac);
-                sbd = fma(p.y, q.y, sbd);
-                sad = fma(p.x, q.y, sad);
-                sbc = fma(p.y, q.x, sbc);
-            }
-    };
-
-    // delta of the previous accepted move, per task, in registers: (+j member, -j member)
-    double2 dp[NT], dm[NT];
-    if (has_pend) {
-        build_xy(2, n1p, p_new, p_old, s_q + n1_max);
-#pragma unroll
-        for (int c = 0; c < NT; ++c) {
-            double sac, sbd, sad, sbc;
-            task_sums(rj[c], 2, n1p, sac, sbd, sad, sbc);
-            dp[c] = make_double2(sac - sbd, sad + sbc);
-            dm[c] = make_double2(sac + sbd, sbc - sad);
-        }
-        __syncthreads();                  // XY is rebuilt for the new candidate
-    }
-    build_xy(0, n1c, c_new, c_old, s_q);
-
-    // ---- the one pass over A(k)
-    double acc = 0.0, acc0 = 0.0;
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-        const int t = threadIdx.x + c * kBlock;
-        if (has_pend) {
-            // A <- A + delta_prev, absent members stay zero (as recip_rows_kernel<true, false> stores them)
-            Ap[c] = (rj[c] & kTaskHasP) ? make_double2(Ap[c].x + dp[c].x, Ap[c].y + dp[c].y) : make_double2(0.0, 0.0);
-            Am[c] = (rj[c] & kTaskHasM) ? make_double2(Am[c].x + dm[c].x, Am[c].y + dm[c].y) : make_double2(0.0, 0.0);
-            if (t < n_tasks) { A[2 * t] = Ap[c]; A[2 * t + 1] = Am[c]; }
-        }
-        double sac, sbd, sad, sbc;
-        task_sums(rj[c], 0, n1c, sac, sbd, sad, sbc);
-        const double wp = w[c].x, wm = w[c].y;
-        acc0 += fma(wp, fma(Ap[c].x, Ap[c].x, Ap[c].y * Ap[c].y), wm * fma(Am[c].x, Am[c].x, Am[c].y * Am[c].y));
-        const double npx = Ap[c].x + (sac - sbd), npy = Ap[c].y + (sad + sbc);
-        const double nmx = Am[c].x + (sac + sbd), nmy = Am[c].y + (sbc - sad);
-        acc += fma(wp, fma(npx, npx, npy * npy), wm * fma(nmx, nmx, nmy * nmy));   // ewald_energy.f90:259-266
-    }
-    acc = wave_sum(acc);
-    acc0 = wave_sum(acc0);
-    if ((threadIdx.x & 63) == 0) { s_red[2 * (threadIdx.x >> 6)] = acc; s_red[2 * (threadIdx.x >> 6) + 1] = acc0; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double u = 0.0, u0 = 0.0;
-        for (int wv = 0; wv < kWavesPerBlock; ++wv) { u += s_red[2 * wv]; u0 += s_red[2 * wv + 1]; }
-        u_new[blockIdx.x] = u * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;   // ewald_energy.f90:272
-        u_old[blockIdx.x] = u0 * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;
-    }
+    if (COMMIT || DECIDE) recip_commit_tail(tp, pos, nmol, it, cand_row, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1951,12 +1755,8 @@ __global__ __launch_bounds__(kBlock) void sfactor_kernel(Topo tp, BoxDev bx, con
 // ComputeIntraResidueRealCoulombEnergySingleMol (ewald_energy.f90:371-411): one thread per item,
 // pairs visited in the reference's order.
 // ------------------------------------------------------------------------------------------
-__global__ void intra_kernel(Topo tp, BoxDev bx, const double *__restrict__ pos, const double *__restrict__ res_q,
-                             const PairItem *__restrict__ items, int n_items, const double *__restrict__ cand_sites,
-                             int site_stride, double *__restrict__ u_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_items) return;
-    const PairItem it = items[i];
+__device__ __forceinline__ double intra_energy(const Topo &tp, const BoxDev &bx, const double *__restrict__ pos, const double *__restrict__ res_q,
+                                               const PairItem &it, const double *__restrict__ cand_sites, int site_stride) {
     const int n1 = tp.n1[it.t];
     const double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
     const double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
@@ -1983,7 +1783,249 @@ __global__ void intra_kernel(Topo tp, BoxDev bx, const double *__restrict__ pos,
             if (r > kErrorTol) u = u + q1 * q2 * (erfc(bx.alpha * r) - 1.0) / r;
         }
     }
-    u_out[i] = u * kEps0InvEvA / kKbEvK;
+    return u * kEps0InvEvA / kKbEvK;
+}
+
+__global__ void intra_kernel(Topo tp, BoxDev bx, const double *__restrict__ pos, const double *__restrict__ res_q,
+                             const PairItem *__restrict__ items, int n_items, const double *__restrict__ cand_sites,
+                             int site_stride, double *__restrict__ u_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    u_out[i] = intra_energy(tp, bx, pos, res_q, items[i], cand_sites, site_stride);
+}
+
+// ------------------------------------------------------------------------------------------
+// Single-chain windows: ONE launch evaluates, decides and commits a window of trial steps of one chain.
+//
+// A single Markov chain is latency-bound: with one engine call per step the host pays an upload, two or three kernel
+// launches, a download, a stream synchronisation and a commit launch for ~10 us of arithmetic (profiles/r04/chain_latency.md).
+// mc_chain.f90 therefore hands over a WINDOW of up to kChainMaxCand consecutive steps drawn under the assumption that
+// every one of them is rejected (all of them are then trials from the same state) together with each step's acceptance
+// draw, and this kernel does everything the steps need in one launch:
+//   * workgroups [0, n)  ("k role"): the reciprocal-space sweep of candidate c (recip_rows_* pieces, old and new energy
+//     from one pass over A(k)); one spare thread computes the intra-molecular term of an insertion / deletion meanwhile;
+//   * the other workgroups ("pair role"): one wave per (candidate state, split) work unit of the pair sweep
+//     (pair_sweep_item / pair_flat_item, single-state items; the engine's nsplit);
+//   * every workgroup publishes its results to device memory, fences and takes a ticket; the workgroup that draws the
+//     LAST ticket sums the split partials in split order (exactly the host's order in trial_wait), forms each step's
+//     old / new totals as ComputeOldEnergy / ComputeNewEnergy and the move drivers form them
+//     (monte_carlo_utils.f90:275-395, create_molecule.f90:100-112, delete_molecule.f90:100-142), walks the window in
+//     order applying mc_acceptance_probability (monte_carlo_utils.f90:184-226) with the host's draws, writes energies +
+//     outcome straight into pinned host memory (the host polls a tag: no download, no stream synchronisation) and then
+//     commits the first accepted step itself (tables rebuilt, A <- A + delta, coordinates / count) while the host
+//     already resolves the window.
+// The rule on the device uses OCML's exp, the host (and the reference) glibc's: a step whose draw lies within
+// `margin` (relative) of its acceptance probability -- or whose probability is not a number -- is left UNDECIDED: the
+// device stops there, commits nothing from that step on, and the host decides it with its own exp.  Every decision the
+// device does take is therefore the host's decision, bit for bit.
+// kind 2 with link >= 0: the reference's deletion exactly as written (monte_carlo_utils.f90:301-309): the new
+// reciprocal energy is the creation-kind energy of row `link` (the molecule RemoveMolecule swaps into the slot) and an
+// accepted step adds THAT molecule's terms to A(k) while the coordinates lose slot m; row `link` itself is energy-only
+// (link = -2).  Orthorhombic boxes, row-form k sweep, molecules of <= kMaxFusedSitesWide sites.
+// ------------------------------------------------------------------------------------------
+constexpr int kChainMaxCand = 16;
+constexpr int kChainBlock = kPairBlock;          // 512 threads: 8 pair waves; the k role uses the first kBlock of them
+struct ChainCand {                               // 168 B = 7 "sites" of three doubles: the pair bodies read the sites as rows of stride 7
+    int t, m, kind, link;                        // link: -1 none, >= 0 companion row of an as-written deletion, -2 energy-only row
+    double u, pref, self;                        // acceptance draw, prefactor (1; phi V / N; (N + 1) / (phi V)), ewald_self of the type
+    double pad;
+    double sites[kMaxFusedSitesWide][3];
+};
+static_assert(sizeof(ChainCand) == 168, "ChainCand is read as 7 sites of 24 bytes");
+struct ChainResult {                             // what the k role of candidate c leaves for the resolving workgroup
+    double u_old, u_new, intra, u, pref, self;
+    int t, m, kind, link;
+};
+struct ChainArgs {
+    const ChainCand *cand;                       // [n] in pinned host memory (read directly: no upload)
+    ChainResult *res;                            // [n] device scratch
+    double2 *partials;                           // [n_ent * nsplit] device scratch
+    int *ticket;                                 // device counter, 0 between launches
+    double *host_out;                            // pinned host: [n][10] energies | first | undecided (ints) ...
+    unsigned long long *host_tag;                // pinned host: window sequence number, written last
+    unsigned long long seq;
+    int n, n_ent, nsplit, replica;
+    double temperature, e_recip, margin;
+    unsigned char ent_c[2 * kChainMaxCand], ent_new[2 * kChainMaxCand];   // pair entries: candidate, 0 = resident (old) / 1 = candidate row (new)
+    signed char ent_old_of[kChainMaxCand], ent_new_of[kChainMaxCand];     // per candidate: its old / new pair entry, -1 none
+};
+
+template <bool FLAT, bool FASTW>
+__global__ __launch_bounds__(kChainBlock, 1) void chain_window_kernel(
+    Topo tp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
+    const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab, const char *__restrict__ coul_tab_g,
+    const int *__restrict__ trj, const double2 *__restrict__ tw, int n_tasks, const RecipRow *__restrict__ rows, int n_rows,
+    double2 *__restrict__ A_base, ChainArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];      // Coulomb table | phase tables | partials staging
+    __shared__ double2 s_pair[kMaxTypes * kMaxTypes];
+    __shared__ int4 s_grp[kMaxGrp];
+    __shared__ int4 s_plane[FLAT ? kPairWaves * kFlatMaxPlanes : 1];
+    __shared__ double s_red[2 * kWavesPerBlock];
+    __shared__ double s_ent[2 * 2 * kChainMaxCand];                    // reduced pair entries {lj, cc}
+    __shared__ ChainResult s_res[kChainMaxCand];
+    __shared__ int s_flag;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = g.n;
+    double2 *A = A_base + (size_t)g.replica * bx.n_slots;
+    const double *cand_sites = reinterpret_cast<const double *>(g.cand) + 6;       // site a of row c: cand_sites + (c * 7 + a) * 3
+
+    if ((int)blockIdx.x < n) {
+        // ---------------- k role: candidate c
+        const int c = blockIdx.x;
+        const ChainCand *cd = g.cand + c;
+        const int kind = cd->kind, link = cd->link;
+        RecipItem it{g.replica, cd->t, cd->m, kind, c, 0, 0};
+        const RecipLds v = recip_lds_view(tp, bx, it, n_rows, reinterpret_cast<double2 *>(s_dyn));
+        const bool active = tid < kBlock;
+        recip_rows_tables(tp, bx, pos, res_q, rows, n_rows, it, cd->sites[0], v, tid, active);
+        double acc = 0.0, acc0 = 0.0;
+        if (active) recip_rows_pass<false, true>(v, trj, tw, n_tasks, A, tid, acc, acc0);
+        if (tid == kBlock && link != -2 && (kind == 1 || kind == 2)) {
+            // ComputeIntraResidueRealCoulombEnergySingleMol of the inserted (candidate row) / deleted (resident) molecule
+            const PairItem pit{g.replica, cd->t, cd->m, kind == 1 ? c : -1, 0};
+            g.res[c].intra = intra_energy(tp, bx, pos, res_q, pit, cand_sites, 7);
+        }
+        if (active) {
+            acc = wave_sum(acc);
+            acc0 = wave_sum(acc0);
+            if (lane == 0) { s_red[2 * wave] = acc; s_red[2 * wave + 1] = acc0; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double u = 0.0, u0 = 0.0;
+            for (int wv = 0; wv < kWavesPerBlock; ++wv) { u += s_red[2 * wv]; u0 += s_red[2 * wv + 1]; }
+            ChainResult *r = g.res + c;
+            r->u_new = u * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;            // ewald_energy.f90:272
+            r->u_old = u0 * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;
+            r->u = cd->u; r->pref = cd->pref; r->self = cd->self;
+            r->t = cd->t; r->m = cd->m; r->kind = kind; r->link = link;
+        }
+    } else {
+        // ---------------- pair role: one wave per (entry, split)
+        for (int i = tid; i < (bx.coul_last_row + 1) * kCoulRowVec; i += kChainBlock)
+            reinterpret_cast<double2 *>(s_dyn)[i] = reinterpret_cast<const double2 *>(coul_tab_g)[i];
+        const int nt = tp.n_types;
+        for (int i = tid; i < nt * nt; i += kChainBlock) s_pair[i] = pair_tab[i];
+        if (FLAT && tid < kMaxGrp) s_grp[tid] = make_int4(tp.grp_start[tid], tp.grp_cnt[tid], tp.grp_ty[tid], 0);
+        __syncthreads();
+        const int w = ((int)blockIdx.x - n) * kPairWaves + wave;
+        if (w < g.n_ent * g.nsplit) {
+            const int ent = w / g.nsplit, split = w - ent * g.nsplit;
+            const int c = g.ent_c[ent];
+            const ChainCand *cd = g.cand + c;
+            const int t = __builtin_amdgcn_readfirstlane(cd->t), kind = __builtin_amdgcn_readfirstlane(cd->kind);
+            // old state: the resident molecule; new state: the candidate row; an insertion excludes nothing
+            const PairItem it{g.replica, t, kind == 1 ? -1 : __builtin_amdgcn_readfirstlane(cd->m), g.ent_new[ent] ? c : -1, 0};
+            const int n1 = tp.n1[t];
+#define MGPU_CHAIN_PAIR(NS)                                                                                              \
+            do {                                                                                                         \
+                if constexpr (FLAT)                                                                                      \
+                    pair_flat_item<NS, false, FASTW>(tp, bx, pos, nmol, res_q, res_atype, s_dyn, s_pair, s_grp,         \
+                                                     s_plane + wave * kFlatMaxPlanes, it, cand_sites, 7, split, g.nsplit, lane, 0, g.partials, w); \
+                else                                                                                                     \
+                    pair_sweep_item<NS, false, false, false, FASTW>(tp, bx, pos, nmol, res_q, res_atype, pair_tab, s_dyn, s_pair, nullptr, \
+                                                                    nullptr, it, cand_sites, 7, split, g.nsplit, lane, g.partials, w);   \
+            } while (0)
+            switch (n1) {
+                case 1: MGPU_CHAIN_PAIR(1); break;
+                case 2: MGPU_CHAIN_PAIR(2); break;
+                case 3: MGPU_CHAIN_PAIR(3); break;
+                case 4: MGPU_CHAIN_PAIR(4); break;
+                default: MGPU_CHAIN_PAIR(5); break;
+            }
+#undef MGPU_CHAIN_PAIR
+        }
+    }
+
+    // ---------------- ticket: the last workgroup to arrive resolves the window
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_flag = (atomicAdd(g.ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_flag) return;
+    __threadfence();
+    // split partials of every pair entry into LDS in one round trip, then one thread per (entry, component) adds them in
+    // split order -- the order trial_wait uses on the host
+    {
+        double *st = reinterpret_cast<double *>(s_dyn);
+        const int np = g.n_ent * g.nsplit;
+        for (int i = tid; i < np; i += kChainBlock) {
+            const double2 pv = g.partials[i];
+            st[2 * i] = pv.x; st[2 * i + 1] = pv.y;
+        }
+        if (tid < n) s_res[tid] = g.res[tid];
+        __syncthreads();
+        if (tid < 2 * g.n_ent) {
+            const int ent = tid >> 1, comp = tid & 1;
+            double a = 0.0;
+            for (int s2 = 0; s2 < g.nsplit; ++s2) a += st[2 * (ent * g.nsplit + s2) + comp];
+            s_ent[tid] = comp ? a * kEps0InvEvA / kKbEvK : a;                  // energy_utils.f90:440
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int first = -1, undecided = -1;
+        for (int c = 0; c < n; ++c) {
+            const ChainResult &r = s_res[c];
+            const ChainResult &cd = r;
+            double o[5] = {0.0, 0.0, r.u_old, 0.0, 0.0}, w[5] = {0.0, 0.0, r.u_new, 0.0, 0.0};
+            if (g.ent_old_of[c] >= 0) { o[0] = s_ent[2 * g.ent_old_of[c]]; o[1] = s_ent[2 * g.ent_old_of[c] + 1]; }
+            if (g.ent_new_of[c] >= 0) { w[0] = s_ent[2 * g.ent_new_of[c]]; w[1] = s_ent[2 * g.ent_new_of[c] + 1]; }
+            if (cd.link != -2) {
+                if (cd.kind == 1) { w[3] = cd.self; w[4] = r.intra; }
+                if (cd.kind == 2) { o[3] = cd.self; o[4] = r.intra; }
+            }
+            double *ho = g.host_out + 10 * (size_t)c;
+            for (int k = 0; k < 5; ++k) { ho[k] = o[k]; ho[5 + k] = w[k]; }
+            if (cd.link == -2 || first >= 0 || undecided >= 0) continue;
+            // totals as the move drivers form them (mc_chain.f90 resolve_step)
+            double e_old, e_new;
+            if (cd.kind == 0) {
+                e_old = (o[0] + o[1]) + o[2];
+                e_new = (w[0] + w[1]) + w[2];
+            } else if (cd.kind == 1) {
+                e_old = g.e_recip;
+                e_new = (((w[0] + w[1]) + w[2]) + w[3]) + w[4];
+            } else {
+                e_old = (((o[0] + o[1]) + g.e_recip) + o[3]) + o[4];
+                e_new = cd.link >= 0 ? s_res[cd.link].u_new : w[2];
+            }
+            const double x = cd.pref * exp(-(e_new - e_old) / g.temperature);
+            const double p = x < 1.0 ? x : 1.0;                        // min(1, x)
+            // too close to call with another exp (or not a number): the host decides this step
+            if (!(x == x) || (x < 1.0 + g.margin && fabs(cd.u - x) <= g.margin * x)) { undecided = c; continue; }
+            if (cd.u <= p) first = c;
+        }
+        int *hi = reinterpret_cast<int *>(g.host_out + 10 * (size_t)n);
+        hi[0] = first;
+        hi[1] = undecided;
+        __threadfence_system();
+        __hip_atomic_store(g.host_tag, g.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        *g.ticket = 0;
+        s_flag = first;
+    }
+    __syncthreads();
+    const int first = s_flag;
+    if (first < 0) return;
+    // ---------------- commit of the accepted step by this workgroup (the stand-alone commit's arithmetic)
+    {
+        const ChainResult *cd = s_res + first;
+        const bool as_written = cd->kind == 2 && cd->link >= 0;
+        const int src = as_written ? cd->link : first;
+        RecipItem it{g.replica, cd->t, cd->m, as_written ? 5 : cd->kind, src, 0, 0};
+        recip_commit_target(tp, nmol, it);
+        const RecipLds v = recip_lds_view(tp, bx, it, n_rows, reinterpret_cast<double2 *>(s_dyn));
+        const bool active = tid < kBlock;
+        recip_rows_tables(tp, bx, pos, res_q, rows, n_rows, it, g.cand[src].sites[0], v, tid, active);
+        double acc = 0.0, acc0 = 0.0;
+        if (active) {
+            recip_rows_pass<true, false>(v, trj, tw, n_tasks, A, tid, acc, acc0);
+            recip_commit_tail(tp, pos, nmol, it, g.cand[src].sites[0], tid);
+        }
+    }
 }
 
 // empty dispatch used by mgpu_profile_enable to switch a stream's queue into profiling mode ahead of time

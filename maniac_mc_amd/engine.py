@@ -311,9 +311,39 @@ class Engine:
         check(self.L.mgpu_gcmc_trial_wait(self.h, C.c_int(lane), _d(old), _d(new)))
         return old, new
 
+    def chain_window_capacity(self):
+        n = C.c_int(0)
+        check(self.L.mgpu_chain_window_capacity(self.h, C.byref(n)))
+        return n.value
+
+    def chain_window(self, replica, t, m, kind, sites, accept_u, accept_pref, temperature, recip_energy, link=None):
+        """mgpu_chain_window: one launch evaluates the window's steps (all trials of replica's current state), decides
+        them in order and commits the first accepted one.  Returns (old[n,5], new[n,5], first_accepted, undecided)."""
+        kind = np.ascontiguousarray(kind, dtype=np.int32)
+        n = kind.shape[0]
+        t = _ints(t, n); m = _ints(m, n)
+        link = _ints(-1 if link is None else link, n)
+        sites = np.ascontiguousarray(sites, dtype=np.float64)
+        assert sites.ndim == 3 and sites.shape[0] == n and sites.shape[2] == 3
+        u = np.ascontiguousarray(accept_u, dtype=np.float64); pref = np.ascontiguousarray(accept_pref, dtype=np.float64)
+        assert u.shape == (n,) and pref.shape == (n,)
+        old = np.zeros((n, 5)); new = np.zeros((n, 5))
+        first = C.c_int(-1); und = C.c_int(-1)
+        check(self.L.mgpu_chain_window(self.h, C.c_int(int(replica)), C.c_int(n), _i(t), _i(m), _i(kind), _i(link), _d(sites),
+                                       C.c_int(sites.shape[1]), _d(u), _d(pref), C.c_double(temperature), C.c_double(recip_energy),
+                                       _d(old), _d(new), C.byref(first), C.byref(und)))
+        return old, new, first.value, und.value
+
+    def chain_set_margin(self, rel):
+        check(self.L.mgpu_chain_set_margin(self.h, C.c_double(rel)))
+
+    def chain_stats(self):
+        w = C.c_longlong(0); u = C.c_longlong(0)
+        check(self.L.mgpu_chain_get_stats(self.h, C.byref(w), C.byref(u)))
+        return w.value, u.value
+
     def commit_lane(self, lane, replica, t, m, kind, accept, sites=None, sync=True):
-        """mgpu_commit_submit (+ synchronize unless sync=False); sites=None reuses the rows of the lane's last trial
-        (such a commit is deferred into the lane's next trial_submit; synchronize launches it at once)."""
+        """mgpu_commit_submit (+ synchronize unless sync=False); sites=None reuses the rows of the lane's last trial."""
         n, replica, t, m, sites = self._cand(replica, t, m, sites)
         kind = _ints(kind, n)
         accept = _ints(accept, n)

@@ -272,6 +272,26 @@ module maniac_gpu
             real(c_double), intent(out) :: old_energy(*), new_energy(*)
             integer(c_int) :: rc
         end function
+        ! one launch per window of trial steps of ONE chain: evaluate, decide in order, commit the first accepted step
+        function mgpu_chain_window_capacity(e, max_candidates) bind(C, name="mgpu_chain_window_capacity") result(rc)
+            import :: c_ptr, c_int
+            type(c_ptr), value :: e
+            integer(c_int), intent(out) :: max_candidates
+            integer(c_int) :: rc
+        end function
+        function mgpu_chain_window(e, replica, n, t, m, kind, link, sites, site_stride, accept_u, accept_pref, temperature, &
+                                   recip_energy, old_energy, new_energy, first_accepted, undecided) &
+                bind(C, name="mgpu_chain_window") result(rc)
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: e
+            integer(c_int), value :: replica, n, site_stride
+            integer(c_int), intent(in) :: t(*), m(*), kind(*), link(*)
+            real(c_double), intent(in) :: sites(*), accept_u(*), accept_pref(*)
+            real(c_double), value :: temperature, recip_energy
+            real(c_double), intent(out) :: old_energy(*), new_energy(*)
+            integer(c_int), intent(out) :: first_accepted, undecided
+            integer(c_int) :: rc
+        end function
         function mgpu_synchronize(e) bind(C, name="mgpu_synchronize") result(rc)
             import :: c_ptr, c_int
             type(c_ptr), value :: e

@@ -43,7 +43,7 @@ module mc_chain
               mchain_set_moves, mchain_set_reservoir_box, mchain_set_reservoir_residue, mchain_run, &
               mchain_get_energy, mchain_get_counters, mchain_get_counts, mchain_get_molecule, mchain_get_steps, &
               mchain_set_mode, mchain_set_as_written, mchain_set_log_header, mchain_write_log_header, &
-              mchain_set_speculation
+              mchain_set_speculation, mchain_set_chain_windows, mchain_get_loop_seconds, mchain_get_times
 
     real(real64), parameter :: PI = 3.14159265358979323846_real64, TWOPI = 2.0_real64 * PI
     real(real64), parameter :: zero = 0.0_real64, one = 1.0_real64, half = 0.5_real64, three = 3.0_real64
@@ -74,6 +74,18 @@ module mc_chain
     ! loop; the engine round trips per step drop by up to 1 / acceptance.  spec_k = 1: the sequential loop.
     integer, save :: spec_k = 1
     integer, parameter :: STEP_NOOP = -1, STEP_ABORT = -2
+    ! One launch per window (mgpu_chain_window): the engine evaluates the window's steps, applies the acceptance rule to
+    ! them in order with the draws saved here and commits the first accepted step itself; a step whose draw is too close
+    ! to its probability for two exp implementations to be sure to agree comes back UNDECIDED and is decided (and
+    ! committed) by this loop.  chain_windows: wanted (default); chain_cap: the engine's window capacity, 0 = the engine
+    ! cannot (triclinic box, large molecules) and the window goes through mgpu_gcmc_trial_submit / wait as before.
+    logical, save :: chain_windows = .true.
+    integer, save :: chain_cap = 0
+    integer, parameter :: BY_HOST = -1, DEVICE_REJECTED = 0, DEVICE_ACCEPTED = 1
+    ! time spent inside the Monte Carlo loop proper (no initial energy, no files), seconds
+    real(real64), save :: loop_seconds = 0.0_real64
+    ! ... in ComputeSystemEnergy before the loop, and in the output files (UpdateFiles, PrintStatus)
+    real(real64), save :: init_seconds = 0.0_real64, file_seconds = 0.0_real64
 
     type :: proposal
         integer :: t = 0, m = 0, kind = STEP_NOOP, mtype = 0
@@ -84,7 +96,8 @@ module mc_chain
         integer, allocatable :: rng(:)                  ! generator state after the step's draws
     end type proposal
     ! the window's candidate list as handed to the engine (kept for the resident-row commit)
-    integer(c_int), allocatable, save :: w_rep(:), w_t(:), w_m(:), w_kind(:), w_acc(:)
+    integer(c_int), allocatable, save :: w_rep(:), w_t(:), w_m(:), w_kind(:), w_acc(:), w_link(:)
+    real(c_double), allocatable, save :: w_u(:), w_pref(:)
     integer, save :: w_stride = 1
 
 contains
@@ -429,6 +442,23 @@ contains
         spec_k = max(1, min(int(k), 64))
     end subroutine mchain_set_speculation
 
+    ! on /= 0 (default): windows go to the engine's one-launch path where it applies
+    subroutine mchain_set_chain_windows(on) bind(C, name="mchain_set_chain_windows")
+        integer(c_int), value :: on
+        chain_windows = on /= 0
+    end subroutine mchain_set_chain_windows
+
+    function mchain_get_loop_seconds() bind(C, name="mchain_get_loop_seconds") result(sec)
+        real(c_double) :: sec
+        sec = loop_seconds
+    end function mchain_get_loop_seconds
+
+    ! seconds of the last mchain_run: initial energy, Monte Carlo steps, output files
+    subroutine mchain_get_times(t) bind(C, name="mchain_get_times")
+        real(c_double), intent(out) :: t(3)
+        t = [init_seconds, loop_seconds, file_seconds]
+    end subroutine mchain_get_times
+
     subroutine mchain_set_as_written(on) bind(C, name="mchain_set_as_written")
         integer(c_int), value :: on
         as_written = on /= 0
@@ -505,6 +535,25 @@ contains
             p = min(one, exp(-delta_e / temp))
         end select
     end function acceptance_probability
+
+    ! The factor in front of exp(-delta_e / T) in mc_acceptance_probability, formed exactly as acceptance_probability forms
+    ! it; n_after = the type's molecule count as the move drivers have it when they call the rule (after the insertion /
+    ! after the removal)
+    function acceptance_prefactor(t, move_type, n_after) result(f)
+        integer, intent(in) :: t, move_type, n_after
+        real(real64) :: f, n, v, phi
+        n = real(n_after)
+        v = S%box%volume
+        phi = S%res(t)%fugacity
+        select case (move_type)
+        case (TYPE_CREATION)
+            f = (phi * v / n)
+        case (TYPE_DELETION)
+            f = ((n + one) / (phi * v))
+        case default
+            f = one
+        end select
+    end function acceptance_prefactor
 
     ! AcceptMove: running energies, then the engine applies the move
     subroutine accept_move(t, m, old, new, which)
@@ -796,10 +845,13 @@ contains
     ! Walk one evaluated step: o / w = the engine's old / new rows of its candidate (w2: the second row of an as-written
     ! deletion).  Mirrors the part of Translation / Rotation / CreateMolecule / DeleteMolecule that follows the energy
     ! evaluation; `restore` = the generator must be put back to this step's state before anything else is drawn.
-    subroutine resolve_step(p, o, w, w2, n_cand, restore, accepted)
+    ! verdict: BY_HOST -- the rule is applied here and an accepted step is committed through the engine (from the lane's
+    ! resident rows, or with explicit sites after a one-launch window); DEVICE_REJECTED / DEVICE_ACCEPTED -- the engine has
+    ! applied the rule (and the commit) already: only the chain's own bookkeeping follows.
+    subroutine resolve_step(p, o, w, w2, n_cand, restore, accepted, verdict)
         type(proposal), intent(in) :: p
         real(real64), intent(in) :: o(5), w(5), w2(5)
-        integer, intent(in) :: n_cand
+        integer, intent(in) :: n_cand, verdict
         logical, intent(in) :: restore
         logical, intent(out) :: accepted
         real(real64) :: old(6), new(6), prob, trial(3)
@@ -822,8 +874,7 @@ contains
             new(1:3) = w(1:3)
             old(IE_TOTAL) = old(IE_NONC) + old(IE_COUL) + old(IE_RECIP)
             new(IE_TOTAL) = new(IE_NONC) + new(IE_COUL) + new(IE_RECIP)
-            prob = acceptance_probability(old, new, t, p%mtype)
-            if (p%u <= prob) then
+            if (decide(old, new, t, p%mtype, p%u, verdict)) then
                 accepted = .true.
                 if (restore) call random_seed(put=p%rng)
                 if (p%mtype == TYPE_TRANSLATION) then
@@ -840,7 +891,7 @@ contains
                 else
                     S%counter(C_R) = S%counter(C_R) + 1
                 end if
-                call window_commit(p, n_cand)
+                if (verdict == BY_HOST) call window_commit(p, n_cand)
             end if
         case (TYPE_CREATION)
             S%counter(C_TRIAL_C) = S%counter(C_TRIAL_C) + 1
@@ -850,8 +901,7 @@ contains
             new(IE_TOTAL) = new(IE_NONC) + new(IE_COUL) + new(IE_RECIP) + new(IE_SELF) + new(IE_INTRA)
             S%res(t)%count = S%res(t)%count + 1
             S%box%num_atoms = S%box%num_atoms + n1
-            prob = acceptance_probability(old, new, t, TYPE_CREATION)
-            if (p%u <= prob) then
+            if (decide(old, new, t, TYPE_CREATION, p%u, verdict)) then
                 accepted = .true.
                 if (restore) call random_seed(put=p%rng)
                 S%res(t)%com(:, m) = p%com
@@ -863,7 +913,7 @@ contains
                 S%energy(IE_INTRA) = S%energy(IE_INTRA) + new(IE_INTRA) - old(IE_INTRA)
                 S%energy(IE_TOTAL) = S%energy(IE_TOTAL) + new(IE_TOTAL) - old(IE_TOTAL)
                 S%counter(C_C) = S%counter(C_C) + 1
-                call window_commit(p, n_cand)
+                if (verdict == BY_HOST) call window_commit(p, n_cand)
                 if (S%has_reservoir) then
                     last = S%rsv(t)%count
                     S%rsv(t)%com(:, p%pick) = S%rsv(t)%com(:, last)
@@ -886,8 +936,7 @@ contains
             last = S%res(t)%count
             S%res(t)%count = S%res(t)%count - 1
             S%box%num_atoms = S%box%num_atoms - n1
-            prob = acceptance_probability(old, new, t, TYPE_DELETION)
-            if (p%u <= prob) then
+            if (decide(old, new, t, TYPE_DELETION, p%u, verdict)) then
                 accepted = .true.
                 if (restore) call random_seed(put=p%rng)
                 off_last = S%res(t)%off(:, :, last)
@@ -900,7 +949,9 @@ contains
                 S%energy(IE_INTRA) = S%energy(IE_INTRA) + new(IE_INTRA) - old(IE_INTRA)
                 S%energy(IE_TOTAL) = S%energy(IE_TOTAL) + new(IE_TOTAL) - old(IE_TOTAL)
                 S%counter(C_D) = S%counter(C_D) + 1
-                if (as_written) then
+                if (verdict /= BY_HOST) then
+                    continue                                                   ! the engine has applied the removal
+                else if (as_written) then
                     allocate(sites_last(3, n1))
                     call MoleculeSites(S%res(t)%com(:, m), S%res(t)%off(:, 1:n1, m), n1, sites_last)
                     stat = mgpu_replica_replace_molecule(S%engine, 0_c_int, int(t - 1, c_int), int(m - 1, c_int), int(last - 1, c_int))
@@ -935,11 +986,36 @@ contains
         end select
     end subroutine resolve_step
 
-    ! apply candidate p%cand of the window's batch from the rows still resident on the lane
+    ! the step's outcome: the engine's where it has decided, else the rule applied here
+    function decide(old, new, t, move_type, u, verdict) result(yes)
+        real(real64), intent(in) :: old(6), new(6), u
+        integer, intent(in) :: t, move_type, verdict
+        logical :: yes
+        if (verdict == BY_HOST) then
+            yes = u <= acceptance_probability(old, new, t, move_type)
+        else
+            yes = verdict == DEVICE_ACCEPTED
+        end if
+    end function decide
+
+    ! apply candidate p%cand of the window's batch from the rows still resident on the lane -- or, after a one-launch
+    ! window (whose rows are not the lane's), from the proposal itself
     subroutine window_commit(p, n_cand)
         type(proposal), intent(in) :: p
         integer, intent(in) :: n_cand
-        integer(c_int) :: rc
+        integer(c_int) :: rc, rep(1), tt(1), mm(1), kk(1), acc(1)
+        real(real64), allocatable, target :: sites(:, :)
+        integer :: n1
+        if (chain_cap > 0) then
+            n1 = S%res(p%t)%n1
+            allocate(sites(3, n1))
+            call MoleculeSites(p%com, p%off, n1, sites)
+            rep = 0; tt = p%t - 1; mm = p%m - 1; kk = int(p%kind, c_int); acc = 1
+            if (p%kind == MGPU_CREATION) mm = -1
+            rc = mgpu_commit_submit(S%engine, 0_c_int, 1_c_int, rep, tt, mm, kk, c_loc(sites), int(n1, c_int), acc)
+            call note(int(rc))
+            return
+        end if
         w_acc(1:n_cand) = 0
         w_acc(p%cand) = 1
         rc = mgpu_commit_submit(S%engine, 0_c_int, int(n_cand, c_int), w_rep, w_t, w_m, w_kind, c_null_ptr, &
@@ -947,23 +1023,26 @@ contains
         call note(int(rc))
     end subroutine window_commit
 
-    ! Propose up to kwin steps, evaluate them in one batched call, walk them; returns the number of steps consumed.
+    ! Propose up to kwin steps, evaluate them in one engine call, walk them; returns the number of steps consumed.
+    ! With the engine's one-launch path (chain_cap > 0) the engine also applies the acceptance rule to the steps in order
+    ! and commits the first accepted one; the walk then only books what the engine decided.
     function run_window(kwin) result(done)
         integer, intent(in) :: kwin
         integer :: done
         type(proposal), allocatable :: P(:)
         real(real64), allocatable :: sites(:, :, :), o(:, :), w(:, :)
         real(real64) :: none5(5)
-        integer :: j, n_prop, n_cand, t, n1, c, last, mx
-        integer(c_int) :: rc
-        logical :: accepted
+        integer :: j, n_prop, n_cand, t, n1, c, last, mx, verdict
+        integer(c_int) :: rc, first, und
+        logical :: accepted, one_launch
+        one_launch = chain_cap > 0
         mx = 1
         do t = 1, S%n_res
             mx = max(mx, S%res(t)%n1)
         end do
         allocate(P(kwin))
         if (.not. allocated(w_rep)) then
-            allocate(w_rep(128), w_t(128), w_m(128), w_kind(128), w_acc(128))
+            allocate(w_rep(128), w_t(128), w_m(128), w_kind(128), w_acc(128), w_link(128), w_u(128), w_pref(128))
         end if
         allocate(sites(3, mx, 2 * kwin), o(5, 2 * kwin), w(5, 2 * kwin))
         sites = zero
@@ -971,6 +1050,8 @@ contains
         n_prop = 0
         n_cand = 0
         do j = 1, kwin
+            ! a step may need two rows (as-written deletion): never draw a step the engine's window cannot hold
+            if (one_launch .and. n_cand + 2 > chain_cap) exit
             call propose_step(P(j))
             n_prop = j
             if (P(j)%kind == STEP_ABORT) exit
@@ -984,22 +1065,43 @@ contains
             w_m(n_cand) = P(j)%m - 1
             if (P(j)%kind == MGPU_CREATION) w_m(n_cand) = -1
             w_kind(n_cand) = P(j)%kind
+            w_link(n_cand) = -1
+            w_u(n_cand) = P(j)%u
+            select case (P(j)%mtype)
+            case (TYPE_CREATION)
+                w_pref(n_cand) = acceptance_prefactor(t, TYPE_CREATION, S%res(t)%count + 1)
+            case (TYPE_DELETION)
+                w_pref(n_cand) = acceptance_prefactor(t, TYPE_DELETION, S%res(t)%count - 1)
+            case default
+                w_pref(n_cand) = one
+            end select
             call MoleculeSites(P(j)%com, P(j)%off, n1, sites(:, 1:n1, n_cand))
             if (P(j)%kind == MGPU_DELETION .and. as_written) then
                 ! F3: the reciprocal update runs with is_creation on the molecule RemoveMolecule moves into slot m
                 last = S%res(t)%count
                 n_cand = n_cand + 1
                 P(j)%cand2 = n_cand
+                w_link(n_cand - 1) = n_cand - 1                             ! 0-based row of the companion
                 w_rep(n_cand) = 0
                 w_t(n_cand) = t - 1
                 w_m(n_cand) = -1
                 w_kind(n_cand) = MGPU_CREATION
+                w_link(n_cand) = -2                                         ! energy only
+                w_u(n_cand) = zero
+                w_pref(n_cand) = zero
                 call MoleculeSites(S%res(t)%com(:, last), S%res(t)%off(:, 1:n1, last), n1, sites(:, 1:n1, n_cand))
             end if
         end do
+        first = -1
+        und = -1
         if (n_cand > 0) then
-            rc = mgpu_gcmc_trial_submit(S%engine, 0_c_int, int(n_cand, c_int), w_rep, w_t, w_m, w_kind, sites, int(mx, c_int))
-            if (rc == MGPU_OK) rc = mgpu_gcmc_trial_wait(S%engine, 0_c_int, o, w)
+            if (one_launch) then
+                rc = mgpu_chain_window(S%engine, 0_c_int, int(n_cand, c_int), w_t, w_m, w_kind, w_link, sites, int(mx, c_int), &
+                                       w_u, w_pref, S%temperature, S%energy(IE_RECIP), o, w, first, und)
+            else
+                rc = mgpu_gcmc_trial_submit(S%engine, 0_c_int, int(n_cand, c_int), w_rep, w_t, w_m, w_kind, sites, int(mx, c_int))
+                if (rc == MGPU_OK) rc = mgpu_gcmc_trial_wait(S%engine, 0_c_int, o, w)
+            end if
             call note(int(rc))
         end if
         none5 = zero
@@ -1016,12 +1118,24 @@ contains
             end if
             if (P(j)%kind == STEP_NOOP) cycle
             c = P(j)%cand
+            verdict = BY_HOST
+            if (one_launch) then
+                verdict = DEVICE_REJECTED
+                if (c - 1 == first) verdict = DEVICE_ACCEPTED
+                if (c - 1 == und) verdict = BY_HOST                         ! too close to call on the device: decided here
+            end if
             if (P(j)%cand2 > 0) then
-                call resolve_step(P(j), o(:, c), w(:, c), w(:, P(j)%cand2), n_cand, j < n_prop, accepted)
+                call resolve_step(P(j), o(:, c), w(:, c), w(:, P(j)%cand2), n_cand, j < n_prop, accepted, verdict)
             else
-                call resolve_step(P(j), o(:, c), w(:, c), none5, n_cand, j < n_prop, accepted)
+                call resolve_step(P(j), o(:, c), w(:, c), none5, n_cand, j < n_prop, accepted, verdict)
             end if
             if (accepted) then
+                done = j
+                exit
+            end if
+            if (one_launch .and. c - 1 == und) then
+                ! rejected here: the engine decided nothing behind this step, so the window ends with it
+                if (j < n_prop) call random_seed(put=P(j)%rng)
                 done = j
                 exit
             end if
@@ -1093,6 +1207,8 @@ contains
         character(kind=c_char), intent(in) :: outdir(*)
         integer(c_int) :: rc
         integer :: i, t, m, stat, step
+        integer(c_int) :: cap
+        integer(kind=8) :: c0, c1, crate
         real(real64) :: draw, e6(6)
 
         S%outdir = ''
@@ -1106,19 +1222,36 @@ contains
         open(unit=S%log_unit, file=trim(S%outdir) // 'log.maniac', status='replace')
         call write_log_header(S)
 
+        call system_clock(c0, crate)
         call ComputeSystemEnergy(S%engine, e6, stat=stat)
         call note(stat)
+        call system_clock(c1)
+        init_seconds = real(c1 - c0, real64) / real(crate, real64)
+        file_seconds = 0.0_real64
         S%energy = e6
         if (seed > 0) call seed_rng(int(seed))
 
+        ! the engine's one-launch window path, where it applies to this system (and the host wants it)
+        chain_cap = 0
+        if (fused .and. chain_windows) then
+            stat = mgpu_chain_window_capacity(S%engine, cap)
+            call note(stat)
+            if (stat == 0) chain_cap = int(cap)
+        end if
+        loop_seconds = 0.0_real64
+
         S%current_block = 0
         call log_start_mc(S)
+        call system_clock(c0, crate)
         call update_files(S, .false.)
+        call system_clock(c1)
+        file_seconds = file_seconds + real(c1 - c0, real64) / real(crate, real64)
         do while (S%current_block < nb_block .and. status == 0)
             S%current_block = S%current_block + 1
             step = 1
+            call system_clock(c0, crate)
             do while (step <= nb_step)
-                if (fused .and. spec_k > 1) then
+                if (fused .and. (spec_k > 1 .or. chain_cap > 0)) then
                     ! a window never crosses the end of a block (AdjustMoveStepSizes and the files come there)
                     step = step + run_window(min(spec_k, nb_step - step + 1))
                     if (status /= 0) exit
@@ -1142,9 +1275,14 @@ contains
                 if (status /= 0) exit
                 step = step + 1
             end do
+            call system_clock(c1)
+            loop_seconds = loop_seconds + real(c1 - c0, real64) / real(crate, real64)
             call adjust_move_step_sizes()
+            call system_clock(c0)
             call log_status(S)
             call update_files(S, .true.)
+            call system_clock(c1)
+            file_seconds = file_seconds + real(c1 - c0, real64) / real(crate, real64)
         end do
         call note(int(mgpu_synchronize(S%engine)))
         ! a Fortran do variable ends one past its limit: FinalReport prints nb_block + 1

@@ -388,7 +388,8 @@ contains
                 deallocate(F%lane(g)%rep, F%lane(g)%t, F%lane(g)%m, F%lane(g)%kind, F%lane(g)%accept, &
                            F%lane(g)%ia, F%lane(g)%move, F%lane(g)%cidx, F%lane(g)%sel_ia, F%lane(g)%sel_mv, &
                            F%lane(g)%sel_slot, F%lane(g)%new_com, &
-                           F%lane(g)%new_off, F%lane(g)%old_e, F%lane(g)%new_e, F%lane(g)%u, F%lane(g)%mvc, F%lane(g)%u5)
+                           F%lane(g)%new_off, F%lane(g)%old_e, F%lane(g)%new_e, F%lane(g)%u, F%lane(g)%mvc, F%lane(g)%u5, &
+                           F%lane(g)%acc_u, F%lane(g)%acc_pref)
                 if (allocated(F%lane(g)%sites_own)) deallocate(F%lane(g)%sites_own)
                 nullify(F%lane(g)%sites)
             end if

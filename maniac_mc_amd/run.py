@@ -67,7 +67,8 @@ def header_text(inp, dat, maniac_path, data_path, inc_path, eng_or_ewald, reserv
 
 
 def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoir_path=None, device=0,
-                   mol_capacity=None, nb_block=None, nb_step=None, seams=False, as_written=False, speculate=8):
+                   mol_capacity=None, nb_block=None, nb_step=None, seams=False, as_written=False, speculate=8,
+                   chain_windows=True):
     """Run the chain; returns a dict with the final energies (K), counters, molecule counts, step sizes.
 
     ``seed``: None -> the input file's ``seed`` if present, else the generator is left unseeded
@@ -82,6 +83,10 @@ def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoi
     order assuming every one is rejected and evaluated in ONE engine call; the first accepted one is applied, the
     generator is put back to its state after that step and the rest is redrawn.  Same states, same files, up to
     1 / acceptance fewer round trips.  1 -> one step per engine call.
+    ``chain_windows``: True (default; batched mode only) -> a window is ONE kernel launch (mgpu_chain_window): the engine
+    evaluates its steps, applies the acceptance rule to them in order with the loop's own draws and commits the first
+    accepted one, leaving to the loop only the steps too close to call; where the engine cannot (triclinic box, molecules
+    of more than five sites) the loop falls back to the batched calls by itself.  False -> the batched calls always.
     """
     system, inp, dat = io_maniac.load_system(maniac_path, data_path, inc_path, with_data=True)
     rdat = io_maniac.read_lammps_data(reservoir_path, inp) if reservoir_path else None
@@ -121,6 +126,8 @@ def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoi
         H.mchain_set_mode(C.c_int(1 if seams else 0))
         H.mchain_set_as_written(C.c_int(1 if as_written else 0))
         H.mchain_set_speculation(C.c_int(1 if seams else max(1, int(speculate))))
+        H.mchain_set_chain_windows(C.c_int(1 if chain_windows else 0))
+        H.mchain_get_loop_seconds.restype = C.c_double
         header = header_text(inp, dat, maniac_path, data_path, inc_path, eng, reservoir_path, rdat)
         H.mchain_set_log_header(header, C.c_int(len(header)))
         H.mchain_set_moves(C.c_double(inp.translation_step), C.c_double(inp.rotation_step_angle),
@@ -152,12 +159,18 @@ def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoi
         H.mchain_get_counters(cnt.ctypes.data_as(_ip))
         H.mchain_get_counts(nm.ctypes.data_as(_ip))
         H.mchain_get_steps(st.ctypes.data_as(_dp))
+        mc_seconds = float(H.mchain_get_loop_seconds())
+        times = np.zeros(3)
+        H.mchain_get_times(times.ctypes.data_as(_dp))
+        chain_stats = eng.chain_stats()
         e_final = eng.system_energy(0)
     finally:
         eng.close()
     keys = ("non_coulomb", "coulomb", "recip_coulomb", "ewald_self", "intra_coulomb", "total")
+    # loop_seconds: mchain_run as a whole (initial energy, Monte Carlo loop, every output file); mc_seconds: the Monte
+    # Carlo steps alone; chain_windows: (one-launch windows, windows with a step left to the host's exp)
     return dict(energy=dict(zip(keys, e)), recomputed_energy=e_final, counters=cnt, n_mol=nm, loop_seconds=t_loop,
-                translation_step=st[0], rotation_step=st[1])
+                mc_seconds=mc_seconds, init_seconds=float(times[0]), file_seconds=float(times[2]), chain_windows=chain_stats, translation_step=st[0], rotation_step=st[1])
 
 
 def main(argv=None):
@@ -176,6 +189,8 @@ def main(argv=None):
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--speculate", type=int, default=8,
                     help="speculative window: steps evaluated per engine call (same states and files; 1: one step per call)")
+    ap.add_argument("--no-chain-windows", action="store_true",
+                    help="evaluate windows through the batched submit / wait calls instead of the one-launch path")
     ap.add_argument("--as-written", action="store_true",
                     help="the reference's deletion update exactly as written (SURVEY F3) instead of the intended physics")
     a = ap.parse_args(argv)
@@ -184,7 +199,7 @@ def main(argv=None):
             print(f"{what} file not found: {path}", file=sys.stderr)
             return 1
     res = run_simulation(a.maniac, a.data, a.inc, a.out, seed=a.seed, reservoir_path=a.reservoir, device=a.device,
-                         as_written=a.as_written, speculate=a.speculate)
+                         as_written=a.as_written, speculate=a.speculate, chain_windows=not a.no_chain_windows)
     e = res["energy"]
     print(f"final energy (K): total {e['total']:.6f}  non_coulomb {e['non_coulomb']:.6f}  coulomb {e['coulomb']:.6f}  "
           f"recip {e['recip_coulomb']:.6f};  molecules {res['n_mol'].tolist()};  output in {os.path.join(a.out, '')}")

@@ -214,13 +214,10 @@ def test_gcmc_farm_framework_water_at_stated_size(device_build):
     farm.close()
 
 
-@pytest.mark.parametrize("env", [{"MFARM_LANE_THREADS": "1"}, {"MFARM_LANE_THREADS": "2"}, {"MGPU_DEFER_COMMIT": "1"},
-                                 {"MFARM_LANE_THREADS": "1", "MGPU_DEFER_COMMIT": "1"}],
-                         ids=["lane_threads", "two_drivers", "deferred_commit", "both"])
+@pytest.mark.parametrize("env", [{"MFARM_LANE_THREADS": "1"}, {"MFARM_LANE_THREADS": "2"}], ids=["lane_threads", "two_drivers"])
 def test_farm_options_keep_the_invariants(env):
     """The opt-in modes -- one host thread per lane (MFARM_LANE_THREADS=1), two driver threads sharing the lanes
-    (MFARM_LANE_THREADS=2) and commits folded into the next trial's k
-    sweep (MGPU_DEFER_COMMIT=1) -- are selected by environment variables read when the libraries start: re-run the
+    (MFARM_LANE_THREADS=2) -- are selected by environment variables read when the libraries start: re-run the
     NVT / GCMC consistency tests (running energies, A(k), host mirrors vs a from-scratch evaluation) in a child
     process with them set."""
     import os

@@ -82,100 +82,6 @@ def test_mixed_gcmc_batch_matches_oracle(refcpu_mod):
     eng.close()
 
 
-def _random_lane_run(eng, s, rng_seed, steps, lane):
-    """A scripted grand-canonical lane run: every step one candidate per replica (moves, insertions, deletions --
-    deliberately hitting the same molecule twice in a row, the slot a deletion has just refilled and the molecule an
-    insertion has just created), random acceptance, commit from the lane's resident rows WITHOUT synchronising."""
-    rng = np.random.default_rng(rng_seed)
-    R = eng.n_replicas
-    n = np.full(R, int(s.n_mol[0]))
-    tmpl = s.offsets[0][0]
-    L = float(s.box_matrix[0, 0])
-    log = []
-    last = [None] * R                       # (kind, slot) of the last ACCEPTED move per replica
-    for step in range(steps):
-        reps = [r for r in range(R) if not (step % 7 == 3 and r == 1)]      # replica 1 sits out sometimes: orphaned commits
-        kinds, ms, sites = [], [], []
-        for r in reps:
-            u = rng.random()
-            k = MGPU_MOVE if (u < 0.4 or n[r] < 3) else (MGPU_CREATION if u < 0.7 else MGPU_DELETION)
-            if k == MGPU_CREATION and n[r] >= eng.mol_capacity[0] - 1:
-                k = MGPU_MOVE
-            m = int(rng.integers(0, n[r]))
-            if last[r] is not None and rng.random() < 0.5:
-                lk, lm = last[r]
-                if lk in (MGPU_MOVE, MGPU_DELETION) and lm < n[r]:
-                    m = lm                                  # the molecule just moved / the slot just refilled
-                elif lk == MGPU_CREATION:
-                    m = n[r] - 1                            # the molecule just created
-            if k == MGPU_CREATION:
-                m = -1
-            kinds.append(k); ms.append(m)
-            sites.append((s.bounds_lo + rng.random(3) * L)[None, :] + tmpl @ np.linalg.qr(rng.normal(size=(3, 3)))[0].T)
-        rep = np.array(reps, dtype=np.int32); kinds = np.array(kinds, dtype=np.int32); ms = np.array(ms, dtype=np.int32)
-        sites = np.array(sites)
-        # moves displace the resident molecule a little instead of teleporting it
-        for c, r in enumerate(reps):
-            if kinds[c] == MGPU_MOVE:
-                sites[c] = eng_sites_cache[id(eng)][r][ms[c]] + rng.uniform(-0.3, 0.3, 3)[None, :]
-        old, new = eng.gcmc_trial(rep, np.zeros(len(reps), np.int32), ms, kinds, sites, lane=lane)
-        acc = (rng.random(len(reps)) < 0.6).astype(np.int32)
-        eng.commit_lane(lane, rep, np.zeros(len(reps), np.int32), ms, kinds, acc, sync=False)
-        for c, r in enumerate(reps):
-            if not acc[c]:
-                continue
-            cache = eng_sites_cache[id(eng)][r]
-            if kinds[c] == MGPU_MOVE:
-                cache[ms[c]] = sites[c]; last[r] = (MGPU_MOVE, int(ms[c]))
-            elif kinds[c] == MGPU_CREATION:
-                cache.append(sites[c].copy()); n[r] += 1; last[r] = (MGPU_CREATION, n[r] - 1)
-            else:
-                cache[ms[c]] = cache[-1]; cache.pop(); n[r] -= 1; last[r] = (MGPU_DELETION, int(ms[c]))
-        log.append((old.copy(), new.copy()))
-    return log, n
-
-
-eng_sites_cache = {}
-
-
-def test_deferred_commit_is_bitwise_the_immediate_commit():
-    """With MGPU_DEFER_COMMIT=1 a resident-row commit is not launched: the lane's next trial applies it inside its k
-    sweep (trial_k_kernel).  The same scripted lane run on an engine that defers and on a default one (immediate
-    commit launches) must give bitwise equal energies at every step and bitwise equal A(k), coordinates and counts
-    at the end."""
-    import os
-    s = synth.co2_box(14, seed=31)
-    R = 5
-    out = []
-    for defer in (True, False):
-        if defer:
-            os.environ["MGPU_DEFER_COMMIT"] = "1"
-        try:
-            eng = Engine.from_system(s, n_replicas=R, mol_capacity=[40])
-        finally:
-            os.environ.pop("MGPU_DEFER_COMMIT", None)
-        for r in range(R):
-            eng.init_structure_factor(r, True)
-        eng_sites_cache[id(eng)] = [[x.copy() for x in s.all_sites(0)] for _ in range(R)]
-        log, n = _random_lane_run(eng, s, 123, 60, lane=2)
-        state = dict(n=n, A=[eng.structure_factor(r) for r in range(R)], pos=[eng.get_molecules(r, 0) for r in range(R)],
-                     cache=eng_sites_cache.pop(id(eng)))
-        for r in range(R):
-            assert eng.num_molecules(r, 0) == n[r]
-            assert np.array_equal(state["pos"][r], np.array(state["cache"][r]))      # device == the scripted bookkeeping
-            fresh = eng.structure_factor(r)
-            eng.init_structure_factor(r, True)
-            assert np.max(np.abs(fresh - eng.structure_factor(r))) < 1e-9            # A(k) == S(k) of the final state
-        out.append((log, state))
-        eng.close()
-    (log_a, st_a), (log_b, st_b) = out
-    assert np.array_equal(st_a["n"], st_b["n"])
-    for (oa, na), (ob, nb) in zip(log_a, log_b):
-        assert np.array_equal(oa, ob) and np.array_equal(na, nb)
-    for r in range(R):
-        assert np.array_equal(st_a["A"][r], st_b["A"][r]) and np.array_equal(st_a["pos"][r], st_b["pos"][r])
-
-
 def test_device_built_trials_match_host_built_rows():
     """mgpu_move_trial_submit builds the trial geometry on the device from the resident molecule frames and the host's
     uniform numbers (Translation / Rotation / CreateMolecule of the reference).  Here the same moves are constructed in
@@ -252,6 +158,68 @@ def test_device_built_trials_match_host_built_rows():
     # bare-site commits would leave the frames behind: refused while the replica holds frames
     with pytest.raises(Exception):
         eng.commit_candidates([0], [0], [1], [MGPU_MOVE], rows[:1], [1])
+    eng.close()
+
+
+def test_device_built_coordinates_are_the_references_moves(refcpu_mod):
+    """The COORDINATES trial_build_kernel writes (the bench's default move construction), read back after a commit, against
+    the oracle's ApplyPBC and RotationMatrix -- both pinned bit for bit to the reference (tests/test_oracle_pin.py) --
+    composed as Translation / Rotation / CreateMolecule compose them (src/translation.f90:93-112,
+    src/monte_carlo_utils.f90:30-66, src/helper_utils.f90:39-77, src/create_molecule.f90:166-207): translations that leave
+    the cell on either side, rotations about each Cartesian axis, insertions rotated about each axis.  <= 1e-12 A (the
+    rotated offsets may differ in the last bit: device sincos against libm's)."""
+    s = synth.co2_box(30, seed=3)
+    P = refcpu_mod.RefCPU(s, mol_capacity=48)
+    L = np.diag(s.box_matrix)
+    lo = s.bounds_lo
+    moves = [1] * 6 + [2] * 6 + [3] * 6
+    n = len(moves)
+    eng = Engine(s.topo, s.box_matrix, s.bounds_lo, s.real_space_cutoff, s.ewald_tolerance, n, 0, [48])
+    eng.set_frames(0, 0, s.com[0], s.offsets[0])
+    eng.init_structure_factor(0, True)
+    for r in range(1, n):
+        eng.replica_copy(r, 0)
+    rng = np.random.default_rng(41)
+    u = rng.random((n, 5))
+    u[6:12, 4] = u[12:18, 4] = [0.05, 0.3, 0.4, 0.6, 0.7, 0.99]          # axes 1, 1, 2, 2, 3, 3
+    # translations: molecules nearest to the cell faces, pushed outwards by a step larger than their distance to the face
+    t_step, r_step = 6.0, 0.6
+    d_lo = np.min(s.com[0] - lo, axis=1)
+    d_hi = np.min(lo + L - s.com[0], axis=1)
+    near = np.concatenate([np.argsort(d_lo)[:3], np.argsort(d_hi)[:3]])
+    m = rng.integers(0, 30, n).astype(np.int32)
+    m[:6] = near
+    for c in range(3):
+        u[c, :3] = 0.02              # towards -x, -y, -z by 2.9 A
+        u[3 + c, :3] = 0.98
+    rep = np.arange(n, dtype=np.int32)
+    t = np.zeros(n, np.int32)
+    move = np.array(moves, dtype=np.int32)
+    kinds = np.where(move <= 2, MGPU_MOVE, MGPU_CREATION).astype(np.int32)
+    eng.move_trial(rep, t, m, move, u, t_step, r_step, lane=0)
+    eng.commit_lane(0, rep, t, m, kinds, np.ones(n, np.int32))
+    crossed = 0
+    for c in range(n):
+        com0, off0 = s.com[0][m[c]].copy(), s.offsets[0][m[c]].copy()
+        slot = int(m[c])
+        if move[c] == 1:
+            raw = com0 + (u[c, :3] - 0.5) * t_step
+            crossed += int(np.any((raw < lo) | (raw >= lo + L)))
+            com_e, off_e = P.apply_pbc(raw), off0
+        elif move[c] == 2:
+            com_e = com0
+            off_e = off0 @ P.rotation_matrix(int(u[c, 4] * 3.0) + 1, (u[c, 3] - 0.5) * r_step).T
+        else:
+            slot = 30
+            com_e = lo + L * u[c, :3]
+            off_e = s.offsets[0][0] @ P.rotation_matrix(int(u[c, 4] * 3.0) + 1, u[c, 3] * 2 * np.pi).T
+        com_d, off_d = eng.get_frames(c, 0)
+        assert np.max(np.abs(com_d[slot] - com_e)) <= 1e-12, (c, move[c], com_d[slot], com_e)
+        assert np.max(np.abs(off_d[slot] - off_e)) <= 1e-12, (c, move[c])
+        assert np.array_equal(eng.get_molecules(c, 0)[slot], com_d[slot][None, :] + off_d[slot])       # sites = com + off, formed once
+        if move[c] != 3:
+            assert np.array_equal(com_d[np.arange(30) != slot], s.com[0][np.arange(30) != slot])
+    assert crossed >= 4                       # the wrap of ApplyPBC was really exercised
     eng.close()
 
 

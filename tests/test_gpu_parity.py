@@ -115,6 +115,10 @@ def test_engine_vs_golden(name):
                                         (lambda: synth.rigid_adsorbate_box(), 2)])
 def test_batched_candidates_vs_refcpu(maker, nrep, refcpu_mod):
     """Many candidates per launch, on replicas holding DIFFERENT configurations."""
+    _batched_vs_refcpu(maker, nrep, refcpu_mod)
+
+
+def _batched_vs_refcpu(maker, nrep, refcpu_mod, engine_replicas=None):
     rng = np.random.default_rng(7)
     base = maker()
     systems = []
@@ -124,7 +128,7 @@ def test_batched_candidates_vs_refcpu(maker, nrep, refcpu_mod):
             if s.topo.is_active[t]:
                 s.com[t] = s.com[t] + rng.uniform(-0.15, 0.15, s.com[t].shape) * (r > 0)
         systems.append(s)
-    eng = Engine.from_system(base, n_replicas=nrep)
+    eng = Engine.from_system(base, n_replicas=engine_replicas or nrep)
     oracles = []
     for r, s in enumerate(systems):
         eng.load_system(s, r)
@@ -169,6 +173,41 @@ def test_batched_candidates_vs_refcpu(maker, nrep, refcpu_mod):
     old2, new2 = eng.trial_energy_candidates(rep, t, m, sites)
     assert np.array_equal(old, old2) and np.array_equal(new, new2)
     eng.close()
+
+
+def test_the_benchmarks_launch_shape_one_wave_per_item(refcpu_mod, monkeypatch):
+    """bench.py's default engine (16 384 replicas) has nsplit = 1: ONE wave sweeps all 477 units of a fused item.  Every
+    other test at N = 10 125 runs a handful of replicas, i.e. nsplit 16-64.  Here that launch shape is forced
+    (MGPU_PAIR_NSPLIT=1) on engines of 256 replicas -- the farm branch of engine_nsplit -- and held to the reference's
+    golden vectors at the benchmark size (spce3375_scalars) and, on replicas holding different configurations, to the
+    oracle."""
+    monkeypatch.setenv("MGPU_PAIR_NSPLIT", "1")
+    g, s = golden_system("spce3375_scalars")
+    R = 256
+    eng = Engine.from_system(s, n_replicas=R)
+    eng.init_structure_factor(0, full=True)
+    for r in range(1, R):
+        eng.replica_copy(r, 0)
+    nmv = len(g["mv_t"])
+    t = g["mv_t"].astype(np.int32); m = g["mv_m"].astype(np.int32)
+    # the golden moves on many replicas at once (all copies of the same state): one launch of R fused items
+    rep = np.arange(R, dtype=np.int32)
+    idx = rep % nmv
+    old, new = eng.trial_energy_candidates(rep, t[idx], m[idx], g["mv_sites"][idx])
+    for c in range(R):
+        close(old[c], g["mv_old"][idx[c]][:3], f"nsplit 1, replica {c} old")
+        close(new[c], g["mv_new"][idx[c]][:3], f"nsplit 1, replica {c} new")
+    for c in range(nmv, R):
+        assert np.array_equal(old[c], old[idx[c]]) and np.array_equal(new[c], new[idx[c]])     # same state, same bits
+    # single-state items of the same shape: an insertion and a deletion
+    tc = int(g["cr_t"])
+    nc, cc = eng.pair_energy_candidates([3], [tc], [-1], g["cr_sites"][None])
+    close([nc[0], cc[0]], g["cr_new"][:2], "nsplit 1 creation pair")
+    td, md = int(g["dl_t"]), int(g["dl_m"])
+    nc, cc = eng.ComputePairInteractionEnergy_singlemol(td, md, None, replica=7)
+    close([nc, cc], g["dl_old"][:2], "nsplit 1 deletion pair")
+    eng.close()
+    _batched_vs_refcpu(lambda: synth.spce_box(6, seed=21), 4, refcpu_mod, engine_replicas=256)
 
 
 def test_markov_chain_of_commits_tracks_oracle(refcpu_mod):
@@ -742,5 +781,48 @@ def test_framework_batch_kernel_matches_the_flat_sweep(three_site, refcpu_mod):
     same(res2[0][0], res2[1][0]); same(res2[0][1], res2[1][1])
     on2 = rep == 2
     assert np.max(np.abs(res2[0][1][on2 & (kinds != MGPU_DELETION)] - res[0][1][on2 & (kinds != MGPU_DELETION)])) > 0    # the moved atom is felt
+    for e in engines:
+        e.close()
+
+
+def test_a_committed_framework_move_switches_the_batch_kernel_off():
+    """pair_frozen_kernel sweeps replica 0's copy of the framework for every replica, which is only right while all
+    replicas hold that copy.  set_molecules / replica_copy track it; so must a COMMIT that moves the framework on one
+    replica (round-3 advisor finding: the flag survived such a commit and later batched trials swept stale atoms).  After
+    the commit the engine with the batch kernel must give what the engine without it gives (MGPU_NO_FROZEN_BATCH=1) --
+    and the moved framework must be felt."""
+    import os
+    s = synth.framework_water_box(n_water=12, n_frame=200, L=22.0, seed=6)
+    engines = []
+    for nobatch in (False, True):
+        if nobatch:
+            os.environ["MGPU_NO_FROZEN_BATCH"] = "1"
+        try:
+            e = Engine.from_system(s, n_replicas=3)
+        finally:
+            os.environ.pop("MGPU_NO_FROZEN_BATCH", None)
+        for r in range(3):
+            e.init_structure_factor(r, True)
+        engines.append(e)
+    rng = np.random.default_rng(2)
+    k = 9
+    m = rng.integers(0, 12, k).astype(np.int32)
+    cand = s.all_sites(1)[m] + rng.uniform(-0.3, 0.3, (k, 1, 3))
+    rep = (np.arange(k) % 3).astype(np.int32)
+    tt = np.ones(k, np.int32)
+    kinds = np.full(k, MGPU_MOVE, np.int32)
+    before = [e.gcmc_trial(rep, tt, m, kinds, cand) for e in engines]
+    frame = s.all_sites(0).copy()                         # (1, 200, 3): the framework is one molecule of type 0
+    frame[0, 17] += np.array([0.4, -0.3, 0.2])
+    for which, target in ((1, 1), (0, 0)):                # first a replica other than 0, then the reference copy itself
+        for e in engines:
+            e.commit_candidates([target], [0], [0], [MGPU_MOVE], frame, [1])
+        after = [e.gcmc_trial(rep, tt, m, kinds, cand) for e in engines]
+        for a, b in zip(after[0], after[1]):
+            assert np.all(np.abs(a - b) <= np.maximum(TOL_K, 16 * np.finfo(float).eps * np.abs(a))), np.max(np.abs(a - b))
+        on = rep == target
+        assert np.max(np.abs(after[0][1][on] - before[0][1][on])) > 1e-6          # the displaced framework atom is felt
+        untouched = rep == 2                                                        # (another kernel now: same sums, last bits may differ)
+        close(after[0][1][untouched], before[0][1][untouched], "replica 2 does not feel another replica's framework")
     for e in engines:
         e.close()

@@ -24,11 +24,13 @@ SUMMARY = json.load(open(os.path.join(RUNS, "summary.json")))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode", ["speculate8", "fused", "seams"])
+@pytest.mark.parametrize("mode", ["speculate8", "chain1", "batched8", "fused", "seams"])
 @pytest.mark.parametrize("case", sorted(SUMMARY))
 def test_run_writes_the_reference_files(case, mode, tmp_path):
-    """mode: speculate8 = windows of 8 steps per engine call (the default of run.py); fused = one batched call per
-    step; seams = one call per reference seam.  All three must write the reference's files."""
+    """mode: speculate8 = windows of 8 steps, ONE kernel launch per window that also decides and commits (the default of
+    run.py; the triclinic case falls back to the batched calls by itself); chain1 = the same with windows of one step;
+    batched8 = windows of 8 through the batched submit / wait calls, the rule and the commit in the host loop; fused = one
+    batched call per step; seams = one call per reference seam.  All five must write the reference's files."""
     seams = mode == "seams"
     from maniac_mc_amd import run
     inputs = os.path.join(RUNS, case, "inputs")
@@ -41,7 +43,11 @@ def test_run_writes_the_reference_files(case, mode, tmp_path):
     try:
         res = run.run_simulation("system.maniac", "system.data", "system.inc", out, seed=SUMMARY[case]["seed"],
                                  reservoir_path=reservoir, seams=seams, as_written=as_written,
-                                 speculate=8 if mode == "speculate8" else 1)
+                                 speculate=8 if mode in ("speculate8", "batched8") else 1,
+                                 chain_windows=mode in ("speculate8", "chain1"))
+        if mode in ("speculate8", "chain1"):
+            assert (res["chain_windows"][0] > 0) == (case != "spce_triclinic_nvt")
+            assert res["chain_windows"][1] == 0          # no step fell inside the 16-ulp margin
     finally:
         os.chdir(cwd)
     # running energies of the chain == a full recomputation of the final configuration (as written, A(k) carries

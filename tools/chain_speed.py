@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=4)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--ks", default="1,4,8,16")
+    ap.add_argument("--cases", default="co2_gcmc,framework_water_gcmc,spce_10125_nvt")
+    ap.add_argument("--chain-windows", type=int, default=1, help="0: batched submit / wait calls instead of one launch per window")
     a = ap.parse_args()
     ks = [int(k) for k in a.ks.split(",")]
     summary = json.load(open(os.path.join(RUNS, "summary.json")))
@@ -38,11 +40,14 @@ def main():
     files = io_maniac.write_input_files(s, tmp + "/spce_in", nb_block=2, nb_step=100, translation_step=0.3, rotation_step_angle=0.3,
                                         translation_proba=0.5, rotation_proba=0.5, masses=[15.9994, 1.008], atom_names=["OW", "HW"])
     cases.append(("spce_10125_nvt", list(files), dict(seed=5)))
+    want = a.cases.split(",")
     for name, files, kw in cases:
+        if name not in want:
+            continue
         base = None
         for k in ks:
             out = os.path.join(tmp, f"{name}_k{k}") + "/"
-            res = run.run_simulation(*files, out, nb_block=a.blocks, nb_step=a.steps, speculate=k, **kw)
+            res = run.run_simulation(*files, out, nb_block=a.blocks, nb_step=a.steps, speculate=k, chain_windows=bool(a.chain_windows), **kw)
             n = a.blocks * a.steps
             c = res["counters"]
             acc = int(c[1] + c[3] + c[5] + c[7])
@@ -52,7 +57,10 @@ def main():
             else:
                 diff = [f for f in sorted(os.listdir(out)) if f != "log.maniac" and not filecmp.cmp(os.path.join(out, f), os.path.join(base[0], f), shallow=False)]
                 same = f"  files identical to K={ks[0]}: {not diff}{' ' + str(diff) if diff else ''}  speed-up {base[1] / res['loop_seconds']:.2f}x"
-            print(f"{name:24s} K={k:2d}: {n} steps in {res['loop_seconds']:.2f} s -> {n / res['loop_seconds']:.0f} steps/s, acceptance {acc / n:.2f}{same}", flush=True)
+            print(f"{name:24s} K={k:2d}: {n} steps in {res['loop_seconds']:.3f} s -> {n / res['loop_seconds']:.0f} steps/s "
+                  f"(Monte Carlo loop alone {res['mc_seconds']:.3f} s -> {n / res['mc_seconds']:.0f} steps/s, initial energy {res['init_seconds']:.3f} s, "
+                  f"files {res['file_seconds']:.3f} s; windows {res['chain_windows'][0]}, "
+                  f"left to the host {res['chain_windows'][1]}), acceptance {acc / n:.2f}{same}", flush=True)
 
 
 if __name__ == "__main__":
