@@ -360,7 +360,7 @@ def replicas_sweep(system, counts, device, host_threads, seconds, t_step, r_step
     return out
 
 
-def single_chain_leg(system, device, t_step, r_step, steps=4000, k=8):
+def single_chain_leg(system, device, t_step, r_step, steps=4000, k=4):
     """ONE chain of the same box through the single-chain drop-in (mc_chain.f90 -> mgpu_chain_window: one kernel launch per
     window of up to k speculative steps, the launch also decides and commits): what a user with one chain gets."""
     import shutil
@@ -397,7 +397,10 @@ def config_legs(args, device):
         t0 = time.perf_counter()
         env = {k: v for k, v in os.environ.items() if k not in ("OMP_PLACES", "OMP_PROC_BIND")}
         try:
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+            # (this process's main thread has been bound to one core by the Fortran driver's OpenMP runtime, and a child
+            #  inherits the mask: give the child the whole original set back)
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env,
+                               preexec_fn=lambda: os.sched_setaffinity(0, ORIG_AFFINITY))
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
             if p.returncode != 0 or not line:
                 out[wl] = {"error": (p.stderr or p.stdout)[-400:], "returncode": p.returncode}
@@ -477,6 +480,10 @@ def main():
                     help="1: the engine keeps the molecules' frames and builds the trial moves on the device (no host mirror, no "
                          "candidate rows staged); 0: the Fortran driver builds them from its mirror (default: see WORKLOADS)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
+    ap.add_argument("--exchange", choices=["torch", "c-abi"], default="torch",
+                    help="the per-block all-gather of counters + uptake histogram: through torch.distributed (default: the "
+                         "tested path) or through the C ABI (mgpu_comm_create / mgpu_allgather_block_stats: RCCL called from "
+                         "libmaniac_hip.so, what a Fortran host uses; the id travels over the torch.distributed group)")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-timing", type=int, default=1, choices=[0, 1],
@@ -655,6 +662,13 @@ def main():
     timers0 = farm.timers() if hasattr(farm, "timers") else None
 
     from maniac_mc_amd import exchange
+    comm = None
+    if args.exchange == "c-abi":
+        uid = [exchange.CAbiComm.unique_id() if (rank == 0 and world > 1) else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        comm = exchange.CAbiComm(device=device, rank=rank, world=world, unique_id=uid[0])
+    gather = comm.gather_block_stats if comm is not None else exchange.gather_block_stats
 
     def fence():
         exchange.barrier()
@@ -681,7 +695,7 @@ def main():
                                    for p in range(ISOTHERM_POINTS)])
         else:
             hist = exchange.molecule_count_histogram(counts, nbins)
-    sums_by_rank, hist_by_rank = exchange.gather_block_stats([float(accepted), trials_now, evals_now], hist)
+    sums_by_rank, hist_by_rank = gather([float(accepted), trials_now, evals_now], hist)
     fence()
     elapsed = exchange.max_over_ranks(time.perf_counter() - t0)
     tot_acc, tot_trials, tot_evals = (float(sums_by_rank[:, k].sum()) for k in range(3))
@@ -702,7 +716,7 @@ def main():
         fence()
         ts0 = time.perf_counter()
         acc_s = farm.run(args.sustained_steps)
-        acc_s = float(exchange.gather_block_stats([float(acc_s)], hist)[0][:, 0].sum())
+        acc_s = float(gather([float(acc_s)], hist)[0][:, 0].sum())
         fence()
         el_s = exchange.max_over_ranks(time.perf_counter() - ts0)
         sustained = {"steps": args.sustained_steps, "value": acc_s / el_s, "unit": "accepted MC moves/s",
@@ -902,10 +916,13 @@ def main():
                                for p in range(ISOTHERM_POINTS)]
         if wl != "spce":
             out["exchange"] = {"collective": "all_gather", "backend": args.dist_backend if world > 1 else None,
+                               "through": "C ABI (mgpu_allgather_block_stats, RCCL from libmaniac_hip.so)" if comm is not None else "torch.distributed",
                                "bytes_per_rank": int(hist.nbytes + 24), "per": "block (= the timed region)"}
         if timers0 is not None:
             out["host_seconds"] = {k: v - timers0[k] for k, v in timers1.items()}   # timed region only
     farm.close()
+    if comm is not None:
+        comm.close()
     if rank == 0:
         # GPU legs first, CPU baselines last (short), so that whoever samples the GPU from outside sees it busy
         if world == 1 and args.replicas_sweep and wl == "spce" and args.host == "fortran":

@@ -356,9 +356,9 @@ int mgpu_replica_set_num_molecules(mgpu_engine *e, int replica, int t, int n_mol
  * accept_u[c] and prefactors accept_pref[c] (1 for a translation / rotation; phi V / N for an insertion, N = the count
  * after it; (N + 1) / (phi V) for a deletion, N = the count after it -- create_molecule.f90:64, delete_molecule.f90:73),
  * and commits the FIRST accepted step on the device (A(k) += delta, coordinates, count -- AcceptMove and the Accept* of
- * create_molecule.f90:100-112 / delete_molecule.f90:100-142).  Candidates are read from, and results written to, pinned
- * host memory by the kernel itself; the call returns as soon as the results are there, while the commit still runs
- * (every later call is ordered behind it).
+ * create_molecule.f90:100-112 / delete_molecule.f90:100-142).  The window travels in the kernel's arguments and the
+ * kernel writes its results straight into pinned host memory; the call returns as soon as the results are there, while
+ * the commit still runs (every later call is ordered behind it).
  *   kind[c]     MGPU_MOVE / MGPU_CREATION / MGPU_DELETION; m[c] ignored for creations (appended)
  *   link[c]     -1: an ordinary step.  >= 0 (deletions only): the reference's deletion AS WRITTEN (SURVEY F3,
  *               monte_carlo_utils.f90:301-309): the step's new reciprocal energy is the creation-kind energy of row
@@ -384,6 +384,49 @@ int mgpu_chain_window(mgpu_engine *e, int replica, int n, const int *t, const in
                       int *first_accepted, int *undecided);
 int mgpu_chain_set_margin(mgpu_engine *e, double relative_margin);
 int mgpu_chain_get_stats(const mgpu_engine *e, long long *windows, long long *undecided);
+/* Stage times of a window, measured inside the kernel (the launch IS the step: there is nothing between its stages for a
+ * host-side tracer to see).  set_timing(1): later windows record the device's 100 MHz wall clock at their stages;
+ * get_timing: the last window's stages in microseconds since its first workgroup started --
+ *   us[0..3]   k role of candidate 0: start, phase tables built, k sweep summed, at the ticket
+ *   us[4..7]   first pair workgroup: start, Coulomb table staged, its work units swept, at the ticket
+ *   us[8..14]  resolving workgroup: last ticket drawn, acquire fence passed, partials reduced, decided, tag published,
+ *              commit tables built, commit done (the last two 0 when the window accepted nothing). */
+int mgpu_chain_set_timing(mgpu_engine *e, int on);
+int mgpu_chain_get_timing(mgpu_engine *e, double us[15]);
+
+/* ------------------------------------------------------------------------------------------
+ * The path's one exchange step: replicas are farmed over the GPUs of a node, one process per GPU,
+ * and never communicate while they run; once per block every rank contributes its chains' molecule-count histogram
+ * (what the reference records per chain in number_<res>.dat, src/write_utils.f90:144-150) and a few running sums, and
+ * receives the rank-ordered table: one RCCL all-gather over xGMI (<= 40 KB per rank: latency-bound).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mgpu_comm mgpu_comm;
+#define MGPU_COMM_ID_BYTES 128
+/* Rank 0 makes the id (ncclGetUniqueId) and hands it to the other ranks by whatever means the host has (a file, MPI,
+ * a socket; bench.py broadcasts it over its torch.distributed group); every rank then calls mgpu_comm_create with it.
+ * world == 1 needs no id (NULL) and never initialises RCCL: its gather is the identity. */
+int mgpu_comm_unique_id(void *id128);
+int mgpu_comm_create(mgpu_comm **out, int device, int rank, int world, const void *id128);
+int mgpu_comm_destroy(mgpu_comm *c);
+int mgpu_comm_rank(const mgpu_comm *c, int *rank, int *world);
+/* sums_by_rank[world][n_sums] <- every rank's sums[n_sums]; hist_by_rank[world][n_bins] <- every rank's hist[n_bins]
+ * (either may be empty).  Blocking; the same call, with the same sizes, on every rank. */
+int mgpu_allgather_block_stats(mgpu_comm *c, int n_sums, const double *sums, int n_bins, const long long *hist,
+                               double *sums_by_rank, long long *hist_by_rank);
+
+/* ------------------------------------------------------------------------------------------
+ * Output surface helper (host only)
+ * ---------------------------------------------------------------------------------------- */
+
+/* The atom records of trajectory.lammpstrj (mol == NULL: '(I6,1X,I4,3(1X,F12.7))', WriteLAMMPSTRJ, src/write_utils.f90:86)
+ * or of topology.data's Atoms section ('(I6,1X,I6,1X,I4,1X,F12.8,3(1X,F12.7))', WriteLAMMPSData, :297-300) appended to
+ * `path`, byte for byte what the Fortran runtime's edit descriptors produce (exact decimal conversion, round half to even,
+ * asterisks on overflow) at a tenth of its cost: the single-chain driver writes 2 x 10 125 of them per block.  On any
+ * error nothing has been written and the caller writes the records itself.  mgpu_format_fixed: the Fw.d conversion alone
+ * (tests). */
+int mgpu_append_atom_records(const char *path, int n, int first_serial, const int *mol, const int *type, const double *charge,
+                             const double *xyz);
+int mgpu_format_fixed(int n, const double *x, int w, int d, char *out);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement

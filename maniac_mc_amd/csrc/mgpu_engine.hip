@@ -206,15 +206,17 @@ struct mgpu_engine {
     // single-chain windows (mgpu_chain_window): pinned, host-coherent blocks the kernel reads its candidates from and
     // writes its results to (no copies, no stream synchronisation: the host polls the tag), and device scratch
     struct Chain {
-        ChainCand *h_cand[2] = {nullptr, nullptr};   // alternate per window: the commit of window w still reads block w & 1
-        double *h_out = nullptr;                     // [kChainMaxCand][10] energies | first, undecided
+        double *h_out = nullptr;                     // [kChainMaxCand][10] energies | first, undecided | stage stamps
         unsigned long long *h_tag = nullptr;
+        Topo *d_topo = nullptr;                      // the engine's Topo in device memory (the kernel indexes it by loaded residue types)
+        bool topo_stale = true;
         ChainResult *d_res = nullptr;
         double2 *d_part = nullptr;
         int *d_ticket = nullptr;
         unsigned long long seq = 0;
         double margin = 16.0 * 2.220446049250313e-16;   // relative band around the acceptance probability left to the host's exp
         long long windows = 0, undecided = 0;
+        bool timing = false;                         // stage stamps wanted (mgpu_chain_set_timing)
     } chain;
     // profiling
     bool profiling = false;
@@ -351,7 +353,9 @@ bool replica_in_range(const mgpu_engine *e, int replica) {
 // the replicas per launch): n_cu * 64 / n_replicas rounded down to a power of two, between 1 and 4 -- 4 at 2048
 // replicas, 2 at 8192 (measured at the 10 125-atom box, 1024 fused items per launch: 4 -> 98.9 us, 8 -> 104.6 us,
 // 16 -> 116 us; 2048 items per launch on four lanes: 2 -> 6.94 M, 4 -> 6.79 M, 8 -> 6.52 M accepted moves/s).
-// A small engine may use up to 16 (single chains are latency-bound: a trial is swept by up to 16 waves).
+// A small engine (< 256 replicas: single chains, a handful of chains) is latency-bound: up to 32 waves per item, two sweep
+// units per wave (round 4, one chain, stage stamps of mgpu_chain_window: 10 125-atom box 59 -> 32 waves 16.7 -> 15.2 us to
+// the window's results, 128 waves 15.1 us with a longer reduction; framework box 5 -> 32 waves 21.1 -> 12.1 us).
 // MGPU_PAIR_NSPLIT overrides it (tuning only; read once at engine creation).
 int engine_nsplit(const mgpu_engine *e) {
     int units = 0;
@@ -359,8 +363,9 @@ int engine_nsplit(const mgpu_engine *e) {
         const int cap = e->tp.cap[t], n1 = e->tp.n1[t];
         units += e->tp.site_major[t] ? cap * ((n1 + 63) / 64) : n1 * ((cap + 63) / 64);
     }
-    int cap_split = 64;
+    int cap_split = 32, per_wave = 2;
     if (e->n_replicas >= 256) {
+        per_wave = 8;
         int want = std::max(1, e->n_cu * 64 / e->n_replicas);
         // Short work units (the grand-canonical boxes: a few dozen units per item, and a launch carries 1.5 items per
         // candidate) are dominated by their tail: twice the waves per item fill the last round (round 3, framework box,
@@ -369,7 +374,7 @@ int engine_nsplit(const mgpu_engine *e) {
         cap_split = 1;
         while (cap_split * 2 <= std::min(want, 4)) cap_split *= 2;
     }
-    int ns = std::max(1, std::min(units / 8, cap_split));
+    int ns = std::max(1, std::min(units / per_wave, cap_split));
     if (const char *ov = std::getenv("MGPU_PAIR_NSPLIT")) ns = std::max(1, std::min(std::atoi(ov), std::max(1, units)));
     return ns;
 }
@@ -552,7 +557,8 @@ int launch_frozen(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items
 #define MGPU_LAUNCH_FROZEN_1(NS, FU, FW)                                                                                \
     do {                                                                                                               \
         const int nb = resident_blocks<&pair_frozen_kernel<NS, FU, FW>>(ln, e->coul_bytes);                                \
-        const int grid_f = std::max(1, std::min((n_work + kPairWaves - 1) / kPairWaves, e->n_cu * nb));               \
+        /* every resident workgroup slot gets a workgroup: the kernel deals the units over them evenly */               \
+        const int grid_f = std::max(1, std::min(n_work, e->n_cu * nb));                                               \
         hipExtLaunchKernelGGL((pair_frozen_kernel<NS, FU, FW>), dim3(grid_f), dim3(kPairBlock), e->coul_bytes, ln.stream, a, b, 0, \
                               e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab,   \
                               d_items, (const double *)ln.d_sites.p, site_stride, n_items, t_frozen, n_chunks, e->frozen_chunk, d_scratch); \
@@ -1033,9 +1039,9 @@ int mgpu_engine_destroy(mgpu_engine *e) {
                     (void *)e->d_tw, (void *)e->d_kslot, (void *)e->d_rrows, (void *)e->d_atom_ty, (void *)e->d_com, (void *)e->d_off})
         if (p) (void)hipFree(p);
     e->h_stage.release();
-    for (void *p : {(void *)e->chain.h_cand[0], (void *)e->chain.h_cand[1], (void *)e->chain.h_out, (void *)e->chain.h_tag})
+    for (void *p : {(void *)e->chain.h_out, (void *)e->chain.h_tag})
         if (p) (void)hipHostFree(p);
-    for (void *p : {(void *)e->chain.d_res, (void *)e->chain.d_part, (void *)e->chain.d_ticket})
+    for (void *p : {(void *)e->chain.d_res, (void *)e->chain.d_part, (void *)e->chain.d_ticket, (void *)e->chain.d_topo})
         if (p) (void)hipFree(p);
     for (auto &ln : e->lanes) {
         ln.release();
@@ -1192,6 +1198,7 @@ int mgpu_replica_set_frames(mgpu_engine *e, int replica, int t, int n_mol, const
         HIP_TRY(hipMemset(e->d_off, 0, R * 3 * tp.n_cap_atoms * sizeof(double)));
         e->tp.com = e->d_com;
         e->tp.off = e->d_off;
+        e->chain.topo_stale = true;
     }
     const size_t seg = (size_t)n1 * cap;
     if ((rc = e->h_stage.reserve(3 * (seg + cap) * sizeof(double)))) return rc;
@@ -2187,6 +2194,33 @@ int mgpu_chain_set_margin(mgpu_engine *e, double relative_margin) {
     return MGPU_OK;
 }
 
+int mgpu_chain_set_timing(mgpu_engine *e, int on) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    e->chain.timing = on != 0;
+    return MGPU_OK;
+}
+
+// Stage times of the LAST window in microseconds since its first workgroup started (100 MHz wall clock of the device):
+//   us[0..3]   k role of candidate 0: start, phase tables built, k sweep summed, at the ticket
+//   us[4..7]   first pair workgroup:  start, Coulomb table staged, its work units swept, at the ticket
+//   us[8..14]  resolving workgroup:   last ticket drawn, acquire fence, partials reduced, decided, tag published,
+//                                     commit tables built, commit done (the last two 0 when nothing was accepted)
+int mgpu_chain_get_timing(mgpu_engine *e, double us[15]) {
+    if (!e || !us) return set_error(MGPU_ERR_INVALID_ARG, "chain_get_timing: null argument");
+    if (!e->chain.h_out) return set_error(MGPU_ERR_STATE, "chain_get_timing: no window has run");
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->lanes[0].stream));      // the commit's stamps are written behind the tag
+    const long long *ts = (const long long *)(e->chain.h_out + 10 * kChainMaxCand + 2);
+    const long long t0 = std::min(ts[0], ts[kChainStamps]);
+    const int first = ((const int *)(e->chain.h_out + 10 * (size_t)kChainMaxCand))[0];
+    int k = 0;
+    for (int i = 0; i < 4; ++i) us[k++] = (double)(ts[i] - t0) * 0.01;
+    for (int i = 0; i < 4; ++i) us[k++] = (double)(ts[kChainStamps + i] - t0) * 0.01;
+    for (int i = 0; i < 7; ++i) us[k++] = (i >= 5 && first < 0) ? 0.0 : (double)(ts[2 * kChainStamps + i] - t0) * 0.01;
+    return MGPU_OK;
+}
+
 int mgpu_chain_get_stats(const mgpu_engine *e, long long *windows, long long *undecided) {
     if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
     if (windows) *windows = e->chain.windows;
@@ -2212,19 +2246,24 @@ int mgpu_chain_window(mgpu_engine *e, int replica, int n, const int *t, const in
     if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "chain_window: lane 0 still holds an un-waited trial");
     mgpu_engine::Chain &ch = e->chain;
     if (!ch.h_tag) {
-        for (auto &p : ch.h_cand) HIP_TRY(hipHostMalloc((void **)&p, sizeof(ChainCand) * kChainMaxCand, hipHostMallocCoherent));
-        HIP_TRY(hipHostMalloc((void **)&ch.h_out, sizeof(double) * (10 * kChainMaxCand + 2), hipHostMallocCoherent));
+        HIP_TRY(hipHostMalloc((void **)&ch.h_out, sizeof(double) * (10 * kChainMaxCand + 2 + 3 * kChainStamps), hipHostMallocCoherent));
+        std::memset(ch.h_out, 0, sizeof(double) * (10 * kChainMaxCand + 2 + 3 * kChainStamps));
         HIP_TRY(hipHostMalloc((void **)&ch.h_tag, 64, hipHostMallocCoherent));
         *ch.h_tag = 0;
         HIP_TRY(hipMalloc((void **)&ch.d_res, sizeof(ChainResult) * kChainMaxCand));
         HIP_TRY(hipMalloc((void **)&ch.d_part, sizeof(double2) * 2 * kChainMaxCand * (size_t)e->pair_nsplit));
         HIP_TRY(hipMalloc((void **)&ch.d_ticket, sizeof(int)));
         HIP_TRY(hipMemset(ch.d_ticket, 0, sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&ch.d_topo, sizeof(Topo)));
         HIP_TRY(hipDeviceSynchronize());
     }
-    // ---- the window's candidate records, written straight into the pinned block the kernel reads
+    if (ch.topo_stale) {
+        if ((rc = sync_lane(e, ln))) return rc;
+        HIP_TRY(hipMemcpy(ch.d_topo, &e->tp, sizeof(Topo), hipMemcpyHostToDevice));
+        ch.topo_stale = false;
+    }
+    // ---- the window travels in the kernel arguments
     ChainArgs g{};
-    ChainCand *cand = ch.h_cand[(ch.seq + 1) & 1];
     bool fast = replica_in_range(e, replica);
     char cand_ok[kChainMaxCand];
     int n1_max = 1, n_ent = 0;
@@ -2248,16 +2287,14 @@ int mgpu_chain_window(mgpu_engine *e, int replica, int n, const int *t, const in
         if (k == MGPU_CREATION && lk != -2 && e->h_nmol[idx] >= e->tp.cap[t[c]])
             return set_error(MGPU_ERR_CAPACITY, "chain_window: residue type is at mol_capacity");
         n1_max = std::max(n1_max, n1);
-        ChainCand &cd = cand[c];
-        cd.t = t[c]; cd.m = mc; cd.kind = k; cd.link = lk;
-        cd.u = accept_u[c]; cd.pref = accept_pref[c]; cd.self = k == MGPU_MOVE ? 0.0 : e->self_of_type[t[c]];
-        cd.pad = 0.0;
+        g.t[c] = t[c]; g.m[c] = mc; g.kind[c] = (signed char)k; g.link[c] = (signed char)lk;
+        g.u[c] = accept_u[c]; g.pref[c] = accept_pref[c];
         const double *row = sites + (size_t)c * site_stride * 3;
         cand_ok[c] = 1;
         if (k != MGPU_DELETION) {
             // the engine's site order for a frozen type is not the caller's: such types are inactive and never move
             if (e->frozen[t[c]]) return set_error(MGPU_ERR_INVALID_ARG, "chain_window: frozen residue types do not move");
-            std::memcpy(&cd.sites[0][0], row, (size_t)n1 * 3 * sizeof(double));
+            std::memcpy(&g.sites[c][0][0], row, (size_t)n1 * 3 * sizeof(double));
             cand_ok[c] = sites_in_range(e, row, n1) ? 1 : 0;
             if (lk != -2) fast = fast && cand_ok[c];
         }
@@ -2270,7 +2307,9 @@ int mgpu_chain_window(mgpu_engine *e, int replica, int n, const int *t, const in
     const size_t lds = std::max(std::max(e->coul_bytes, recip_rows_lds_bytes(e, n1_max)), (size_t)n_ent * nsplit * sizeof(double2));
     if (lds > 64 * 1024) return set_error(MGPU_ERR_CAPACITY, "chain_window: the window does not fit the LDS budget");
     ch.seq += 1;
-    g.cand = cand; g.res = ch.d_res; g.partials = ch.d_part; g.ticket = ch.d_ticket;
+    for (int tt = 0; tt < e->tp.n_res; ++tt) g.self_of_type[tt] = e->self_of_type[tt];
+    g.stamps = ch.timing ? 1 : 0;
+    g.res = ch.d_res; g.partials = ch.d_part; g.ticket = ch.d_ticket;
     g.host_out = ch.h_out; g.host_tag = ch.h_tag; g.seq = ch.seq;
     g.n = n; g.n_ent = n_ent; g.nsplit = nsplit; g.replica = replica;
     g.temperature = temperature; g.e_recip = recip_energy; g.margin = ch.margin;
@@ -2281,7 +2320,7 @@ int mgpu_chain_window(mgpu_engine *e, int replica, int n, const int *t, const in
     ln.d_trial_items = nullptr;
     ln.h_trial_items = nullptr;
 #define MGPU_LAUNCH_CHAIN(FL, FW)                                                                                          \
-    hipLaunchKernelGGL((chain_window_kernel<FL, FW>), dim3(grid), dim3(kChainBlock), lds, ln.stream, e->tp, e->bx, e->d_pos, e->d_nmol, \
+    hipLaunchKernelGGL((chain_window_kernel<FL, FW>), dim3(grid), dim3(kChainBlock), lds, ln.stream, ch.d_topo, e->bx, e->d_pos, e->d_nmol, \
                        e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab, e->d_trj, e->d_tw, e->n_rtasks, e->d_rrows, e->n_rrows, \
                        e->d_A, g)
     if (e->pair_flat) { if (ff) MGPU_LAUNCH_CHAIN(true, true); else MGPU_LAUNCH_CHAIN(true, false); }
@@ -2307,7 +2346,7 @@ int mgpu_chain_window(mgpu_engine *e, int replica, int n, const int *t, const in
         std::memcpy(old_energy + 5 * (size_t)c, ch.h_out + 10 * (size_t)c, 5 * sizeof(double));
         std::memcpy(new_energy + 5 * (size_t)c, ch.h_out + 10 * (size_t)c + 5, 5 * sizeof(double));
     }
-    const int *hi = (const int *)(ch.h_out + 10 * (size_t)n);
+    const int *hi = (const int *)(ch.h_out + 10 * (size_t)kChainMaxCand);
     const int first = hi[0], und = hi[1];
     *first_accepted = first;
     *undecided = und;

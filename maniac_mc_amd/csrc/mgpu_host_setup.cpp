@@ -9,7 +9,9 @@
 // The arithmetic keeps the reference's association order so that alpha, kmax, Nk, |k|^2 and
 // W(k) come out identical to the Fortran on the same inputs (checked in tests/).
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/maniac_gpu.h"
@@ -218,7 +220,130 @@ double coulomb_table_eval_host(const std::vector<CoulRow> &rows, int idx_base, d
 
 }  // namespace mgpu
 
+// ------------------------------------------------------------------------------------------
+// Atom records of the reference's output files (trajectory.lammpstrj, topology.data: src/write_utils.f90:86, :297-300),
+// formatted here instead of by the Fortran runtime: flang's Fw.d conversion costs ~0.2 us per number -- 16 ms per
+// UpdateFiles at 10 125 atoms, a third of a single chain's run time once a window is one kernel launch.  The conversion
+// below is EXACT (the double's integer mantissa times 10^d in 128-bit arithmetic, shifted with round-half-to-even), so
+// the bytes are the runtime's own: tests/test_host_setup.py holds it to flang's output on random and boundary values.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+// x in Fortran Fw.d into out[0..w) (no terminator); false: not finite (the caller falls back to the Fortran write)
+bool format_fixed(char *out, int w, int d, double x) {
+    if (!std::isfinite(x)) return false;
+    const bool neg = std::signbit(x);
+    const double ax = std::fabs(x);
+    auto stars = [&]() { std::memset(out, '*', (size_t)w); return true; };
+    int e = 0;
+    unsigned long long m = 0;
+    if (ax != 0.0) {
+        const double fr = std::frexp(ax, &e);                 // ax = fr * 2^e, fr in [0.5, 1)
+        m = (unsigned long long)std::ldexp(fr, 53);           // exact 53-bit integer
+        e -= 53;                                              // ax = m * 2^e
+    }
+    if (e >= 0 && m != 0) return stars();                     // |x| >= 2^52: never fits these widths
+    static const unsigned long long p10[] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull, 100000000ull,
+                                             1000000000ull};
+    if (d < 0 || d > 9) return false;
+    unsigned __int128 P = (unsigned __int128)m * p10[d];
+    unsigned __int128 N = 0;
+    const int sh = -e;
+    if (m != 0) {
+        if (sh >= 127) {
+            N = 0;                                            // below half a unit of the last place by far
+        } else {
+            N = P >> sh;
+            const unsigned __int128 rem = P & ((((unsigned __int128)1) << sh) - 1), half = ((unsigned __int128)1) << (sh - 1);
+            if (rem > half || (rem == half && (N & 1))) N += 1;
+        }
+    }
+    if (N >> 64) return stars();
+    const unsigned long long n64 = (unsigned long long)N, ip = n64 / p10[d], fp = n64 % p10[d];
+    char tmp[64];
+    int len = 0;
+    char digits[24];
+    int nd = 0;
+    unsigned long long v = ip;
+    do { digits[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
+    if (neg) tmp[len++] = '-';
+    for (int k = nd - 1; k >= 0; --k) tmp[len++] = digits[k];
+    tmp[len++] = '.';
+    for (int k = d - 1; k >= 0; --k) tmp[len++] = (char)('0' + (fp / p10[k]) % 10);
+    if (len > w) {
+        // the optional leading zero goes first (F editing, Fortran 2018 13.7.2.3.2)
+        if (ip == 0 && len - 1 == w) {
+            std::memmove(tmp + (neg ? 1 : 0), tmp + (neg ? 2 : 1), (size_t)(len - (neg ? 2 : 1)));
+            len -= 1;
+        } else {
+            return stars();
+        }
+    }
+    std::memset(out, ' ', (size_t)(w - len));
+    std::memcpy(out + (w - len), tmp, (size_t)len);
+    return true;
+}
+
+void format_int(char *out, int w, long long v) {
+    char tmp[32];
+    const int len = std::snprintf(tmp, sizeof tmp, "%lld", v);
+    if (len > w) { std::memset(out, '*', (size_t)w); return; }
+    std::memset(out, ' ', (size_t)(w - len));
+    std::memcpy(out + (w - len), tmp, (size_t)len);
+}
+
+}  // namespace
+
+using mgpu::set_error;
+
 extern "C" {
+
+// n atom records appended to `path`.  mol == NULL: '(I6,1X,I4,3(1X,F12.7))' = serial, type, x, y, z (WriteLAMMPSTRJ);
+// else '(I6,1X,I6,1X,I4,1X,F12.8,3(1X,F12.7))' = serial, molecule, type, charge, x, y, z (WriteLAMMPSData).  xyz is
+// [n][3]; serials count from first_serial.  Returns MGPU_OK, or an error WITHOUT having written anything (a value that is
+// not finite, a file that cannot be opened): the caller then writes the records itself.
+int mgpu_append_atom_records(const char *path, int n, int first_serial, const int *mol, const int *type, const double *charge,
+                             const double *xyz) {
+    if (!path || n < 0 || !type || !xyz || (mol && !charge)) return set_error(MGPU_ERR_INVALID_ARG, "append_atom_records: bad argument");
+    const int reclen = mol ? (6 + 1 + 6 + 1 + 4 + 1 + 12 + 3 * 13 + 1) : (6 + 1 + 4 + 3 * 13 + 1);
+    std::vector<char> buf((size_t)n * reclen);
+    for (int i = 0; i < n; ++i) {
+        char *r = buf.data() + (size_t)i * reclen;
+        int at = 0;
+        format_int(r + at, 6, (long long)first_serial + i); at += 6;
+        r[at++] = ' ';
+        if (mol) {
+            format_int(r + at, 6, mol[i]); at += 6;
+            r[at++] = ' ';
+        }
+        format_int(r + at, 4, type[i]); at += 4;
+        if (mol) {
+            r[at++] = ' ';
+            if (!format_fixed(r + at, 12, 8, charge[i])) return set_error(MGPU_ERR_INVALID_ARG, "append_atom_records: charge not finite");
+            at += 12;
+        }
+        for (int dd = 0; dd < 3; ++dd) {
+            r[at++] = ' ';
+            if (!format_fixed(r + at, 12, 7, xyz[(size_t)i * 3 + dd])) return set_error(MGPU_ERR_INVALID_ARG, "append_atom_records: coordinate not finite");
+            at += 12;
+        }
+        r[at++] = '\n';
+    }
+    FILE *f = std::fopen(path, "ab");
+    if (!f) return set_error(MGPU_ERR_STATE, std::string("append_atom_records: cannot open ") + path);
+    const size_t wrote = buf.empty() ? 0 : std::fwrite(buf.data(), 1, buf.size(), f);
+    const int rc = std::fclose(f);
+    if (wrote != buf.size() || rc != 0) return set_error(MGPU_ERR_STATE, std::string("append_atom_records: short write to ") + path);
+    return MGPU_OK;
+}
+
+// test hook: x[i] in Fortran Fw.d, w characters each, into out[n * w]; out[i * w] = '?' where the value is not finite
+int mgpu_format_fixed(int n, const double *x, int w, int d, char *out) {
+    if (n < 0 || !x || !out || w < 1 || w > 40) return set_error(MGPU_ERR_INVALID_ARG, "format_fixed: bad argument");
+    for (int i = 0; i < n; ++i)
+        if (!format_fixed(out + (size_t)i * w, w, d, x[i])) std::memset(out + (size_t)i * w, '?', (size_t)w);
+    return MGPU_OK;
+}
 
 int mgpu_box_prepare(const double box_matrix[9], int *box_type, double *volume, double reciprocal[9], double metrics[9]) {
     return mgpu::box_prepare(box_matrix, box_type, volume, reciprocal, metrics);

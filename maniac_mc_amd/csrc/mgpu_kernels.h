@@ -116,6 +116,20 @@ __device__ __forceinline__ int atom_slot(const Topo &tp, int t, int m, int a) {
     return tp.site_major[t] ? tp.seg_off[t] + m * tp.n1[t] + a : tp.seg_off[t] + a * tp.cap[t] + m;
 }
 
+// a pair-sweep partial {e_lj, e_coul}; SC1: agent-scope write-through stores (see pair_sweep_item)
+template <bool SC1>
+__device__ __forceinline__ void store_partial(double2 *p, double a, double b) {
+    if constexpr (SC1) {
+        __hip_atomic_store(&p->x, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p->y, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *p = make_double2(a, b);
+    }
+}
+__device__ __forceinline__ double load_sc1(const double *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -188,19 +202,25 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // (build_coulomb_table, mgpu_host_setup.cpp): the row is selected by the binary exponent and the top
 // 6 mantissa bits of s, the local coordinate t = s - (s with the remaining mantissa bits cleared), the value a
 // degree-6 polynomial (5 fp64 + 2 fp32 coefficients = 48 bytes = three ds_read_b128).  No sqrt, rsqrt,
-// erfc, exp or division.  `below` is set for s < 2^-2 (r < 0.5 A), where the caller takes the slow path.
-__device__ __forceinline__ double coul_lds(double s, const char *__restrict__ tab, int idx_base, int last_row,
-                                           bool &below) {
+// erfc, exp or division.
+// Index path, two instructions (round 4; it was four): sh = the high word of s shifted down to (exponent | 6 mantissa bits),
+// address = sh * 48 + tab_adj in ONE v_mad_u32_u24, where tab_adj = table - idx_base * 48 (coul_tab_adjusted) carries the
+// subtraction of the table's first index.  There is NO clamp: a minimum-image r^2 cannot lie beyond the table (it is built
+// up to the box's largest minimum-image distance), and an s BELOW the table (r < 0.5 A: sh < idx_base) makes the 32-bit
+// address wrap far outside the workgroup's LDS allocation, where ds_read returns zeros and raises nothing
+// (tools/probe_lds_oob.hip, measured on MI355X) -- the caller replaces those lanes by the slow path anyway: it keeps
+// the smallest sh of a unit (`sh_min`: v_min3_u32, one instruction per two or three terms) and compares once.
+__device__ __forceinline__ const char *coul_tab_adjusted(const char *tab, int idx_base) {
+    return tab - (size_t)idx_base * sizeof(CoulRow);
+}
+__device__ __forceinline__ double coul_lds(double s, const char *__restrict__ tab_adj, unsigned &sh_out) {
     const int hi = __double2hiint(s);
-    const int srow = (hi >> (20 - kCoulM)) - idx_base;
-    below = srow < 0;
-    // one unsigned min clamps both ends: rows below the table wrap to huge values and land, like rows
-    // above it, on the all-zero last row (the caller replaces `below` lanes by the slow path)
-    const unsigned row = min((unsigned)srow, (unsigned)last_row);
+    const unsigned sh = (unsigned)hi >> (20 - kCoulM);
+    sh_out = sh;
     constexpr int kMant = (1 << (20 - kCoulM)) - 1;
     const double s0 = __hiloint2double(hi & ~kMant, 0);                  // the row's first s: low mantissa bits cleared
     const double t = s - s0;                                             // exact; rows are expanded in it
-    const double2 *r = reinterpret_cast<const double2 *>(tab + __umul24(row, (unsigned)sizeof(CoulRow)));
+    const double2 *r = reinterpret_cast<const double2 *>(tab_adj + __umul24(sh, (unsigned)sizeof(CoulRow)));
     const double2 c01 = r[0], c23 = r[1], c4f = r[2];
     const double c5 = (double)__int_as_float(__double2loint(c4f.y));
     double p = fma((double)__int_as_float(__double2hiint(c4f.y)), t, c5);
@@ -235,9 +255,9 @@ __device__ __forceinline__ void pair_term(double dx, double dy, double dz, const
         elj += (r2 < bx.rc2) ? e : 0.0;
     }
     if (do_c) {
-        bool below;
-        double g = coul_lds(r2, coul_tab, bx.coul_idx_base, bx.coul_last_row, below);
-        if (below) g = coul_slow(r2, bx.alpha, GUARD_R0);
+        unsigned sh;
+        double g = coul_lds(r2, coul_tab_adjusted(coul_tab, bx.coul_idx_base), sh);
+        if (sh < (unsigned)bx.coul_idx_base) g = coul_slow(r2, bx.alpha, GUARD_R0);
         ec += qq * g;
     }
 }
@@ -264,7 +284,9 @@ __device__ __forceinline__ void pair_term(double dx, double dy, double dz, const
 // partial {e_lj, e_coul} per state into partials[w * NST ...].  cand_sites / site_stride: the candidate rows (row it.src);
 // s_coul / s_pair: the workgroup's LDS copies of the Coulomb table and the pair table; w_site / w_sty: this wave's LDS slab
 // (NS = 0 only).  Shared by pair_sweep_kernel and chain_window_kernel.
-template <int NS, bool ORDERED, bool TRI, bool FUSED, bool FASTW>
+// SC1OUT: the partials are stored with agent-scope (`sc1`, write-through) stores, for a consumer in ANOTHER workgroup of the
+// same launch that reads them with `sc1` loads (chain_window_kernel's ticket hand-off).
+template <int NS, bool ORDERED, bool TRI, bool FUSED, bool FASTW, bool SC1OUT = false>
 __device__ __forceinline__ void pair_sweep_item(
     const Topo &tp, const BoxDev &bx, const double *__restrict__ pos, const int *__restrict__ nmol,
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
@@ -277,6 +299,7 @@ __device__ __forceinline__ void pair_sweep_item(
     constexpr int NST = FUSED ? 2 : 1;                    // states swept together (old, new)
     constexpr int NREG = NTY * NST;                       // register-resident sites: state-major, [state][site]
     const int nt = tp.n_types;
+    [[maybe_unused]] const char *coul_adj = coul_tab_adjusted(s_coul, bx.coul_idx_base);
     {
         const double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
         const double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
@@ -388,7 +411,7 @@ __device__ __forceinline__ void pair_sweep_item(
                         auto unit = [&](double xj, double yj, double zj, double wq, bool valid) {
                             const double rc2l = valid ? bx.rc2 : -1.0;
                             double r2[NREG], g[NREG];
-                            bool any_below = false;
+                            unsigned sh_min = ~0u;
 #pragma unroll
                             for (int s = 0; s < NREG; ++s) {
                                 r2[s] = FASTW ? image_r2_fast(xj - rx[s], yj - ry[s], zj - rz[s], bx)
@@ -397,11 +420,11 @@ __device__ __forceinline__ void pair_sweep_item(
 #pragma unroll
                             for (int s = 0; s < NREG; ++s) {
                                 if (!ALL_C && !c_on[s % NTY]) { g[s] = 0.0; continue; }
-                                bool below;
-                                g[s] = coul_lds(r2[s], s_coul, bx.coul_idx_base, bx.coul_last_row, below);
-                                any_below = any_below || below;
+                                unsigned sh;
+                                g[s] = coul_lds(r2[s], coul_adj, sh);
+                                sh_min = min(sh_min, sh);
                             }
-                            if (any_below) {   // r < 0.5 A somewhere in the wave: rare slow path
+                            if (sh_min < (unsigned)bx.coul_idx_base) {   // r < 0.5 A for this lane: rare slow path
 #pragma unroll
                                 for (int s = 0; s < NREG; ++s)
                                     if ((ALL_C || c_on[s % NTY]) && r2[s] < kCoulSlowBelow) g[s] = coul_slow(r2[s], bx.alpha, ORDERED);
@@ -516,7 +539,7 @@ __device__ __forceinline__ void pair_sweep_item(
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
             const double a = wave_sum(elj[st]), b = wave_sum(ec[st]);
-            if (lane == 0) partials[(size_t)w * NST + st] = make_double2(a, b);     // fused: {old, new} per work unit
+            if (lane == 0) store_partial<SC1OUT>(partials + (size_t)w * NST + st, a, b);     // fused: {old, new} per work unit
         }
     }
 }
@@ -580,7 +603,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
 // One work unit (item, split) of the flat sweep, executed by ONE WAVE; partials[w * NST ...] receives its partials.  s_grp: the
 // workgroup's LDS copy of the frozen residues' group records; w_plane: this wave's LDS slab of kFlatMaxPlanes records.
 // Shared by pair_flat_kernel and chain_window_kernel.
-template <int NS, bool FUSED, bool FASTW>
+template <int NS, bool FUSED, bool FASTW, bool SC1OUT = false>
 __device__ __forceinline__ void pair_flat_item(
     const Topo &tp, const BoxDev &bx, const double *__restrict__ pos, const int *__restrict__ nmol,
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const char *__restrict__ s_coul,
@@ -592,6 +615,7 @@ __device__ __forceinline__ void pair_flat_item(
     constexpr int NST = FUSED ? 2 : 1;
     constexpr int NREG = NTY * NST;
     const int nt = tp.n_types;
+    const char *coul_adj = coul_tab_adjusted(s_coul, bx.coul_idx_base);
     {
         const double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
         const double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
@@ -751,14 +775,14 @@ __device__ __forceinline__ void pair_flat_item(
                               : image_r2<false>(xj - rx[s], yj - ry[s], zj - rz[s], bx);
             if (any_c && __ballot(wq != 0.0) != 0ull) {
                 double g[NREG];
-                bool any_below = false;
+                unsigned sh_min = ~0u;
 #pragma unroll
                 for (int s = 0; s < NREG; ++s) {
-                    bool below;
-                    g[s] = coul_lds(r2[s], s_coul, bx.coul_idx_base, bx.coul_last_row, below);
-                    any_below = any_below || below;
+                    unsigned sh;
+                    g[s] = coul_lds(r2[s], coul_adj, sh);
+                    sh_min = min(sh_min, sh);
                 }
-                if (any_below) {   // r < 0.5 A somewhere in the wave: rare slow path
+                if (sh_min < (unsigned)bx.coul_idx_base) {   // r < 0.5 A for this lane: rare slow path
 #pragma unroll
                     for (int s = 0; s < NREG; ++s)
                         if (r2[s] < kCoulSlowBelow) g[s] = coul_slow(r2[s], bx.alpha, false);
@@ -793,7 +817,7 @@ __device__ __forceinline__ void pair_flat_item(
 #pragma unroll
             for (int s = 0; s < NTY; ++s) ec = fma(rq[s], acc[st * NTY + s], ec);
             const double a = wave_sum(elj[st]), b = wave_sum(ec);
-            if (lane == 0) partials[(size_t)w * NST + st] = make_double2(a, b);
+            if (lane == 0) store_partial<SC1OUT>(partials + (size_t)w * NST + st, a, b);
         }
     }
 }
@@ -863,6 +887,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const char *coul_adj = coul_tab_adjusted(s_coul, bx.coul_idx_base);
     const int n_groups = (n_items + 63) >> 6;
     const int n_work = n_groups * n_chunks;
     const int n_waves = gridDim.x * kPairWaves;
@@ -872,7 +897,11 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
     const double *fq = tp.slot_q + tp.seg_off[t_frozen];
     const int *fty = tp.slot_ty + tp.seg_off[t_frozen];
 
-    for (int w = blockIdx.x * kPairWaves + wave; w < n_work; w += n_waves) {
+    // Work units are dealt WORKGROUP-minor: unit w goes to workgroup w mod gridDim.x, so when a launch has fewer units than
+    // resident waves (3312 units on 4096 slots at the bench's framework box) every workgroup -- hence every CU -- carries
+    // the same number of busy waves (6-7 of 8) instead of the first workgroups carrying 8 and the last none.  Which wave
+    // computes a unit does not enter its partial: same bits.
+    for (int w = wave * (int)gridDim.x + (int)blockIdx.x; w < n_work; w += n_waves) {
         const int grp = w / n_chunks, chunk = w - grp * n_chunks;
         const int item_id = grp * 64 + lane;
         const bool live = item_id < n_items;
@@ -948,14 +977,14 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                               : image_r2<false>(xj - rx[s], yj - ry[s], zj - rz[s], bx);
             if (any_c && qj != 0.0) {
                 double g[NREG];
-                bool any_below = false;
+                unsigned sh_min = ~0u;
 #pragma unroll
                 for (int s = 0; s < NREG; ++s) {
-                    bool below;
-                    g[s] = coul_lds(r2[s], s_coul, bx.coul_idx_base, bx.coul_last_row, below);
-                    any_below = any_below || below;
+                    unsigned sh;
+                    g[s] = coul_lds(r2[s], coul_adj, sh);
+                    sh_min = min(sh_min, sh);
                 }
-                if (any_below) {   // r < 0.5 A for some lane: rare slow path
+                if (sh_min < (unsigned)bx.coul_idx_base) {   // r < 0.5 A for this lane: rare slow path
 #pragma unroll
                     for (int s = 0; s < NREG; ++s)
                         if (r2[s] < kCoulSlowBelow) g[s] = coul_slow(r2[s], bx.alpha, false);
@@ -1006,14 +1035,14 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                                       : image_r2<false>(xj - rx[s], yj - ry[s], zj - rz[s], bx);
                     if (any_c && qj != 0.0) {
                         double g[NREG];
-                        bool any_below = false;
+                        unsigned sh_min = ~0u;
 #pragma unroll
                         for (int s = 0; s < NREG; ++s) {
-                            bool below;
-                            g[s] = coul_lds(r2[s], s_coul, bx.coul_idx_base, bx.coul_last_row, below);
-                            any_below = any_below || (below && ok);
+                            unsigned sh;
+                            g[s] = coul_lds(r2[s], coul_adj, sh);
+                            sh_min = min(sh_min, sh);
                         }
-                        if (any_below) {
+                        if (ok && sh_min < (unsigned)bx.coul_idx_base) {
 #pragma unroll
                             for (int s = 0; s < NREG; ++s)
                                 if (ok && r2[s] < kCoulSlowBelow) g[s] = coul_slow(r2[s], bx.alpha, false);
@@ -1825,37 +1854,41 @@ __global__ void intra_kernel(Topo tp, BoxDev bx, const double *__restrict__ pos,
 // ------------------------------------------------------------------------------------------
 constexpr int kChainMaxCand = 16;
 constexpr int kChainBlock = kPairBlock;          // 512 threads: 8 pair waves; the k role uses the first kBlock of them
-struct ChainCand {                               // 168 B = 7 "sites" of three doubles: the pair bodies read the sites as rows of stride 7
-    int t, m, kind, link;                        // link: -1 none, >= 0 companion row of an as-written deletion, -2 energy-only row
-    double u, pref, self;                        // acceptance draw, prefactor (1; phi V / N; (N + 1) / (phi V)), ewald_self of the type
-    double pad;
-    double sites[kMaxFusedSitesWide][3];
-};
-static_assert(sizeof(ChainCand) == 168, "ChainCand is read as 7 sites of 24 bytes");
+constexpr int kChainStamps = 8;                  // stage time stamps per role (k role of candidate 0, first pair workgroup, resolver)
 struct ChainResult {                             // what the k role of candidate c leaves for the resolving workgroup
-    double u_old, u_new, intra, u, pref, self;
-    int t, m, kind, link;
+    double u_old, u_new, intra;
 };
+// The whole window travels in the KERNEL ARGUMENTS (3.6 KB with Topo and BoxDev, under the 4 KB limit): no upload, no
+// staging block, and no read of host memory on the kernel's critical path.
 struct ChainArgs {
-    const ChainCand *cand;                       // [n] in pinned host memory (read directly: no upload)
     ChainResult *res;                            // [n] device scratch
     double2 *partials;                           // [n_ent * nsplit] device scratch
     int *ticket;                                 // device counter, 0 between launches
-    double *host_out;                            // pinned host: [n][10] energies | first | undecided (ints) ...
+    double *host_out;                            // pinned host: [n][10] energies | first | undecided (ints) | stage stamps
     unsigned long long *host_tag;                // pinned host: window sequence number, written last
     unsigned long long seq;
     int n, n_ent, nsplit, replica;
+    int stamps;                                  // 1: record wall_clock64() at the stages (mgpu_chain_set_timing)
     double temperature, e_recip, margin;
+    double self_of_type[kMaxRes];                // ewald_self per residue type
+    int t[kChainMaxCand], m[kChainMaxCand];
+    signed char kind[kChainMaxCand];
+    signed char link[kChainMaxCand];             // -1 none, >= 0 companion row of an as-written deletion, -2 energy-only row
     unsigned char ent_c[2 * kChainMaxCand], ent_new[2 * kChainMaxCand];   // pair entries: candidate, 0 = resident (old) / 1 = candidate row (new)
     signed char ent_old_of[kChainMaxCand], ent_new_of[kChainMaxCand];     // per candidate: its old / new pair entry, -1 none
+    double u[kChainMaxCand], pref[kChainMaxCand];                          // acceptance draw, prefactor (1; phi V / N; (N + 1) / (phi V))
+    double sites[kChainMaxCand][kMaxFusedSitesWide][3];                    // candidate rows, site stride kMaxFusedSitesWide
 };
+static_assert(sizeof(BoxDev) + sizeof(ChainArgs) + 160 <= 4096, "a window must fit the kernel-argument segment");
 
+// (The topology comes through a pointer: a by-value Topo indexed by a residue type that is itself loaded -- g.t[c] -- makes
+//  the compiler copy all 664 bytes of it into every lane's scratch at kernel start: measured 4 us per window.)
 template <bool FLAT, bool FASTW>
 __global__ __launch_bounds__(kChainBlock, 1) void chain_window_kernel(
-    Topo tp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
+    const Topo *__restrict__ tpp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
     const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab, const char *__restrict__ coul_tab_g,
     const int *__restrict__ trj, const double2 *__restrict__ tw, int n_tasks, const RecipRow *__restrict__ rows, int n_rows,
-    double2 *__restrict__ A_base, ChainArgs g) {
+    double2 *__restrict__ A_base, const ChainArgs g) {
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];      // Coulomb table | phase tables | partials staging
     __shared__ double2 s_pair[kMaxTypes * kMaxTypes];
     __shared__ int4 s_grp[kMaxGrp];
@@ -1863,30 +1896,40 @@ __global__ __launch_bounds__(kChainBlock, 1) void chain_window_kernel(
     __shared__ double s_red[2 * kWavesPerBlock];
     __shared__ double s_ent[2 * 2 * kChainMaxCand];                    // reduced pair entries {lj, cc}
     __shared__ ChainResult s_res[kChainMaxCand];
+    __shared__ int s_verdict[kChainMaxCand];
     __shared__ int s_flag;
 
+    const Topo &tp = *tpp;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = g.n;
     double2 *A = A_base + (size_t)g.replica * bx.n_slots;
-    const double *cand_sites = reinterpret_cast<const double *>(g.cand) + 6;       // site a of row c: cand_sites + (c * 7 + a) * 3
+    const double *cand_sites = &g.sites[0][0][0];
+    // stage stamps (100 MHz wall clock): role 0 = the k role of candidate 0, 1 = the first pair workgroup, 2 = the resolver
+    long long *stamp = reinterpret_cast<long long *>(g.host_out + 10 * kChainMaxCand + 2);
+    const int my_role = g.stamps ? ((int)blockIdx.x == 0 ? 0 : ((int)blockIdx.x == n ? 1 : -1)) : -1;
+    auto mark = [&](int role, int i) {
+        if (tid == 0 && role >= 0) stamp[role * kChainStamps + i] = wall_clock64();
+    };
+    mark(my_role, 0);
 
     if ((int)blockIdx.x < n) {
         // ---------------- k role: candidate c
         const int c = blockIdx.x;
-        const ChainCand *cd = g.cand + c;
-        const int kind = cd->kind, link = cd->link;
-        RecipItem it{g.replica, cd->t, cd->m, kind, c, 0, 0};
+        const int kind = g.kind[c], link = g.link[c];
+        RecipItem it{g.replica, g.t[c], g.m[c], kind, c, 0, 0};
         const RecipLds v = recip_lds_view(tp, bx, it, n_rows, reinterpret_cast<double2 *>(s_dyn));
         const bool active = tid < kBlock;
-        recip_rows_tables(tp, bx, pos, res_q, rows, n_rows, it, cd->sites[0], v, tid, active);
+        recip_rows_tables(tp, bx, pos, res_q, rows, n_rows, it, &g.sites[c][0][0], v, tid, active);
+        mark(my_role, 1);
         double acc = 0.0, acc0 = 0.0;
         if (active) recip_rows_pass<false, true>(v, trj, tw, n_tasks, A, tid, acc, acc0);
         if (tid == kBlock && link != -2 && (kind == 1 || kind == 2)) {
             // ComputeIntraResidueRealCoulombEnergySingleMol of the inserted (candidate row) / deleted (resident) molecule
-            const PairItem pit{g.replica, cd->t, cd->m, kind == 1 ? c : -1, 0};
-            g.res[c].intra = intra_energy(tp, bx, pos, res_q, pit, cand_sites, 7);
+            const PairItem pit{g.replica, it.t, it.m, kind == 1 ? c : -1, 0};
+            __hip_atomic_store(&g.res[c].intra, intra_energy(tp, bx, pos, res_q, pit, cand_sites, kMaxFusedSitesWide), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
         if (active) {
             acc = wave_sum(acc);
@@ -1897,12 +1940,10 @@ __global__ __launch_bounds__(kChainBlock, 1) void chain_window_kernel(
         if (tid == 0) {
             double u = 0.0, u0 = 0.0;
             for (int wv = 0; wv < kWavesPerBlock; ++wv) { u += s_red[2 * wv]; u0 += s_red[2 * wv + 1]; }
-            ChainResult *r = g.res + c;
-            r->u_new = u * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;            // ewald_energy.f90:272
-            r->u_old = u0 * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;
-            r->u = cd->u; r->pref = cd->pref; r->self = cd->self;
-            r->t = cd->t; r->m = cd->m; r->kind = kind; r->link = link;
+            __hip_atomic_store(&g.res[c].u_new, u * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ewald_energy.f90:272
+            __hip_atomic_store(&g.res[c].u_old, u0 * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        mark(my_role, 2);
     } else {
         // ---------------- pair role: one wave per (entry, split)
         for (int i = tid; i < (bx.coul_last_row + 1) * kCoulRowVec; i += kChainBlock)
@@ -1911,23 +1952,23 @@ __global__ __launch_bounds__(kChainBlock, 1) void chain_window_kernel(
         for (int i = tid; i < nt * nt; i += kChainBlock) s_pair[i] = pair_tab[i];
         if (FLAT && tid < kMaxGrp) s_grp[tid] = make_int4(tp.grp_start[tid], tp.grp_cnt[tid], tp.grp_ty[tid], 0);
         __syncthreads();
+        mark(my_role, 1);
         const int w = ((int)blockIdx.x - n) * kPairWaves + wave;
         if (w < g.n_ent * g.nsplit) {
             const int ent = w / g.nsplit, split = w - ent * g.nsplit;
             const int c = g.ent_c[ent];
-            const ChainCand *cd = g.cand + c;
-            const int t = __builtin_amdgcn_readfirstlane(cd->t), kind = __builtin_amdgcn_readfirstlane(cd->kind);
+            const int t = g.t[c], kind = g.kind[c];
             // old state: the resident molecule; new state: the candidate row; an insertion excludes nothing
-            const PairItem it{g.replica, t, kind == 1 ? -1 : __builtin_amdgcn_readfirstlane(cd->m), g.ent_new[ent] ? c : -1, 0};
+            const PairItem it{g.replica, t, kind == 1 ? -1 : g.m[c], g.ent_new[ent] ? c : -1, 0};
             const int n1 = tp.n1[t];
 #define MGPU_CHAIN_PAIR(NS)                                                                                              \
             do {                                                                                                         \
                 if constexpr (FLAT)                                                                                      \
-                    pair_flat_item<NS, false, FASTW>(tp, bx, pos, nmol, res_q, res_atype, s_dyn, s_pair, s_grp,         \
-                                                     s_plane + wave * kFlatMaxPlanes, it, cand_sites, 7, split, g.nsplit, lane, 0, g.partials, w); \
+                    pair_flat_item<NS, false, FASTW, true>(tp, bx, pos, nmol, res_q, res_atype, s_dyn, s_pair, s_grp,         \
+                                                     s_plane + wave * kFlatMaxPlanes, it, cand_sites, kMaxFusedSitesWide, split, g.nsplit, lane, 0, g.partials, w); \
                 else                                                                                                     \
-                    pair_sweep_item<NS, false, false, false, FASTW>(tp, bx, pos, nmol, res_q, res_atype, pair_tab, s_dyn, s_pair, nullptr, \
-                                                                    nullptr, it, cand_sites, 7, split, g.nsplit, lane, g.partials, w);   \
+                    pair_sweep_item<NS, false, false, false, FASTW, true>(tp, bx, pos, nmol, res_q, res_atype, pair_tab, s_dyn, s_pair, nullptr, \
+                                                                    nullptr, it, cand_sites, kMaxFusedSitesWide, split, g.nsplit, lane, g.partials, w);   \
             } while (0)
             switch (n1) {
                 case 1: MGPU_CHAIN_PAIR(1); break;
@@ -1938,25 +1979,30 @@ __global__ __launch_bounds__(kChainBlock, 1) void chain_window_kernel(
             }
 #undef MGPU_CHAIN_PAIR
         }
+        mark(my_role, 2);
     }
 
-    // ---------------- ticket: the last workgroup to arrive resolves the window
-    __threadfence();
+    // ---------------- ticket: the last workgroup to arrive resolves the window.  Hand-off without cache-wide fences
+    // (/opt/skills/guides/MI355X_MICROARCH.md, "Valid forms": everything handed over is stored `sc1` (agent-scope,
+    // write-through), every storing wave waits for its stores, ONE lane per workgroup adds to the counter behind a
+    // workgroup barrier, and the workgroup whose add came last reads everything with `sc1` loads, its other waves behind a
+    // barrier that the adding wave joins.  An agent release + acquire pair here cost 3-4 us of an 18 us window.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    mark(my_role, 3);
     if (tid == 0) s_flag = (atomicAdd(g.ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
     __syncthreads();
     if (!s_flag) return;
-    __threadfence();
+    const int rs = g.stamps ? 2 : -1;
+    mark(rs, 0);
+    mark(rs, 1);
     // split partials of every pair entry into LDS in one round trip, then one thread per (entry, component) adds them in
     // split order -- the order trial_wait uses on the host
     {
         double *st = reinterpret_cast<double *>(s_dyn);
         const int np = g.n_ent * g.nsplit;
-        for (int i = tid; i < np; i += kChainBlock) {
-            const double2 pv = g.partials[i];
-            st[2 * i] = pv.x; st[2 * i + 1] = pv.y;
-        }
-        if (tid < n) s_res[tid] = g.res[tid];
+        for (int i = tid; i < 2 * np; i += kChainBlock) st[i] = load_sc1(reinterpret_cast<const double *>(g.partials) + i);
+        if (tid < 3 * n) reinterpret_cast<double *>(s_res)[tid] = load_sc1(reinterpret_cast<const double *>(g.res) + tid);
         __syncthreads();
         if (tid < 2 * g.n_ent) {
             const int ent = tid >> 1, comp = tid & 1;
@@ -1966,65 +2012,80 @@ __global__ __launch_bounds__(kChainBlock, 1) void chain_window_kernel(
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        int first = -1, undecided = -1;
-        for (int c = 0; c < n; ++c) {
-            const ChainResult &r = s_res[c];
-            const ChainResult &cd = r;
-            double o[5] = {0.0, 0.0, r.u_old, 0.0, 0.0}, w[5] = {0.0, 0.0, r.u_new, 0.0, 0.0};
-            if (g.ent_old_of[c] >= 0) { o[0] = s_ent[2 * g.ent_old_of[c]]; o[1] = s_ent[2 * g.ent_old_of[c] + 1]; }
-            if (g.ent_new_of[c] >= 0) { w[0] = s_ent[2 * g.ent_new_of[c]]; w[1] = s_ent[2 * g.ent_new_of[c] + 1]; }
-            if (cd.link != -2) {
-                if (cd.kind == 1) { w[3] = cd.self; w[4] = r.intra; }
-                if (cd.kind == 2) { o[3] = cd.self; o[4] = r.intra; }
-            }
-            double *ho = g.host_out + 10 * (size_t)c;
-            for (int k = 0; k < 5; ++k) { ho[k] = o[k]; ho[5 + k] = w[k]; }
-            if (cd.link == -2 || first >= 0 || undecided >= 0) continue;
+    mark(rs, 2);
+    // every step's totals and verdict by its own thread (the rule needs one exp per step); thread 0 then walks the verdicts
+    // in order: the window ends at the first accepted or undecided step
+    if (tid < n) {
+        const int c = tid;
+        const ChainResult &r = s_res[c];
+        const int kind = g.kind[c], link = g.link[c];
+        double o[5] = {0.0, 0.0, r.u_old, 0.0, 0.0}, w[5] = {0.0, 0.0, r.u_new, 0.0, 0.0};
+        if (g.ent_old_of[c] >= 0) { o[0] = s_ent[2 * g.ent_old_of[c]]; o[1] = s_ent[2 * g.ent_old_of[c] + 1]; }
+        if (g.ent_new_of[c] >= 0) { w[0] = s_ent[2 * g.ent_new_of[c]]; w[1] = s_ent[2 * g.ent_new_of[c] + 1]; }
+        if (link != -2) {
+            if (kind == 1) { w[3] = g.self_of_type[g.t[c]]; w[4] = r.intra; }
+            if (kind == 2) { o[3] = g.self_of_type[g.t[c]]; o[4] = r.intra; }
+        }
+        double *ho = g.host_out + 10 * (size_t)c;
+        for (int k = 0; k < 5; ++k) { ho[k] = o[k]; ho[5 + k] = w[k]; }
+        int verdict = 3;                                           // 0 rejected, 1 accepted, 2 undecided, 3 energy-only row
+        if (link != -2) {
             // totals as the move drivers form them (mc_chain.f90 resolve_step)
             double e_old, e_new;
-            if (cd.kind == 0) {
+            if (kind == 0) {
                 e_old = (o[0] + o[1]) + o[2];
                 e_new = (w[0] + w[1]) + w[2];
-            } else if (cd.kind == 1) {
+            } else if (kind == 1) {
                 e_old = g.e_recip;
                 e_new = (((w[0] + w[1]) + w[2]) + w[3]) + w[4];
             } else {
                 e_old = (((o[0] + o[1]) + g.e_recip) + o[3]) + o[4];
-                e_new = cd.link >= 0 ? s_res[cd.link].u_new : w[2];
+                e_new = link >= 0 ? s_res[link].u_new : w[2];
             }
-            const double x = cd.pref * exp(-(e_new - e_old) / g.temperature);
+            const double x = g.pref[c] * exp(-(e_new - e_old) / g.temperature);
             const double p = x < 1.0 ? x : 1.0;                        // min(1, x)
             // too close to call with another exp (or not a number): the host decides this step
-            if (!(x == x) || (x < 1.0 + g.margin && fabs(cd.u - x) <= g.margin * x)) { undecided = c; continue; }
-            if (cd.u <= p) first = c;
+            if (!(x == x) || (x < 1.0 + g.margin && fabs(g.u[c] - x) <= g.margin * x)) verdict = 2;
+            else verdict = g.u[c] <= p ? 1 : 0;
         }
-        int *hi = reinterpret_cast<int *>(g.host_out + 10 * (size_t)n);
+        s_verdict[c] = verdict;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int first = -1, undecided = -1;
+        for (int c = 0; c < n && first < 0 && undecided < 0; ++c) {
+            if (s_verdict[c] == 1) first = c;
+            if (s_verdict[c] == 2) undecided = c;
+        }
+        int *hi = reinterpret_cast<int *>(g.host_out + 10 * (size_t)kChainMaxCand);
         hi[0] = first;
         hi[1] = undecided;
+        mark(rs, 3);
         __threadfence_system();
         __hip_atomic_store(g.host_tag, g.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        *g.ticket = 0;
+        __hip_atomic_store(g.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_flag = first;
+        mark(rs, 4);
     }
     __syncthreads();
     const int first = s_flag;
     if (first < 0) return;
     // ---------------- commit of the accepted step by this workgroup (the stand-alone commit's arithmetic)
     {
-        const ChainResult *cd = s_res + first;
-        const bool as_written = cd->kind == 2 && cd->link >= 0;
-        const int src = as_written ? cd->link : first;
-        RecipItem it{g.replica, cd->t, cd->m, as_written ? 5 : cd->kind, src, 0, 0};
+        const bool as_written = g.kind[first] == 2 && g.link[first] >= 0;
+        const int src = as_written ? g.link[first] : first;
+        RecipItem it{g.replica, g.t[first], g.m[first], as_written ? 5 : g.kind[first], src, 0, 0};
         recip_commit_target(tp, nmol, it);
         const RecipLds v = recip_lds_view(tp, bx, it, n_rows, reinterpret_cast<double2 *>(s_dyn));
         const bool active = tid < kBlock;
-        recip_rows_tables(tp, bx, pos, res_q, rows, n_rows, it, g.cand[src].sites[0], v, tid, active);
+        recip_rows_tables(tp, bx, pos, res_q, rows, n_rows, it, &g.sites[src][0][0], v, tid, active);
+        mark(rs, 5);
         double acc = 0.0, acc0 = 0.0;
         if (active) {
             recip_rows_pass<true, false>(v, trj, tw, n_tasks, A, tid, acc, acc0);
-            recip_commit_tail(tp, pos, nmol, it, g.cand[src].sites[0], tid);
+            recip_commit_tail(tp, pos, nmol, it, &g.sites[src][0][0], tid);
         }
+        mark(rs, 6);
     }
 }
 

@@ -337,6 +337,15 @@ class Engine:
     def chain_set_margin(self, rel):
         check(self.L.mgpu_chain_set_margin(self.h, C.c_double(rel)))
 
+    def chain_set_timing(self, on=True):
+        check(self.L.mgpu_chain_set_timing(self.h, C.c_int(1 if on else 0)))
+
+    def chain_timing(self):
+        """Stage times (us) of the last window: see include/maniac_gpu.h."""
+        us = np.zeros(15)
+        check(self.L.mgpu_chain_get_timing(self.h, _d(us)))
+        return us
+
     def chain_stats(self):
         w = C.c_longlong(0); u = C.c_longlong(0)
         check(self.L.mgpu_chain_get_stats(self.h, C.byref(w), C.byref(u)))

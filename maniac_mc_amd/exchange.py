@@ -75,3 +75,49 @@ def molecule_count_histogram(counts, nbins):
     c = np.clip(np.asarray(counts, dtype=np.int64), 0, nbins - 1)
     np.add.at(h, c, 1)
     return h
+
+
+class CAbiComm:
+    """The same exchange behind the C ABI (include/maniac_gpu.h: mgpu_comm_create / mgpu_allgather_block_stats -- RCCL's
+    ncclAllGather called from libmaniac_hip.so, no torch involved): what a Fortran host links against.  One rank needs no
+    id and never initialises RCCL; with more ranks, rank 0 makes the id (CAbiComm.unique_id()) and the host passes it
+    round (bench.py --exchange c-abi broadcasts it over its torch.distributed group)."""
+
+    ID_BYTES = 128
+
+    def __init__(self, device=0, rank=0, world=1, unique_id=None):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib = C, _lib
+        self.L = _lib.lib()
+        self.h = C.c_void_p()
+        self.rank, self.world = int(rank), int(world)
+        if unique_id is not None and len(unique_id) != self.ID_BYTES:
+            raise ValueError("unique_id must be the 128 bytes CAbiComm.unique_id() returned")
+        buf = (C.c_char * self.ID_BYTES).from_buffer_copy(bytes(unique_id)) if unique_id is not None else None
+        _lib.check(self.L.mgpu_comm_create(C.byref(self.h), C.c_int(device), C.c_int(rank), C.c_int(world), buf))
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _lib
+        buf = (C.c_char * CAbiComm.ID_BYTES)()
+        _lib.check(_lib.lib().mgpu_comm_unique_id(buf))
+        return bytes(buf)
+
+    def gather_block_stats(self, sums, histogram=None):
+        """Same contract as the module-level gather_block_stats."""
+        C = self._C
+        sums = np.ascontiguousarray(sums, dtype=np.float64)
+        hist = np.zeros(0, dtype=np.int64) if histogram is None else np.ascontiguousarray(histogram, dtype=np.int64)
+        out_s = np.zeros((self.world, sums.shape[0]), dtype=np.float64)
+        out_h = np.zeros((self.world, hist.shape[0]), dtype=np.int64)
+        dp, lp = C.POINTER(C.c_double), C.POINTER(C.c_longlong)
+        self._lib.check(self.L.mgpu_allgather_block_stats(self.h, C.c_int(sums.shape[0]), sums.ctypes.data_as(dp), C.c_int(hist.shape[0]),
+                                                          hist.ctypes.data_as(lp), out_s.ctypes.data_as(dp), out_h.ctypes.data_as(lp)))
+        return out_s, (None if histogram is None else out_h)
+
+    def close(self):
+        if self.h:
+            self.L.mgpu_comm_destroy(self.h)
+            self.h = self._C.c_void_p()

@@ -292,6 +292,35 @@ module maniac_gpu
             integer(c_int), intent(out) :: first_accepted, undecided
             integer(c_int) :: rc
         end function
+        ! the path's one exchange step (RCCL all-gather of every rank's block sums and molecule-count histogram)
+        function mgpu_comm_unique_id(id128) bind(C, name="mgpu_comm_unique_id") result(rc)
+            import :: c_char, c_int
+            character(kind=c_char), intent(out) :: id128(128)
+            integer(c_int) :: rc
+        end function
+        function mgpu_comm_create(comm, device, rank, world, id128) bind(C, name="mgpu_comm_create") result(rc)
+            import :: c_ptr, c_int
+            type(c_ptr), intent(out) :: comm
+            integer(c_int), value :: device, rank, world
+            type(c_ptr), value :: id128                     ! c_null_ptr for a single rank
+            integer(c_int) :: rc
+        end function
+        function mgpu_comm_destroy(comm) bind(C, name="mgpu_comm_destroy") result(rc)
+            import :: c_ptr, c_int
+            type(c_ptr), value :: comm
+            integer(c_int) :: rc
+        end function
+        function mgpu_allgather_block_stats(comm, n_sums, sums, n_bins, hist, sums_by_rank, hist_by_rank) &
+                bind(C, name="mgpu_allgather_block_stats") result(rc)
+            import :: c_ptr, c_int, c_double, c_long_long
+            type(c_ptr), value :: comm
+            integer(c_int), value :: n_sums, n_bins
+            real(c_double), intent(in) :: sums(*)
+            integer(c_long_long), intent(in) :: hist(*)
+            real(c_double), intent(out) :: sums_by_rank(*)
+            integer(c_long_long), intent(out) :: hist_by_rank(*)
+            integer(c_int) :: rc
+        end function
         function mgpu_synchronize(e) bind(C, name="mgpu_synchronize") result(rc)
             import :: c_ptr, c_int
             type(c_ptr), value :: e

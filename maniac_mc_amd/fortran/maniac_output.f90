@@ -27,11 +27,25 @@ module maniac_output
     public :: residue_block, box_block, chain_block
     public :: log_line, log_box_line, log_rule, log_start_mc, log_status, log_final_report
     public :: write_trajectory, write_energy_and_count, write_topology, update_files, wrap_into_box
-    public :: KB_KCALMOL_OUT, BOX_WIDTH
+    public :: KB_KCALMOL_OUT, BOX_WIDTH, mout_format_fixed
 
     integer, parameter :: BOX_WIDTH = 78                                  ! src/parameters.f90:25
     real(real64), parameter :: KB_KCALMOL_OUT = 0.0019872041_real64       ! src/constants.f90 KB_kcalmol
     character(len=*), parameter :: TOPOLOGY_NAME = 'topology.data'        ! src/parameters.f90:32
+
+    interface
+        ! include/maniac_gpu.h: the atom records of the two big files, formatted outside the Fortran runtime (same bytes)
+        function mgpu_append_atom_records(path, n, first_serial, mol, atype, charge, xyz) &
+                bind(C, name="mgpu_append_atom_records") result(rc)
+            import :: c_char, c_int, c_ptr, c_double
+            character(kind=c_char), intent(in) :: path(*)
+            integer(c_int), value :: n, first_serial
+            type(c_ptr), value :: mol, charge               ! c_null_ptr: trajectory records
+            integer(c_int), intent(in) :: atype(*)
+            real(c_double), intent(in) :: xyz(3, *)
+            integer(c_int) :: rc
+        end function
+    end interface
 
     ! energy components, in the order of type(energy_state) as the writers print them
     integer, parameter, public :: IE_NONC = 1, IE_COUL = 2, IE_RECIP = 3, IE_SELF = 4, IE_INTRA = 5, IE_TOTAL = 6
@@ -79,6 +93,24 @@ module maniac_output
     end type chain_block
 
 contains
+
+    ! Test hook: x(i) through the Fortran runtime's Fw.d editing, w characters each, into out -- what
+    ! mgpu_append_atom_records' own conversion must reproduce byte for byte (tests/test_host_setup.py)
+    subroutine mout_format_fixed(n, x, w, d, out) bind(C, name="mout_format_fixed")
+        integer(c_int), value :: n, w, d
+        real(c_double), intent(in) :: x(n)
+        character(kind=c_char), intent(out) :: out(w, n)
+        character(len=32) :: fmt
+        character(len=64) :: field
+        integer :: i, k
+        write(fmt, '(A,I0,A,I0,A)') '(F', w, '.', d, ')'
+        do i = 1, n
+            write(field, fmt) x(i)
+            do k = 1, w
+                out(k, i) = field(k:k)
+            end do
+        end do
+    end subroutine mout_format_fixed
 
     !---------------------------------------------------------------------------
     ! log.maniac
@@ -227,8 +259,10 @@ contains
         character(*), intent(in) :: filename
         logical, intent(in) :: append
         integer, parameter :: u = 18
-        integer :: t, m, a, serial
+        integer :: t, m, a, serial, i
         real(real64) :: com(3), pos(3)
+        integer(c_int), allocatable :: ty(:)
+        real(real64), allocatable :: xyz(:, :)
 
         if (append) then
             open(unit=u, file=trim(ch%outdir) // filename, status='unknown', action='write', position='append')
@@ -246,6 +280,11 @@ contains
         write(u, '(A)') 'ITEM: ATOMS id type x y z'
         serial = 0
         do t = 1, ch%n_res
+            serial = serial + res(t)%count * ch%res(t)%n1
+        end do
+        allocate(ty(serial), xyz(3, serial))
+        serial = 0
+        do t = 1, ch%n_res
             do m = 1, res(t)%count
                 com = res(t)%com(:, m)
                 if (ch%res(t)%active == 1) call wrap_into_box(com, box)     ! active molecules: wrap the COM
@@ -253,11 +292,22 @@ contains
                     serial = serial + 1
                     pos = com + res(t)%off(:, a, m)
                     if (ch%res(t)%active == 0) call wrap_into_box(pos, box)  ! inactive structure: wrap every atom
-                    write(u, '(I6,1X,I4,3(1X,F12.7))') serial, ch%res(t)%atom_type(a), pos(1), pos(2), pos(3)
+                    ty(serial) = ch%res(t)%atom_type(a)
+                    xyz(:, serial) = pos
                 end do
             end do
         end do
+        ! the atom records (write_utils.f90:86's edit descriptors) are appended by the engine library's exact formatter: the
+        ! runtime's Fw.d conversion costs 8 ms per frame at 10 125 atoms; should that fail, by one formatted write here
         close(u)
+        if (serial > 0) then
+            if (mgpu_append_atom_records(trim(ch%outdir) // filename // c_null_char, int(serial, c_int), 1_c_int, c_null_ptr, ty, &
+                                         c_null_ptr, xyz) /= 0) then
+                open(unit=u, file=trim(ch%outdir) // filename, status='old', action='write', position='append')
+                write(u, '((I6,1X,I4,3(1X,F12.7)))') (i, ty(i), xyz(1, i), xyz(2, i), xyz(3, i), i = 1, serial)
+                close(u)
+            end if
+        end if
     end subroutine write_trajectory
 
     !---------------------------------------------------------------------------
@@ -313,8 +363,12 @@ contains
         type(chain_block), intent(in) :: ch
         integer, parameter :: u = 19
         character(len=9), parameter :: section(4) = [character(len=9) :: 'Bonds', 'Angles', 'Dihedrals', 'Impropers']
-        integer :: t, m, a, k, kind, serial, mol, total(4), first_atom, n_members, c
+        integer :: t, m, a, k, kind, serial, mol, total(4), first_atom, n_members, c, i
         real(real64) :: pos(3)
+        integer(c_int), allocatable, target :: mols(:)
+        integer(c_int), allocatable :: tys(:)
+        real(real64), allocatable, target :: qs(:)
+        real(real64), allocatable :: xyz(:, :)
 
         total = 0
         do t = 1, ch%n_res
@@ -354,6 +408,11 @@ contains
         write(u, *) 'Atoms'
         write(u, *)
         serial = 0
+        do t = 1, ch%n_res
+            serial = serial + ch%res(t)%count * ch%res(t)%n1
+        end do
+        allocate(mols(serial), tys(serial), qs(serial), xyz(3, serial))
+        serial = 0
         mol = 0
         do t = 1, ch%n_res
             do m = 1, ch%res(t)%count
@@ -363,11 +422,25 @@ contains
                     pos = ch%res(t)%com(:, m) + ch%res(t)%off(:, a, m)
                     ! active molecules stay whole across the boundary; only the inactive structure is wrapped
                     if (ch%res(t)%active == 0) call wrap_into_box(pos, ch%box)
-                    write(u, '(I6,1X,I6,1X,I4,1X,F12.8,3(1X,F12.7))') serial, mol, ch%res(t)%atom_type(a), &
-                        ch%res(t)%charge(a), pos(1), pos(2), pos(3)
+                    mols(serial) = mol
+                    tys(serial) = ch%res(t)%atom_type(a)
+                    qs(serial) = ch%res(t)%charge(a)
+                    xyz(:, serial) = pos
                 end do
             end do
         end do
+        ! the section's records (write_utils.f90:297-300's edit descriptors) by the engine library's exact formatter, as in
+        ! write_trajectory; the unit is closed around the append and reopened for the sections that follow
+        if (serial > 0) then
+            close(u)
+            if (mgpu_append_atom_records(trim(ch%outdir) // TOPOLOGY_NAME // c_null_char, int(serial, c_int), 1_c_int, c_loc(mols), tys, &
+                                         c_loc(qs), xyz) /= 0) then
+                open(unit=u, file=trim(ch%outdir) // TOPOLOGY_NAME, status='old', action='write', position='append')
+                write(u, '((I6,1X,I6,1X,I4,1X,F12.8,3(1X,F12.7)))') (i, mols(i), tys(i), qs(i), xyz(1, i), xyz(2, i), xyz(3, i), i = 1, serial)
+            else
+                open(unit=u, file=trim(ch%outdir) // TOPOLOGY_NAME, status='old', action='write', position='append')
+            end if
+        end if
 
         do kind = 1, 4
             ! primary%num_bonds > 0 .or. reservoir%num_bonds > 0 (write_utils.f90:336), the primary count being

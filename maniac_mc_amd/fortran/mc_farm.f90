@@ -47,7 +47,7 @@ module mc_farm
     private
     public :: mfarm_create, mfarm_run, mfarm_destroy, mfarm_get_energy, mfarm_get_molecule, mfarm_recalibrate
     public :: mfarm_get_timers, mfarm_set_gcmc, mfarm_get_counts, mfarm_get_counters, mfarm_set_triclinic
-    public :: mfarm_rng_sample, mfarm_set_drivers, mfarm_configure, mfarm_select
+    public :: mfarm_rng_sample, mfarm_set_drivers, mfarm_configure, mfarm_select, mfarm_exchange_block
 
     real(real64), parameter :: PI = 3.14159265358979323846_real64
     real(real64), parameter :: TWOPI = 2.0_real64 * PI
@@ -352,6 +352,37 @@ contains
         F%fugacity = fugacity
         F%gcmc = .true.
     end function mfarm_set_gcmc
+
+    ! The one exchange step of a farm of replicas spread over the GPUs of a node (SURVEY 8(e)): at a block's end every rank
+    ! contributes {moves accepted, trials} so far and, per active residue type, the histogram of its chains' molecule counts
+    ! -- what the reference records per chain in number_<res>.dat (src/write_utils.f90:144-150) -- and receives the
+    ! rank-ordered tables: sums_by_rank(2, world), hist_by_rank(n_bins, n_active, world).  `comm` comes from
+    ! mgpu_comm_create (one rank: the identity, no RCCL).  Counts beyond the last bin land in it.
+    function mfarm_exchange_block(comm, n_bins, world, sums_by_rank, hist_by_rank) bind(C, name="mfarm_exchange_block") result(rc)
+        type(c_ptr), value :: comm
+        integer(c_int), value :: n_bins, world
+        real(c_double), intent(out) :: sums_by_rank(2, world)
+        integer(c_long_long), intent(out) :: hist_by_rank(n_bins, F%n_active, world)
+        integer(c_int) :: rc
+        integer(c_long_long), allocatable :: hist(:, :)
+        real(c_double) :: sums(2)
+        integer :: r, ia, b
+        rc = MGPU_OK
+        if (.not. F%ready .or. n_bins < 1 .or. world < 1) then
+            rc = 1
+            return
+        end if
+        allocate(hist(n_bins, F%n_active))
+        hist = 0
+        do r = 1, F%n_replicas
+            do ia = 1, F%n_active
+                b = min(max(F%cnt(ia, r), 0), n_bins - 1) + 1
+                hist(b, ia) = hist(b, ia) + 1
+            end do
+        end do
+        sums = [real(F%accepted, c_double), real(F%trials, c_double)]
+        rc = mgpu_allgather_block_stats(comm, 2_c_int, sums, int(n_bins * F%n_active, c_int), hist, sums_by_rank, hist_by_rank)
+    end function mfarm_exchange_block
 
     subroutine alloc_lane(L, n, max_n1, g)
         type(lane_buffers), intent(inout), target :: L

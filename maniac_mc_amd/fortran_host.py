@@ -201,6 +201,19 @@ class FortranFarm:
         self.H.mfarm_get_counts(c.ctypes.data_as(_ip))
         return c
 
+    def exchange_block(self, comm, n_bins=5001):
+        """mfarm_exchange_block: every rank's {accepted, trials} and per-active-type histogram of its chains' molecule
+        counts through the C-ABI communicator `comm` (exchange.CAbiComm).  Returns (sums[world, 2], hist[world, n_active,
+        n_bins])."""
+        self._select()
+        sums = np.zeros((comm.world, 2))
+        hist = np.zeros((comm.world, self.n_active, n_bins), dtype=np.int64)
+        self.H.mfarm_exchange_block.restype = C.c_int
+        rc = self.H.mfarm_exchange_block(comm.h, C.c_int(n_bins), C.c_int(comm.world), sums.ctypes.data_as(_dp),
+                                         hist.ctypes.data_as(C.POINTER(C.c_longlong)))
+        _lib.check(rc)
+        return sums, hist
+
     def energy(self, replica: int):
         e = np.zeros(5)
         self._select()

@@ -67,7 +67,7 @@ def header_text(inp, dat, maniac_path, data_path, inc_path, eng_or_ewald, reserv
 
 
 def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoir_path=None, device=0,
-                   mol_capacity=None, nb_block=None, nb_step=None, seams=False, as_written=False, speculate=8,
+                   mol_capacity=None, nb_block=None, nb_step=None, seams=False, as_written=False, speculate=4,
                    chain_windows=True):
     """Run the chain; returns a dict with the final energies (K), counters, molecule counts, step sizes.
 
@@ -79,7 +79,8 @@ def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoi
     ``as_written``: True -> the reference's deletion update exactly as written (A(k) gains the swapped-in
     molecule's terms, monte_carlo_utils.f90:308), composed in the host loop from neutral engine primitives; for
     charged grand-canonical runs this reproduces the reference's files but not the intended physics (default False).
-    ``speculate``: K > 1 (default 8; batched mode only) -> the next K steps are drawn in the reference's random-number
+    ``speculate``: K > 1 (default 4 -- measured best with one launch per window, where a longer window costs more than the
+    steps it saves; batched mode only) -> the next K steps are drawn in the reference's random-number
     order assuming every one is rejected and evaluated in ONE engine call; the first accepted one is applied, the
     generator is put back to its state after that step and the rest is redrawn.  Same states, same files, up to
     1 / acceptance fewer round trips.  1 -> one step per engine call.
@@ -187,7 +188,7 @@ def main(argv=None):
     ap.add_argument("-o", dest="out", default="outputs/", help="output directory")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--speculate", type=int, default=8,
+    ap.add_argument("--speculate", type=int, default=4,
                     help="speculative window: steps evaluated per engine call (same states and files; 1: one step per call)")
     ap.add_argument("--no-chain-windows", action="store_true",
                     help="evaluate windows through the batched submit / wait calls instead of the one-launch path")

@@ -792,7 +792,7 @@ def test_a_committed_framework_move_switches_the_batch_kernel_off():
     the commit the engine with the batch kernel must give what the engine without it gives (MGPU_NO_FROZEN_BATCH=1) --
     and the moved framework must be felt."""
     import os
-    s = synth.framework_water_box(n_water=12, n_frame=200, L=22.0, seed=6)
+    s = synth.framework_water_box(n_water=12, n_frame=72, L=20.0, seed=6)      # (a commit's phase tables limit n1 to ~85 sites)
     engines = []
     for nobatch in (False, True):
         if nobatch:
@@ -812,7 +812,7 @@ def test_a_committed_framework_move_switches_the_batch_kernel_off():
     tt = np.ones(k, np.int32)
     kinds = np.full(k, MGPU_MOVE, np.int32)
     before = [e.gcmc_trial(rep, tt, m, kinds, cand) for e in engines]
-    frame = s.all_sites(0).copy()                         # (1, 200, 3): the framework is one molecule of type 0
+    frame = s.all_sites(0).copy()                         # (1, 72, 3): the framework is one molecule of type 0
     frame[0, 17] += np.array([0.4, -0.3, 0.2])
     for which, target in ((1, 1), (0, 0)):                # first a replica other than 0, then the reference copy itself
         for e in engines:

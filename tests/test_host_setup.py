@@ -182,3 +182,54 @@ def test_oracle_all_core_trial_farm_runs_the_same_trial(refcpu_mod):
     el, tr, ac = refcpu_mod.trial_farm(synth.spce_box(5, seed=2), 2, 2, 0.6, 0.3, 0.3)     # one chain per thread
     assert 0.5 < el < 5.0 and tr.shape == (2,) and np.all(tr > 20) and np.all(ac <= tr)
     assert 0.4 < ac.sum() / tr.sum() < 0.95
+
+
+def test_atom_record_formatter_is_the_fortran_runtimes(tmp_path):
+    """mgpu_append_atom_records formats the atom records of trajectory.lammpstrj / topology.data outside the Fortran
+    runtime (whose Fw.d conversion dominated a single chain's run time at 10 125 atoms).  Its conversion is exact --
+    integer mantissa x 10^d in 128-bit arithmetic, round half to even -- and must be the runtime's bytes: random values
+    over twenty decades, exact ties of the last printed digit, signed zeros, values that round up into the next width and
+    values that overflow it (asterisks), in the three widths the writers use (src/write_utils.f90:86, :297-300)."""
+    import ctypes as C
+    import shutil
+    if not shutil.which("amdflang"):
+        pytest.skip("needs the Fortran runtime (amdflang) to compare with")
+    from maniac_mc_amd import _lib, fortran_host
+    L, H = _lib.lib(), fortran_host.lib()
+    rng = np.random.default_rng(0)
+    x = np.concatenate([
+        rng.uniform(-1, 1, 60000) * 10.0 ** rng.integers(-12, 8, 60000),
+        rng.integers(-4000000, 4000000, 20000) / 256.0, rng.integers(-4000000, 4000000, 20000) / 512.0,      # ties of F12.7 / F12.8
+        rng.integers(-400, 400, 2000) / 256.0 * 1e-3,
+        [0.0, -0.0, 1e-9, -1e-9, 5e-8, -5e-8, 4.9999999e-8, 0.5, -0.5, 999.99999995, 9999.99999995, -999.99999995, 9999.9999999,
+         -999.9999999, 99999.0, 123456.7891234, 1e15, -1e15, 1e300, 4.5e15, 2.0 ** 52, 2.0 ** 53, 1e-300, 5e-324],
+    ])
+    n = len(x)
+    dp = C.POINTER(C.c_double)
+    for w, d in ((12, 7), (12, 8), (15, 8)):
+        mine = C.create_string_buffer(n * w)
+        ref = C.create_string_buffer(n * w)
+        _lib.check(L.mgpu_format_fixed(C.c_int(n), x.ctypes.data_as(dp), C.c_int(w), C.c_int(d), mine))
+        H.mout_format_fixed(C.c_int(n), x.ctypes.data_as(dp), C.c_int(w), C.c_int(d), ref)
+        a = np.frombuffer(mine.raw, dtype=f"S{w}")
+        b = np.frombuffer(ref.raw, dtype=f"S{w}")
+        bad = np.flatnonzero(a != b)
+        assert len(bad) == 0, [(x[i], a[i], b[i]) for i in bad[:10]]
+    # ... and whole records, both layouts, against formatted writes of the same numbers
+    m = 500
+    xyz = np.ascontiguousarray(rng.uniform(-40, 40, (m, 3)))
+    ty = rng.integers(1, 12, m).astype(np.int32)
+    mol = rng.integers(1, 4000, m).astype(np.int32)
+    q = np.ascontiguousarray(rng.uniform(-1.2, 1.2, m))
+    ip = C.POINTER(C.c_int)
+    p1, p2 = str(tmp_path / "traj"), str(tmp_path / "topo")
+    open(p1, "w").write("HEADER\n")
+    _lib.check(L.mgpu_append_atom_records(p1.encode(), C.c_int(m), C.c_int(1), None, ty.ctypes.data_as(ip), None, xyz.ctypes.data_as(dp)))
+    _lib.check(L.mgpu_append_atom_records(p2.encode(), C.c_int(m), C.c_int(7), mol.ctypes.data_as(ip), ty.ctypes.data_as(ip),
+                                          q.ctypes.data_as(dp), xyz.ctypes.data_as(dp)))
+    want1 = "HEADER\n" + "".join("%6d %4d %12.7f %12.7f %12.7f\n" % (i + 1, ty[i], *xyz[i]) for i in range(m))
+    want2 = "".join("%6d %6d %4d %12.8f %12.7f %12.7f %12.7f\n" % (i + 7, mol[i], ty[i], q[i], *xyz[i]) for i in range(m))
+    assert open(p1).read() == want1 and open(p2).read() == want2
+    bad = xyz.copy(); bad[3, 1] = np.nan
+    assert L.mgpu_append_atom_records(p1.encode(), C.c_int(m), C.c_int(1), None, ty.ctypes.data_as(ip), None, bad.ctypes.data_as(dp)) != 0
+    assert open(p1).read() == want1                       # nothing was written by the failed call

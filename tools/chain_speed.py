@@ -24,7 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--blocks", type=int, default=4)
     ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--ks", default="1,4,8,16")
+    ap.add_argument("--ks", default="1,2,4,8")
     ap.add_argument("--cases", default="co2_gcmc,framework_water_gcmc,spce_10125_nvt")
     ap.add_argument("--chain-windows", type=int, default=1, help="0: batched submit / wait calls instead of one launch per window")
     a = ap.parse_args()
