@@ -68,7 +68,7 @@ def header_text(inp, dat, maniac_path, data_path, inc_path, eng_or_ewald, reserv
 
 def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoir_path=None, device=0,
                    mol_capacity=None, nb_block=None, nb_step=None, seams=False, as_written=False, speculate=4,
-                   chain_windows=True):
+                   chain_windows=True, chain_margin=None):
     """Run the chain; returns a dict with the final energies (K), counters, molecule counts, step sizes.
 
     ``seed``: None -> the input file's ``seed`` if present, else the generator is left unseeded
@@ -88,6 +88,8 @@ def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoi
     evaluates its steps, applies the acceptance rule to them in order with the loop's own draws and commits the first
     accepted one, leaving to the loop only the steps too close to call; where the engine cannot (triclinic box, molecules
     of more than five sites) the loop falls back to the batched calls by itself.  False -> the batched calls always.
+    ``chain_margin``: relative width of the band around an acceptance probability inside which the engine leaves the step to
+    this loop's own exp (default: the engine's 16 ulp; tests widen it to drive the loop's side of that hand-over).
     """
     system, inp, dat = io_maniac.load_system(maniac_path, data_path, inc_path, with_data=True)
     rdat = io_maniac.read_lammps_data(reservoir_path, inp) if reservoir_path else None
@@ -96,6 +98,8 @@ def run_simulation(maniac_path, data_path, inc_path, outdir, seed=None, reservoi
     if mol_capacity is None:
         mol_capacity = [NB_MAX_MOLECULE if topo.is_active[t] == 1 else max(1, int(system.n_mol[t])) for t in range(n_res)]
     eng = Engine.from_system(system, n_replicas=1, device=device, mol_capacity=mol_capacity)
+    if chain_margin is not None:
+        eng.chain_set_margin(float(chain_margin))
     H = fortran_host.lib()
     H.mchain_run.restype = C.c_int
     try:

@@ -73,3 +73,30 @@ def test_isotherm_two_gloo_ranks_on_one_gpu_histogram_matches_rank_counts(tmp_pa
         assert row["N_min"] == min(counts[p]) and row["N_max"] == max(counts[p])
     # uptake grows with fugacity (8x in fugacity from the first to the last point)
     assert d["isotherm"][-1]["mean_N"] > d["isotherm"][0]["mean_N"]
+
+
+@pytest.mark.gpu
+def test_default_line_carries_the_other_configs_the_chain_count_curve_and_both_baselines():
+    """The driver's command shape (`bench.py --gpus 1 --steps K --warmup W`, nothing else): ONE JSON line with the headline
+    metric, `roofline`, `cpu_baseline`, and -- round 4 -- `configs` (BASELINE.json configs[2]-[4] as short legs with their own
+    roofline and CPU baseline), `replicas_sweep` and `single_chain`.  Short legs here; the structure is what is checked."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "5", "--warmup", "2", "--settle-s", "0", "--sustained-steps", "0",
+                          "--config-steps", "40", "--sweep-seconds", "0.05", "--replicas-sweep", "1,64", "--cpu-budget", "0.5",
+                          "--cpu-all-cores-budget", "0", "--configs", "1"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["metric"] == "MC moves/sec" and d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["dtype"] == "f64"
+    assert d["value"] > 1e5 and d["config"]["workload"].startswith("spce_3375mol_10125atoms")
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and 0 < d["roofline"]["frac"] < 1
+    assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
+    assert set(d["configs"]) == {"co2_gcmc", "framework_water", "co2_isotherm"}
+    for name, leg in d["configs"].items():
+        assert "error" not in leg, (name, leg)
+        assert leg["value"] > 1e5 and leg["steps"] == 40 and leg["roofline"]["frac"] is not None and leg["roofline"]["basis"]
+        assert leg["cpu_baseline"]["value"] > 0
+    assert [r["replicas"] for r in d["replicas_sweep"]] == [1, 64] and all(r["value"] > 0 for r in d["replicas_sweep"])
+    assert d["single_chain"]["value"] > 0 and d["single_chain"]["windows"] > 0

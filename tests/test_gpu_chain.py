@@ -273,3 +273,37 @@ def test_chain_loop_modes_write_the_same_files(tmp_path):
             for f in sorted(os.listdir(outs[0])):
                 if f != "log.maniac":
                     assert filecmp.cmp(os.path.join(o, f), os.path.join(outs[0], f), shallow=False), (case, o, f)
+
+
+@pytest.mark.parametrize("margin", [0.2, 1e300], ids=["a_fifth_of_the_steps", "every_step"])
+@pytest.mark.parametrize("case", ["co2_gcmc", "dumbbell_gcmc_reservoir", "spce_nvt"])
+def test_steps_left_to_the_host_still_write_the_reference_files(case, margin, tmp_path):
+    """The loop's side of the hand-over: with the engine's margin widened, a fifth of the steps -- or every one -- come back
+    undecided; the loop then applies the rule itself, commits an accepted step with explicit sites (or, for the as-written
+    deletion, through the neutral primitives), ends the window there and puts the generator back.  The files must still be
+    the reference's, character for character."""
+    import json
+    import os
+    from maniac_mc_amd import run
+    from tests.util import GOLDEN
+    runs = os.path.join(GOLDEN, "runs")
+    summary = json.load(open(os.path.join(runs, "summary.json")))
+    inputs = os.path.join(runs, case, "inputs")
+    expected = os.path.join(runs, case, "expected")
+    out = str(tmp_path / "out") + "/"
+    cwd = os.getcwd()
+    os.chdir(inputs)
+    try:
+        res = run.run_simulation("system.maniac", "system.data", "system.inc", out, seed=summary[case]["seed"],
+                                 reservoir_path="reservoir.data" if summary[case]["reservoir"] else None,
+                                 as_written=bool(summary[case].get("as_written")), chain_margin=margin)
+    finally:
+        os.chdir(cwd)
+    windows, undecided = res["chain_windows"]
+    assert windows > 0 and undecided > (0.05 * windows if margin < 1 else 0.99 * windows)
+    for f in summary[case]["files"]:
+        want = open(os.path.join(expected, f)).read().split("\n")
+        got = open(os.path.join(out, f)).read().split("\n")
+        if f == "log.maniac":
+            got = ["<output path>" if out.rstrip("/") in ln else ln for ln in got]
+        assert got == want, f

@@ -18,18 +18,6 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "maniac_mc_amd", "csrc", "mgpu_engine.hip")
 
-CLASSES = [
-    ("separation  v_add_f64 (xj - rx ...)", lambda i, ops: i.startswith("v_add_f64") and "|" not in ops and "s[" not in ops and "v[38:39]" not in ops),
-    ("fold        v_add_f64 L - |d|, v_min_f64", lambda i, ops: (i.startswith("v_add_f64") and "|" in ops) or i.startswith("v_min_f64")),
-    ("r^2         v_mul_f64 / v_fmac_f64 (squares)", None),       # filled by the dependency walk below
-    ("table index v_ashrrev / v_subrev / v_min_u32 / v_mad_u32_u24 / v_and_b32", lambda i, ops: i.split("_e")[0] in (
-        "v_ashrrev_i32", "v_subrev_u32", "v_min_u32", "v_mad_u32_u24", "v_and_b32", "v_bfe_u32", "v_lshl_add_u32", "v_sub_u32", "v_lshrrev_b32")),
-    ("below-table test  v_or_b32 / v_or3_b32 / v_cmp", lambda i, ops: i.startswith("v_or") or i.startswith("v_cmp") or i.startswith("v_min3")),
-    ("conversion  v_cvt_f64_f32", lambda i, ops: i.startswith("v_cvt_f64_f32")),
-    ("LDS         ds_read_b128", lambda i, ops: i.startswith("ds_read")),
-]
-
-
 def main():
     args = sys.argv[1:]
     want = "pair_sweep_kernelILi3ELb0ELb0ELb1ELb1E"
@@ -81,17 +69,23 @@ def main():
 
     def bump(k):
         counts[k] = counts.get(k, 0) + 1
+    masked = set()                      # VGPRs holding the high word of a row start (s with its low mantissa bits cleared)
     for i in body:
         op = i.split()[0]
         ops = i[len(op):]
         base = re.sub(r"_e(32|64)$", "", op)
+        if base == "v_and_b32":
+            m = re.match(r"\s*v(\d+),", ops)
+            if m:
+                masked.add(int(m.group(1)))
         if base in ("v_add_f64",):
+            m = re.search(r"-v\[(\d+):(\d+)\]\s*$", ops)
             if "|" in ops:
                 bump("fold: L - |d|            v_add_f64 s, -|v|")
-            elif "v[38:39]" in ops or re.search(r"-v\[\d+:\d+\]\s*$", ops) and False:
+            elif m and int(m.group(2)) in masked:
                 bump("table: t = s - s_row     v_add_f64")
             else:
-                bump("v_add_f64 (separations xj - rx, and t = s - s_row)")
+                bump("separation: xj - rx ...  v_add_f64")
         elif base == "v_min_f64":
             bump("fold: min(|d|, L - |d|)  v_min_f64")
         elif base in ("v_mul_f64",):
@@ -119,6 +113,17 @@ def main():
     for k, v in sorted(counts.items(), key=lambda kv: -kv[1]):
         print(f"| {k} | {v} | {v / max(1, terms):.2f} |")
     print(f"| **VALU total** | {valu} | **{valu / max(1, terms):.2f}** |\n")
+    # the rest of one loop iteration: the blocks from the hot one to the back edge
+    hi = blocks.index(hot)
+    print("## the loop around it (blocks up to the back edge; VALU / SALU / memory instructions, and how each ends)\n")
+    print("| block | instructions | VALU | SALU | memory | ends with |\n|---|---|---|---|---|---|")
+    for b in blocks[hi:hi + 48]:
+        br = [i for i in b[1] if "branch" in i]
+        print(f"| {b[0]} | {len(b[1])} | {sum(1 for i in b[1] if i.startswith('v_'))} | {sum(1 for i in b[1] if i.startswith('s_'))} | "
+              f"{sum(1 for i in b[1] if i.startswith(('global_', 'scratch_', 'ds_', 'buffer_')))} | {'; '.join(br[-2:]) if br else 'falls through'} |")
+        if any(hot[0] in i for i in br):
+            break
+    print()
     print("## the block\n")
     for i in body:
         print("    " + i)
