@@ -428,6 +428,12 @@ int mgpu_append_atom_records(const char *path, int n, int first_serial, const in
                              const double *xyz);
 int mgpu_format_fixed(int n, const double *x, int w, int d, char *out);
 
+/* Test and diagnostic hook: exp(i k theta) = (cos, sin)(k * theta) exactly as the device's phase tables hold it -- the
+ * reference's ComputePhaseFactors1D, src/ewald_phase.f90:100-109, dcos / dsin of the rounded product.  The device
+ * evaluates it with its own bounded-argument routine (|k theta| < 2^30, within 1.5 ulp of the exact value:
+ * tests/test_gpu_parity.py::test_phase_factors_are_within_two_ulp).  Host arrays of n entries; synchronous. */
+int mgpu_phase_factors(mgpu_engine *e, int n, const double *theta, const int *k, double *cos_out, double *sin_out);
+
 /* ------------------------------------------------------------------------------------------
  * Measurement
  * ---------------------------------------------------------------------------------------- */

@@ -608,7 +608,7 @@ size_t recip_lds_bytes(const mgpu_engine *e, int n1_max) {
 }
 
 size_t recip_rows_lds_bytes(const mgpu_engine *e, int n1_max) {
-    return recip_lds_bytes(e, n1_max) + (size_t)e->n_rrows * (2 * n1_max * sizeof(double2) + sizeof(RecipRow));
+    return recip_lds_bytes(e, n1_max) + (size_t)e->n_rrows * (2 * n1_max * sizeof(double2));
 }
 
 // d_u_old != nullptr: also return the energy of the unchanged A(k) from the same pass (trial moves)
@@ -2421,6 +2421,34 @@ int mgpu_system_energy(mgpu_engine *e, int replica, double out[6]) {
     }
     out[0] = e_nc; out[1] = e_c; out[2] = e_recip; out[3] = e_self; out[4] = e_intra;
     out[5] = e_recip + e_nc + e_c + e_self + e_intra;  // energy_utils.f90:32-33
+    return MGPU_OK;
+}
+
+// ---- test hook --------------------------------------------------------------------------------
+
+int mgpu_phase_factors(mgpu_engine *e, int n, const double *theta, const int *k, double *cos_out, double *sin_out) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    if (n < 0 || (n > 0 && (!theta || !k || !cos_out || !sin_out))) return set_error(MGPU_ERR_INVALID_ARG, "mgpu_phase_factors: bad arguments");
+    if (n == 0) return MGPU_OK;
+    int rc = use_device(e);
+    if (rc) return rc;
+    double *d_theta = nullptr;
+    int *d_k = nullptr;
+    double2 *d_out = nullptr;
+    std::vector<double2> h((size_t)n);
+    hipError_t err = hipMalloc(&d_theta, (size_t)n * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc(&d_k, (size_t)n * sizeof(int));
+    if (err == hipSuccess) err = hipMalloc(&d_out, (size_t)n * sizeof(double2));
+    if (err == hipSuccess) err = hipMemcpy(d_theta, theta, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(d_k, k, (size_t)n * sizeof(int), hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        phase_factors_kernel<<<(n + 255) / 256, 256>>>(n, d_theta, d_k, d_out);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipMemcpy(h.data(), d_out, (size_t)n * sizeof(double2), hipMemcpyDeviceToHost);
+    (void)hipFree(d_theta); (void)hipFree(d_k); (void)hipFree(d_out);
+    if (err != hipSuccess) return set_error(MGPU_ERR_HIP, hipGetErrorString(err));
+    for (int i = 0; i < n; ++i) { cos_out[i] = h[i].x; sin_out[i] = h[i].y; }
     return MGPU_OK;
 }
 

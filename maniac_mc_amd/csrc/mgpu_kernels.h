@@ -257,6 +257,9 @@ __device__ __forceinline__ void pair_term(double dx, double dy, double dz, const
     if (do_c) {
         unsigned sh;
         double g = coul_lds(r2, coul_tab_adjusted(coul_tab, bx.coul_idx_base), sh);
+        // (this generic path also serves triclinic boxes, where a site more than a cell outside the box can give an r^2
+        //  beyond the table: such a lookup is discarded -- the all-zero last row's value -- as the clamped index gave it)
+        if (sh >= (unsigned)(bx.coul_idx_base + bx.coul_last_row)) g = 0.0;
         if (sh < (unsigned)bx.coul_idx_base) g = coul_slow(r2, bx.alpha, GUARD_R0);
         ec += qq * g;
     }
@@ -396,11 +399,19 @@ __device__ __forceinline__ void pair_sweep_item(
                         int m2 = cc * 64 + lane;
                         ok = true;
                         if (special) {
+                            // (a real scalar branch: the empty asm keeps the compiler from turning the rare masked unit
+                            //  into selects that every ordinary unit would pay for)
+                            asm volatile("" ::: "memory");
                             ok = m2 < nm;
                             if (excl) ok = ok && (ORDERED ? (m2 > it.m) : (m2 != it.m));
                             m2 = ok ? m2 : dummy_m;
                         }
-                        x = pxp[m2]; y = pyp[m2]; z = pzp[m2];
+                        // one 32-bit byte offset serves the three loads (scalar plane bases + a VGPR offset: no 64-bit address
+                        // arithmetic per lane; a plane is far shorter than 4 GB)
+                        const unsigned ob = (unsigned)m2 * 8u;
+                        x = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(pxp) + ob);
+                        y = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(pyp) + ob);
+                        z = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(pzp) + ob);
                     };
                     double acc[NREG];
 #pragma unroll
@@ -1126,12 +1137,52 @@ __device__ __forceinline__ double atom_phase(const BoxDev &bx, int axis, double 
     return kTwoPi * acc;
 }
 
+// sin and cos of x for |x| < 2^30 (here |k theta| <= 255 * 2 pi * a fractional coordinate of order one): the argument
+// is reduced by n = rint(x * 2/pi) against pi/2 held in three doubles (Cody-Waite with fused multiply-adds: the
+// products are exact inside the fma, so the reduction holds next to the multiples of pi/2 as well), the two kernels are
+// the classic minimax polynomials on [-pi/4, pi/4] (degree 13 / 14; the cosine's 1 - z/2 carries its rounding error
+// along), the quadrant picks and signs them.  Within 1.5 ulp of the exact value over the whole range (measured on
+// 2 x 10^7 arguments, tests/test_gpu_parity.py::test_phase_factors_are_within_two_ulp) -- the accuracy class of the
+// library's sincos -- in ~48 vector instructions against the library routine's ~130 with its large-argument branch,
+// and 20 fewer registers: phase 1 of the k sweep is one such evaluation per thread, and the registers buy the sweep
+// its sixth workgroup per CU.
+__device__ __forceinline__ void sincos_bounded(double x, double &sn, double &cs) {
+    const double n = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-n, 1.5707963267948966, x);                    // pi/2 = 1.5707963267948966 + 6.123233995736766e-17 - 1.4973849048591698e-33
+    r = fma(-n, 6.123233995736766e-17, r);
+    r = fma(-n, -1.4973849048591698e-33, r);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double s0 = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double c0 = w + fma(z * z, pc, (1.0 - w) - hz);         // (1 - w) - hz: what rounding w lost, exactly
+    const int q = (int)n;
+    const bool swap = q & 1;
+    const double sv = swap ? c0 : s0, cv = swap ? s0 : c0;
+    sn = (q & 2) ? -sv : sv;
+    cs = ((q + 1) & 2) ? -cv : cv;
+}
+
 // exp(i k theta): dcos / dsin of the rounded product k * theta, as ComputePhaseFactors1D (ewald_phase.f90:100-109).
-// (sincospi(2 k f) -- a third of the instructions -- was measured in round 3 and changed nothing: LABNOTES.md.)
 __device__ __forceinline__ double2 phase_entry(double theta, int k) {
     double s, c;
-    sincos((double)k * theta, &s, &c);
+    sincos_bounded((double)k * theta, s, c);
     return make_double2(c, s);
+}
+
+// test and diagnostic hook (mgpu_phase_factors): the table entries exactly as the sweeps form them
+__global__ void phase_factors_kernel(int n, const double *__restrict__ theta, const int *__restrict__ k, double2 *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = phase_entry(theta[i], k[i]);
 }
 
 // SingleMolFourierTerms + ComputeRecipEnergySingleMol (ewald_phase.f90:383-420,
@@ -1325,17 +1376,24 @@ struct AcceptBits {
 };
 
 #ifndef MGPU_RECIP_MINWAVES
-#define MGPU_RECIP_MINWAVES 4   // <= 128 VGPRs: four 4-wave workgroups per CU, 1024 items resident at once
+#define MGPU_RECIP_MINWAVES 6   // six 4-wave workgroups per CU, 1536 items resident at once (round 4: one-task chunks and the short
+                                // sincos leave the sweep at 74 VGPRs; at five 39.8 us, at six 37.9, at seven -- spills -- 39.8-40.3)
 #endif
 #ifndef MGPU_COMMIT_MINWAVES
 #define MGPU_COMMIT_MINWAVES 5  // the commit needs 76 VGPRs: five workgroups per CU (measured 26.8 -> 24.7 us at the SPC/E box, 17.2 -> 16.0 us
-                                // at the framework box; the k sweep at five: 25.8 -> 28.8 us, it spills below 125 VGPRs)
+                                // at the framework box; round 3's k sweep, chunks of two, at five: 25.8 -> 28.8 us, spills)
 #endif
-// Phase 3: a thread's tasks are taken in chunks of kRecipTaskChunk with TWO chunks in flight (the next chunk's A(k),
+// Phase 3: a thread's tasks are taken in chunks (recip_chunk_tasks) with TWO chunks in flight (the next chunk's A(k),
 // weights and task words are requested before the current chunk's arithmetic).  A thread visits its tasks in ascending
 // order whatever the chunking, so the sums are the same bits.  (Round-3 measurements of the alternatives -- one chunk of
 // 3 / 4 / 5, pipelined 3 + 3, A(k) requested before the tables, cache prefetch, staggered starts: LABNOTES.md.)
-constexpr int kRecipTaskChunk = 2;
+#ifndef MGPU_RECIP_TASK_CHUNK
+#define MGPU_RECIP_TASK_CHUNK 1
+#endif
+#ifndef MGPU_RECIP_COMMIT_CHUNK
+#define MGPU_RECIP_COMMIT_CHUNK 2
+#endif
+constexpr int kRecipTaskChunk = MGPU_RECIP_TASK_CHUNK, kRecipCommitChunk = MGPU_RECIP_COMMIT_CHUNK;
 
 // Acceptance decided on the device (recip_rows_kernel<false, true, true>): the k sweep's workgroup is the last kernel of a
 // candidate's trial, so once its two reciprocal energies are summed thread 0 has everything mc_acceptance_probability
@@ -1385,11 +1443,10 @@ __device__ inline bool decide_candidate(const DecideItem &d, const DecideArgs &g
 // ---- the row-form update in pieces (shared by recip_rows_kernel and chain_window_kernel).  All of them are executed by
 //      the first kBlock threads of a workgroup (`tid` < kBlock: `active`); every thread of the workgroup must reach the
 //      barriers inside.
-// LDS view of one item: 1-D tables [nss][ktot] | XY [n_rows][nss] | charges [n1] | rows [n_rows]
+// LDS view of one item: 1-D tables [nss][ktot] | XY [n_rows][nss] | charges [n1]
 struct RecipLds {
     double2 *tab, *xy;
     double *q;
-    RecipRow *rows;
     int n1, nss, ktot, kofs1, kofs2;
     bool use_new, use_old, two_sets;
 };
@@ -1409,30 +1466,35 @@ __device__ __forceinline__ RecipLds recip_lds_view(const Topo &tp, const BoxDev 
     v.tab = s_tab;
     v.xy = s_tab + v.nss * v.ktot;
     v.q = reinterpret_cast<double *>(v.xy + n_rows * v.nss);
-    v.rows = reinterpret_cast<RecipRow *>(v.q + v.n1);
     return v;
 }
 
-// phases 1 and 2 (two workgroup barriers inside).  cand_row = the item's candidate row (new sites), unused without one
+// phases 1 and 2 (two workgroup barriers inside).  cand_row = the item's candidate row (new sites), unused without one.
+// `after_loads()` runs once per active thread after the loads phases 1 and 2 wait for (the thread's first table entry's
+// coordinates, the charge, its first row) have been requested and before the first wait: the place where the kernels
+// request their first chunks of A(k) (recip_rows_prefetch), so that the wait for the small loads leaves the large ones
+// in flight (the memory counter retires in order) and phases 1 and 2 run under them.
+template <class Hook>
 __device__ __forceinline__ void recip_rows_tables(const Topo &tp, const BoxDev &bx, const double *__restrict__ pos,
                                                   const double *__restrict__ res_q, const RecipRow *__restrict__ rows, int n_rows,
                                                   const RecipItem &it, const double *__restrict__ cand_row, const RecipLds &v,
-                                                  int tid, bool active) {
+                                                  int tid, bool active, Hook &&after_loads) {
     const double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
     const double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
     const int n1 = v.n1, nss = v.nss, ktot = v.ktot;
+    // with no set at all (MGPU_NONE: the energy of A as it is) the entries are zero and phase 3 adds nothing
+    const bool used = v.use_new || v.use_old;
+    RecipRow r_first{0, 0};
     if (active) {
-        for (int r = tid; r < n_rows; r += kBlock) v.rows[r] = rows[r];
         // phase 1: entry (s, axis, k >= 0) at tab[s * ktot + kofs[axis] + k]; s = set * n1 + a with both sets, s = a with one
-        // (set 0 = the new sites, set 1 = the old ones)
-        for (int e = tid; e < nss * ktot; e += kBlock) {
-            const int s = e / ktot, kk = e - s * ktot;
+        // (set 0 = the new sites, set 1 = the old ones).  e / ktot by a multiplication: floor(e M / 2^32) with
+        // M = ceil(2^32 / ktot) is exact for e < 2^32 / ktot
+        const unsigned ktot_magic = 0xffffffffu / (unsigned)ktot + 1u;
+        const int n_ent = nss * ktot;
+        auto fetch = [&](int e, double &x, double &y, double &z) {
+            const int s = (int)__umulhi((unsigned)e, ktot_magic);
             const int set = v.two_sets ? (s >= n1 ? 1 : 0) : (v.use_old ? 1 : 0), a = s - (s >= n1 ? n1 : 0);
-            const int axis = (kk >= v.kofs2) ? 2 : (kk >= v.kofs1 ? 1 : 0);
-            const int k0 = axis == 2 ? v.kofs2 : (axis == 1 ? v.kofs1 : 0);
-            // with no set at all (MGPU_NONE: the energy of A as it is) the entries are zero and phase 3 adds nothing
-            const bool used = v.use_new || v.use_old;
-            double x = 0.0, y = 0.0, z = 0.0;
+            x = 0.0; y = 0.0; z = 0.0;
             if (used) {
                 if (set == 0) {
                     const double *c = cand_row + (size_t)a * 3;
@@ -1442,28 +1504,46 @@ __device__ __forceinline__ void recip_rows_tables(const Topo &tp, const BoxDev &
                     x = px[j]; y = py[j]; z = pz[j];
                 }
             }
+        };
+        double x = 0.0, y = 0.0, z = 0.0, q = 0.0;
+        int e = tid;
+        if (e < n_ent) fetch(e, x, y, z);
+        if (tid < n1) q = res_q[it.t * tp.max_atom + tid];
+        if (tid < n_rows) r_first = rows[tid];
+        after_loads();
+        for (; e < n_ent;) {
+            const int s = (int)__umulhi((unsigned)e, ktot_magic), kk = e - s * ktot;
+            const int axis = (kk >= v.kofs2) ? 2 : (kk >= v.kofs1 ? 1 : 0);
+            const int k0 = axis == 2 ? v.kofs2 : (axis == 1 ? v.kofs1 : 0);
             v.tab[e] = used ? phase_entry(atom_phase(bx, axis, x, y, z), kk - k0) : make_double2(0.0, 0.0);
+            e += kBlock;
+            if (e < n_ent) fetch(e, x, y, z);
         }
-        for (int a = tid; a < n1; a += kBlock) v.q[a] = res_q[it.t * tp.max_atom + a];
+        if (tid < n1) v.q[tid] = q;
+        for (int a = tid + kBlock; a < n1; a += kBlock) v.q[a] = res_q[it.t * tp.max_atom + a];
     }
     __syncthreads();
     // phase 2: XY[row][s] = (+q for the new sites, -q for the old ones) * X[kx] * Y[ky]   (ewald_energy.f90:241-256)
+    // (one thread per row, the site-states in its inner loop: the row's indices are read once -- straight from the
+    //  launch's row list -- and nothing is divided)
     if (active) {
-        for (int e = tid; e < n_rows * nss; e += kBlock) {
-            const int row = e / nss, s = e - row * nss;
-            const int set = v.two_sets ? (s >= n1 ? 1 : 0) : (v.use_old ? 1 : 0), a = s - (s >= n1 ? n1 : 0);
-            double2 xy = make_double2(0.0, 0.0);
-            if (v.use_new || v.use_old) {
-                const RecipRow r = v.rows[row];
-                const double2 *t = v.tab + s * ktot;
-                const int aky = r.ky < 0 ? -r.ky : r.ky;
-                double2 Y = t[v.kofs1 + aky];
-                if (r.ky < 0) Y.y = -Y.y;
-                xy = cmul(t[r.kx], Y);
-                const double q = set == 0 ? v.q[a] : -v.q[a];
-                xy.x *= q; xy.y *= q;
+        for (int row = tid; row < n_rows; row += kBlock) {
+            const RecipRow r = row == tid ? r_first : rows[row];
+            const int aky = r.ky < 0 ? -r.ky : r.ky;
+            const double2 *tx = v.tab + r.kx, *ty = v.tab + v.kofs1 + aky;
+            double2 *out = v.xy + row * nss;
+            for (int s = 0; s < nss; ++s) {
+                const int set = v.two_sets ? (s >= n1 ? 1 : 0) : (v.use_old ? 1 : 0), a = s - (s >= n1 ? n1 : 0);
+                double2 xy = make_double2(0.0, 0.0);
+                if (used) {
+                    double2 Y = ty[s * ktot];
+                    if (r.ky < 0) Y.y = -Y.y;
+                    xy = cmul(tx[s * ktot], Y);
+                    const double q = set == 0 ? v.q[a] : -v.q[a];
+                    xy.x *= q; xy.y *= q;
+                }
+                out[s] = xy;
             }
-            v.xy[e] = xy;
         }
     }
     __syncthreads();
@@ -1472,42 +1552,78 @@ __device__ __forceinline__ void recip_rows_tables(const Topo &tp, const BoxDev &
 // phase 3: one pass over the replica's A(k) by the first kBlock threads.  STORE = false: acc += ff W |A + delta|^2 and, with
 // BOTH, acc0 += ff W |A|^2 (the reference's ComputeOldEnergy call, delta = 0); STORE = true: A <- A + delta.
 // A(k) (32 contiguous bytes per task, the bulk of the kernel's memory traffic), ff*W and the task words of a whole chunk
-// are requested before any of them is used; none of the addresses depends on a load.
-template <bool STORE, bool BOTH>
-__device__ __forceinline__ void recip_rows_pass(const RecipLds &v, const int *__restrict__ trj, const double2 *__restrict__ tw, int n_tasks,
-                                                double2 *__restrict__ A, int tid, double &acc, double &acc0) {
-    struct Chunk {
-        int rj[kRecipTaskChunk];
-        double2 Ap[kRecipTaskChunk], Am[kRecipTaskChunk], w[kRecipTaskChunk];
-    };
-    const int nss = v.nss, ktot = v.ktot;
-    auto load_chunk = [&](Chunk &ch, int t0) {
+// are requested before any of them is used; none of the addresses depends on a load OR on the tables, so the first two
+// chunks are requested (recip_rows_prefetch) BEFORE the tables are built: the workgroup's one long memory round trip
+// runs under phases 1 and 2 instead of after them.
+template <int CH>
+struct RecipChunk {
+    int rj[CH];
+    double2 Ap[CH], Am[CH], w[CH];
+};
+template <int CH>
+struct RecipInFlight {
+    RecipChunk<CH> ch0, ch1;
+};
+// tasks per chunk: ONE for the energy sweeps (two tasks of a thread in flight: 89 VGPRs, five workgroups per CU), two for
+// the commit (76 VGPRs with them, five workgroups as well).  Measured round 4, k sweep / commit in us at the SPC/E, CO2 and
+// framework boxes: chunks of two at four workgroups 43.5 / 39.4 / 32.4, of one at five 40.5 / 35.9 / 29.6 (at six: spills,
+// 57.8 / 62.9 / 34.7); the commit with chunks of one 41.4-43.0 against 40.0.
+template <bool STORE>
+constexpr int recip_chunk_tasks() { return STORE ? kRecipCommitChunk : kRecipTaskChunk; }
+
+template <bool STORE, int CH>
+__device__ __forceinline__ void recip_load_chunk(RecipChunk<CH> &ch, const int *__restrict__ trj, const double2 *__restrict__ tw, int n_tasks,
+                                                 const double2 *__restrict__ A, int t0) {
 #pragma unroll
-        for (int c = 0; c < kRecipTaskChunk; ++c) {
-            const int t = t0 + c * kBlock;
-            const bool in = t < n_tasks;
-            ch.rj[c] = in ? trj[t] : 0;                                // filler: row 0, j 0, nothing present
-            ch.Ap[c] = in ? A[2 * t] : make_double2(0.0, 0.0);
-            ch.Am[c] = in ? A[2 * t + 1] : make_double2(0.0, 0.0);
-            ch.w[c] = (in && !STORE) ? tw[t] : make_double2(0.0, 0.0);
-        }
-    };
+    for (int c = 0; c < CH; ++c) {
+        const int t = t0 + c * kBlock;
+        const bool in = t < n_tasks;
+        ch.rj[c] = in ? trj[t] : 0;                                // filler: row 0, j 0, nothing present
+        ch.Ap[c] = in ? A[2 * t] : make_double2(0.0, 0.0);
+        ch.Am[c] = in ? A[2 * t + 1] : make_double2(0.0, 0.0);
+        ch.w[c] = (in && !STORE) ? tw[t] : make_double2(0.0, 0.0);
+    }
+}
+template <bool STORE, int CH>
+__device__ __forceinline__ void recip_rows_prefetch(RecipInFlight<CH> &f, const int *__restrict__ trj, const double2 *__restrict__ tw, int n_tasks,
+                                                    const double2 *__restrict__ A, int tid) {
+    constexpr int kStride = kBlock * CH;
+    if (tid < n_tasks) recip_load_chunk<STORE>(f.ch0, trj, tw, n_tasks, A, tid);
+    if (tid + kStride < n_tasks) recip_load_chunk<STORE>(f.ch1, trj, tw, n_tasks, A, tid + kStride);
+}
+
+// `f` holds the thread's first two chunks (recip_rows_prefetch with the same arguments)
+template <bool STORE, bool BOTH, int CH>
+__device__ __forceinline__ void recip_rows_pass(const RecipLds &v, const int *__restrict__ trj, const double2 *__restrict__ tw, int n_tasks,
+                                                double2 *__restrict__ A, int tid, RecipInFlight<CH> &f, double &acc, double &acc0) {
+    constexpr int kRecipStride = kBlock * CH;
+    const int nss = v.nss, ktot = v.ktot;
     const double2 *zt = v.tab + v.kofs2;
     // the tasks of one chunk: a thread's tasks are visited in ascending order whatever the chunk size, so the sums do
     // not depend on it
-    auto compute_chunk = [&](const Chunk &ch, int t0) {
+    auto compute_chunk = [&](const RecipChunk<CH> &ch, int t0) {
 #pragma unroll
-        for (int c = 0; c < kRecipTaskChunk; ++c) {
+        for (int c = 0; c < CH; ++c) {
+            // past the end for the whole wave (its first lane holds the smallest task): a filler adds exact zeros
+            if (__builtin_amdgcn_readfirstlane(t0 + c * kBlock) >= n_tasks) continue;
             const double2 *xy = v.xy + ((ch.rj[c] >> 8) & 0xfffff) * nss;
             const double2 *z = zt + (ch.rj[c] & 0xff);
             double sac = 0.0, sbd = 0.0, sad = 0.0, sbc = 0.0;
-            for (int s = 0; s < nss; ++s) {
-                const double2 p = xy[s], q = z[s * ktot];
+            auto term = [&](const double2 p, const double2 q) {
                 sac = fma(p.x, q.x, sac);
                 sbd = fma(p.y, q.y, sbd);
                 sad = fma(p.x, q.y, sad);
                 sbc = fma(p.y, q.x, sbc);
+            };
+            // site-states two at a time (the four LDS reads of a pair are requested together), then the odd one; the
+            // order of the sums is s = 0, 1, 2, ... either way
+            int s = 0;
+            for (; s + 2 <= nss; s += 2) {
+                const double2 p0 = xy[s], p1 = xy[s + 1];
+                const double2 q0 = z[s * ktot], q1 = z[(s + 1) * ktot];
+                term(p0, q0); term(p1, q1);
             }
+            for (; s < nss; ++s) term(xy[s], z[s * ktot]);
             const double wp = ch.w[c].x, wm = ch.w[c].y;
             // explicit fma forms: every kernel that forms these sums must produce the same bits, and a contraction left to
             // the compiler may pick a different product to fuse in a different kernel
@@ -1525,19 +1641,17 @@ __device__ __forceinline__ void recip_rows_pass(const RecipLds &v, const int *__
             }
         }
     };
-    constexpr int kStride = kBlock * kRecipTaskChunk;
-    // two chunks in flight: the next chunk's A(k) is requested before the current one is consumed
-    Chunk ch0, ch1;
+    // two chunks in flight: the chunk after the next is requested as soon as its registers are free
     int t0 = tid;
-    if (t0 < n_tasks) load_chunk(ch0, t0);
     while (t0 < n_tasks) {
-        const int t1 = t0 + kStride;
-        if (t1 < n_tasks) load_chunk(ch1, t1);
-        compute_chunk(ch0, t0);
+        compute_chunk(f.ch0, t0);
+        const int t1 = t0 + kRecipStride;
         if (t1 >= n_tasks) break;
-        const int t2 = t1 + kStride;
-        if (t2 < n_tasks) load_chunk(ch0, t2);
-        compute_chunk(ch1, t1);
+        const int t2 = t1 + kRecipStride;
+        if (t2 < n_tasks) recip_load_chunk<STORE>(f.ch0, trj, tw, n_tasks, A, t2);
+        compute_chunk(f.ch1, t1);
+        if (t2 >= n_tasks) break;
+        if (t2 + kRecipStride < n_tasks) recip_load_chunk<STORE>(f.ch1, trj, tw, n_tasks, A, t2 + kRecipStride);
         t0 = t2;
     }
 }
@@ -1616,9 +1730,14 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
     double2 *A = A_base + (size_t)it.replica * bx.n_slots;
     const int tid = threadIdx.x;
 
-    recip_rows_tables(tp, bx, pos, res_q, rows, n_rows, it, cand_row, v, tid, true);
+    // the energy sweeps request their first chunks of A(k) under the table phases; the commit, whose registers buy it a
+    // fifth workgroup per CU, after them (measured at the SPC/E box: 40.9 us against 44.3 at four and 70 with spills)
+    RecipInFlight<recip_chunk_tasks<COMMIT>()> inflight;
+    recip_rows_tables(tp, bx, pos, res_q, rows, n_rows, it, cand_row, v, tid, true,
+                      [&] { if (!COMMIT) recip_rows_prefetch<COMMIT>(inflight, trj, tw, n_tasks, A, tid); });
+    if (COMMIT) recip_rows_prefetch<COMMIT>(inflight, trj, tw, n_tasks, A, tid);
     double acc = 0.0, acc0 = 0.0;
-    recip_rows_pass<COMMIT, BOTH>(v, trj, tw, n_tasks, A, tid, acc, acc0);
+    recip_rows_pass<COMMIT, BOTH>(v, trj, tw, n_tasks, A, tid, inflight, acc, acc0);
 
     if (!COMMIT) {
         acc = wave_sum(acc);
@@ -1645,7 +1764,9 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
         recip_commit_target(tp, nmol, it);
         // A <- A + delta from the tables still in LDS: the stand-alone commit's pass (same sums, same bits); this
         // workgroup has just read the replica's A(k), so the second read comes from L2 / the Infinity Cache
-        recip_rows_pass<true, false>(v, trj, tw, n_tasks, A, tid, acc, acc0);
+        RecipInFlight<kRecipTaskChunk> again;       // (chunks of one here too: the registers are the sweep's)
+        recip_rows_prefetch<true>(again, trj, tw, n_tasks, A, tid);
+        recip_rows_pass<true, false>(v, trj, tw, n_tasks, A, tid, again, acc, acc0);
     }
     if (COMMIT || DECIDE) recip_commit_tail(tp, pos, nmol, it, cand_row, tid);
 }
@@ -1921,10 +2042,12 @@ __global__ __launch_bounds__(kChainBlock, 1) void chain_window_kernel(
         RecipItem it{g.replica, g.t[c], g.m[c], kind, c, 0, 0};
         const RecipLds v = recip_lds_view(tp, bx, it, n_rows, reinterpret_cast<double2 *>(s_dyn));
         const bool active = tid < kBlock;
-        recip_rows_tables(tp, bx, pos, res_q, rows, n_rows, it, &g.sites[c][0][0], v, tid, active);
+        RecipInFlight<kRecipTaskChunk> inflight;
+        recip_rows_tables(tp, bx, pos, res_q, rows, n_rows, it, &g.sites[c][0][0], v, tid, active,
+                          [&] { recip_rows_prefetch<false>(inflight, trj, tw, n_tasks, A, tid); });
         mark(my_role, 1);
         double acc = 0.0, acc0 = 0.0;
-        if (active) recip_rows_pass<false, true>(v, trj, tw, n_tasks, A, tid, acc, acc0);
+        if (active) recip_rows_pass<false, true>(v, trj, tw, n_tasks, A, tid, inflight, acc, acc0);
         if (tid == kBlock && link != -2 && (kind == 1 || kind == 2)) {
             // ComputeIntraResidueRealCoulombEnergySingleMol of the inserted (candidate row) / deleted (resident) molecule
             const PairItem pit{g.replica, it.t, it.m, kind == 1 ? c : -1, 0};
@@ -2078,11 +2201,13 @@ __global__ __launch_bounds__(kChainBlock, 1) void chain_window_kernel(
         recip_commit_target(tp, nmol, it);
         const RecipLds v = recip_lds_view(tp, bx, it, n_rows, reinterpret_cast<double2 *>(s_dyn));
         const bool active = tid < kBlock;
-        recip_rows_tables(tp, bx, pos, res_q, rows, n_rows, it, &g.sites[src][0][0], v, tid, active);
+        RecipInFlight<kRecipCommitChunk> inflight;
+        recip_rows_tables(tp, bx, pos, res_q, rows, n_rows, it, &g.sites[src][0][0], v, tid, active,
+                          [&] { recip_rows_prefetch<true>(inflight, trj, tw, n_tasks, A, tid); });
         mark(rs, 5);
         double acc = 0.0, acc0 = 0.0;
         if (active) {
-            recip_rows_pass<true, false>(v, trj, tw, n_tasks, A, tid, acc, acc0);
+            recip_rows_pass<true, false>(v, trj, tw, n_tasks, A, tid, inflight, acc, acc0);
             recip_commit_tail(tp, pos, nmol, it, &g.sites[src][0][0], tid);
         }
         mark(rs, 6);

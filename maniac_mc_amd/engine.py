@@ -395,6 +395,15 @@ class Engine:
         """ewald_energy.f90:371-411"""
         return float(self.intra_energy_candidates(replica, residue_type, molecule_index, sites)[0])
 
+    def phase_factors(self, theta, k):
+        """(cos, sin)(k * theta) as the device's phase tables hold them (mgpu_phase_factors; ewald_phase.f90:100-109)."""
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        k = np.ascontiguousarray(k, dtype=np.int32)
+        n = theta.shape[0]
+        c, s = np.empty(n), np.empty(n)
+        check(self.L.mgpu_phase_factors(self.h, C.c_int(n), _d(theta), _i(k), _d(c), _d(s)))
+        return c, s
+
     # ---- measurement ---------------------------------------------------------------------
     def synchronize(self):
         check(self.L.mgpu_synchronize(self.h))

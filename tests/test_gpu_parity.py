@@ -385,6 +385,36 @@ def test_per_k_reciprocal_kernel():
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
 
 
+def test_phase_factors_are_within_two_ulp():
+    """The device's own sin / cos of the phase tables (sincos_bounded, csrc/mgpu_kernels.h) against extended precision
+    on the rounded product k * theta (ComputePhaseFactors1D, ewald_phase.f90:100-109): every argument the tables can
+    meet (|k| <= 255, theta = 2 pi * a fractional coordinate of a few box lengths), arguments next to the multiples of
+    pi / 2 where the reduction cancels, zero, and far beyond the tables' range (|x| up to 2^29)."""
+    s = synth.spce_box(3, seed=3)
+    eng = Engine.from_system(s, n_replicas=1)
+    rng = np.random.default_rng(11)
+    n = 200000
+    theta = 2.0 * np.pi * rng.uniform(-3.0, 3.0, n)
+    k = rng.integers(0, 256, n).astype(np.int32)
+    # multiples of pi / 2 and their neighbours (k = 1), tiny arguments, zero
+    j = np.arange(-2000, 2001, dtype=np.float64)
+    near = np.concatenate([np.nextafter(j * (np.pi / 2), np.inf), j * (np.pi / 2), np.nextafter(j * (np.pi / 2), -np.inf)])
+    tiny = np.concatenate([[0.0, -0.0], 10.0 ** rng.uniform(-300, -1, 1000) * rng.choice([-1.0, 1.0], 1000)])
+    far = rng.uniform(-2.0 ** 29, 2.0 ** 29, 20000)
+    theta = np.concatenate([theta, near, tiny, far])
+    k = np.concatenate([k, np.ones(near.size + tiny.size + far.size, np.int32)])
+    c, sn = eng.phase_factors(theta, k)
+    x = (k.astype(np.float64) * theta).astype(np.longdouble)       # the rounded product, then exact to 64 bits
+    for got, ref, name in ((c, np.cos(x), "cos"), (sn, np.sin(x), "sin")):
+        ulp = np.spacing(np.abs(ref.astype(np.float64)))
+        err = np.abs(got.astype(np.longdouble) - ref) / np.maximum(ulp, np.finfo(np.float64).tiny).astype(np.longdouble)
+        worst = int(np.argmax(err))
+        assert float(err[worst]) <= 2.0, f"{name}: {float(err[worst]):.2f} ulp at x = {float(x[worst])!r}"
+    assert c[near.size + 200000] == 1.0 and sn[200000 + near.size] == 0.0
+    # the identity the structure factor relies on: |e^{i x}| = 1 to rounding
+    assert np.max(np.abs(c * c + sn * sn - 1.0)) < 5e-16
+
+
 def test_maximum_molecule_count(refcpu_mod):
     """NB_MAX_MOLECULE = 5000 molecules of one residue type (src/parameters.f90:8), the reference's hard limit:
     fill a 4913-molecule SPC/E box up to 5000 by committed insertions, check trial energies of the full box
