@@ -181,8 +181,9 @@ struct mgpu_engine {
     std::vector<char> frozen_same;
     std::vector<int> frozen_diff;
     bool frozen_batch = true;
-    int frozen_chunk = 32;           // framework atoms per pair_frozen_kernel work unit (engine constant: the chunk partials are
-                                     // summed in order, so the chunking must not depend on the batch; MGPU_FROZEN_CHUNK, <= 64)
+    int frozen_chunk = 0;            // framework atoms per pair_frozen_kernel work unit; 0 = frozen_chunk_atoms' rule.  The chunk
+                                     // partials are summed in order, so the chunking depends on the framework's size alone,
+                                     // never on the batch (MGPU_FROZEN_CHUNK, <= 64, overrides)
     // molecule frames (mgpu_replica_set_frames): com [R][3][n_mol_slots], off [R][3][Ncap]; allocated on first use
     double *d_com = nullptr, *d_off = nullptr;
     std::vector<char> frames_ok;     // [R][n_res]: the frames of (replica, type) mirror its sites
@@ -542,14 +543,27 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
     return MGPU_OK;
 }
 
+// Framework atoms per work unit of pair_frozen_kernel: the fewest chunks that are a multiple of the eight waves of a
+// workgroup (a workgroup takes eight chunks of one candidate group: no idle wave in the last one) and hold at most 30
+// atoms.  Measured at the 2208-atom framework, chunks of 24 / 28 / 32 / 36 / 40 atoms, us per launch with its finalize:
+// 1531 evaluations 52.2 / 42.4 / 42.3 / 46.2 / 47.6, 3066: 66.6 / 60.4 / 62.1 / 68.7 / 72.0, 6156: 106.5 / 105.0 / 110.8 /
+// 111.2 / 97.6 -> 28 atoms (80 chunk slots, 79 used).
+int frozen_chunk_atoms(const mgpu_engine *e, int n_atoms) {
+    if (e->frozen_chunk > 0) return e->frozen_chunk;
+    const int n_slots = kPairWaves * std::max(1, (n_atoms + kPairWaves * 30 - 1) / (kPairWaves * 30));
+    return std::max(1, std::min(64, (n_atoms + n_slots - 1) / n_slots));
+}
+
 // The framework part of a launch segment, candidates in the lanes (pair_frozen_kernel + frozen_finalize_kernel): items of
 // ONE residue type with n1 register sites; one extra record {e_lj, e_coul} per entry lands in d_extra.
 int launch_frozen(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, int n1, int site_stride, bool fused, bool fast_fold,
                   int t_frozen, double2 *d_scratch, double2 *d_extra) {
     const int n_atoms = e->h_nmol[t_frozen] * e->tp.n1[t_frozen];
-    const int n_chunks = (n_atoms + e->frozen_chunk - 1) / e->frozen_chunk;
+    const int chunk_atoms = frozen_chunk_atoms(e, n_atoms);
+    const int n_chunks = (n_atoms + chunk_atoms - 1) / chunk_atoms;
     if (n_chunks == 0 || n_items == 0) return MGPU_OK;
-    const int n_work = ((n_items + 63) / 64) * n_chunks;
+    // one workgroup per (group of 64 candidates, eight chunks): pair_frozen_kernel
+    const int n_wg_units = ((n_items + 63) / 64) * ((n_chunks + kPairWaves - 1) / kPairWaves);
     const bool ff = fast_fold && e->pair_fast_fold;
     hipEvent_t a = nullptr, b = nullptr;
     int rc = prof_begin(e, ln, MGPU_KERNEL_PAIR, &a, &b);
@@ -557,11 +571,10 @@ int launch_frozen(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items
 #define MGPU_LAUNCH_FROZEN_1(NS, FU, FW)                                                                                \
     do {                                                                                                               \
         const int nb = resident_blocks<&pair_frozen_kernel<NS, FU, FW>>(ln, e->coul_bytes);                                \
-        /* every resident workgroup slot gets a workgroup: the kernel deals the units over them evenly */               \
-        const int grid_f = std::max(1, std::min(n_work, e->n_cu * nb));                                               \
+        const int grid_f = std::max(1, std::min(n_wg_units, e->n_cu * nb));                                           \
         hipExtLaunchKernelGGL((pair_frozen_kernel<NS, FU, FW>), dim3(grid_f), dim3(kPairBlock), e->coul_bytes, ln.stream, a, b, 0, \
                               e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab,   \
-                              d_items, (const double *)ln.d_sites.p, site_stride, n_items, t_frozen, n_chunks, e->frozen_chunk, d_scratch); \
+                              d_items, (const double *)ln.d_sites.p, site_stride, n_items, t_frozen, n_chunks, chunk_atoms, d_scratch); \
     } while (0)
 #define MGPU_LAUNCH_FROZEN(NS)                                                                                          \
     do {                                                                                                               \
@@ -1645,7 +1658,8 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
         if (nf != 1 || e->frozen_diff[t_frozen] != 0 || e->h_nmol[t_frozen] < 1) t_frozen = -1;
     }
     auto type_batched = [&](int ty, int n1) { return t_frozen >= 0 && ty != t_frozen && n1 <= kMaxFusedSitesWide; };
-    const int n_chunks_f = t_frozen >= 0 ? (e->h_nmol[t_frozen] * e->tp.n1[t_frozen] + e->frozen_chunk - 1) / e->frozen_chunk : 0;
+    const int n_atoms_f = t_frozen >= 0 ? e->h_nmol[t_frozen] * e->tp.n1[t_frozen] : 0;
+    const int n_chunks_f = t_frozen >= 0 ? (n_atoms_f + frozen_chunk_atoms(e, n_atoms_f) - 1) / frozen_chunk_atoms(e, n_atoms_f) : 0;
     const int nsplit_engine = e->pair_nsplit;
     std::vector<Seg> segs;
     int seg_fused[kMaxRes], seg_single[kMaxRes];        // per class: index of its fused / single segment (-1: none)

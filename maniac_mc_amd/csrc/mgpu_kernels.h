@@ -890,6 +890,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
     constexpr int NREG = NTY * NST;
     extern __shared__ __attribute__((aligned(16))) char s_coul[];     // (coul_last_row + 1) x 48 B
     __shared__ double2 s_pair[kMaxTypes * kMaxTypes];
+    __shared__ double s_cand[NREG * 3 * 64];                          // the group's candidate sites, [site-state][x, y, z][lane]
     for (int i = threadIdx.x; i < (bx.coul_last_row + 1) * kCoulRowVec; i += kPairBlock)
         reinterpret_cast<double2 *>(s_coul)[i] = reinterpret_cast<const double2 *>(coul_tab_g)[i];
     const int nt = tp.n_types;
@@ -900,42 +901,48 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const char *coul_adj = coul_tab_adjusted(s_coul, bx.coul_idx_base);
     const int n_groups = (n_items + 63) >> 6;
-    const int n_work = n_groups * n_chunks;
-    const int n_waves = gridDim.x * kPairWaves;
     // the framework's atoms: every molecule of the frozen type of replica 0 (identical in all replicas)
     const int n_atoms = nmol[t_frozen] * tp.n1[t_frozen];
     const double *fx = pos + tp.seg_off[t_frozen], *fy = fx + tp.n_cap_atoms, *fz = fy + tp.n_cap_atoms;
     const double *fq = tp.slot_q + tp.seg_off[t_frozen];
     const int *fty = tp.slot_ty + tp.seg_off[t_frozen];
 
-    // Work units are dealt WORKGROUP-minor: unit w goes to workgroup w mod gridDim.x, so when a launch has fewer units than
-    // resident waves (3312 units on 4096 slots at the bench's framework box) every workgroup -- hence every CU -- carries
-    // the same number of busy waves (6-7 of 8) instead of the first workgroups carrying 8 and the last none.  Which wave
-    // computes a unit does not enter its partial: same bits.
-    for (int w = wave * (int)gridDim.x + (int)blockIdx.x; w < n_work; w += n_waves) {
-        const int grp = w / n_chunks, chunk = w - grp * n_chunks;
+    // A workgroup takes ONE group of 64 candidates and eight of its chunks (one per wave).  The candidates' sites -- per
+    // lane a different replica: 64 separate cache lines per load -- are gathered ONCE per workgroup into LDS, each thread
+    // one or two of the NREG x 3 x 64 values, and every wave takes its lanes' values from there: an eighth of the gathers
+    // of the one-unit-per-wave form, where each wave gathered all 12-30 values of its lanes itself (stage stamps inside
+    // the kernel, round 4, bench's framework box: 8.0 -> 3.8 us from the unit's start to its first framework atom).
+    // Which wave computes a unit does not enter its partial: same bits.
+    const int wg_per_group = (n_chunks + kPairWaves - 1) / kPairWaves;
+    const int n_wg_units = n_groups * wg_per_group;
+    for (int b = blockIdx.x; b < n_wg_units; b += gridDim.x) {
+        const int grp = b / wg_per_group, chunk = (b - grp * wg_per_group) * kPairWaves + wave;
+        __syncthreads();                                                    // the previous group's readers are done
+        for (int idx = threadIdx.x; idx < NREG * 3 * 64; idx += kPairBlock) {
+            const int ln = idx & 63, comp = idx >> 6, sreg = comp / 3, d = comp - 3 * sreg;
+            const int id = grp * 64 + ln;
+            const PairItem il = items[id < n_items ? id : n_items - 1];
+            const double *pd = pos + (size_t)il.replica * 3 * tp.n_cap_atoms + (size_t)d * tp.n_cap_atoms;
+            const bool resident = FUSED ? (sreg < NTY) : (il.src < 0);
+            const int a = (FUSED && sreg >= NTY) ? sreg - NTY : sreg;
+            s_cand[idx] = resident ? pd[atom_slot(tp, il.t, il.m, a)]
+                                   : cand_sites[((size_t)(il.src < 0 ? 0 : il.src) * site_stride + a) * 3 + d];
+        }
+        __syncthreads();
+        if (chunk >= n_chunks) continue;                                    // (uniform per wave; the barriers are above)
         const int item_id = grp * 64 + lane;
         const bool live = item_id < n_items;
         const PairItem it = items[live ? item_id : n_items - 1];
         const double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
         const double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
-        // the lane's own candidate: both states' sites (per-lane gathers), charges / types of its residue type (uniform)
+        // the lane's own candidate: both states' sites, charges / types of its residue type (uniform)
         double rx[NREG], ry[NREG], rz[NREG], rq[NTY];
         int rty[NTY];
 #pragma unroll
-        for (int a = 0; a < NTY; ++a) {
-            if constexpr (FUSED) {
-                const int j = atom_slot(tp, it.t, it.m, a);
-                rx[a] = px[j]; ry[a] = py[j]; rz[a] = pz[j];
-                const double *c = cand_sites + ((size_t)it.src * site_stride + a) * 3;
-                rx[NTY + a] = c[0]; ry[NTY + a] = c[1]; rz[NTY + a] = c[2];
-            } else if (it.src < 0) {
-                const int j = atom_slot(tp, it.t, it.m, a);
-                rx[a] = px[j]; ry[a] = py[j]; rz[a] = pz[j];
-            } else {
-                const double *c = cand_sites + ((size_t)it.src * site_stride + a) * 3;
-                rx[a] = c[0]; ry[a] = c[1]; rz[a] = c[2];
-            }
+        for (int sreg = 0; sreg < NREG; ++sreg) {
+            rx[sreg] = s_cand[(sreg * 3 + 0) * 64 + lane];
+            ry[sreg] = s_cand[(sreg * 3 + 1) * 64 + lane];
+            rz[sreg] = s_cand[(sreg * 3 + 2) * 64 + lane];
         }
         const int t_item = __builtin_amdgcn_readfirstlane(it.t);          // one residue type per launch
         bool any_c = false;
