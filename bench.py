@@ -868,6 +868,10 @@ def main():
                                           "pass); measured_traffic = the PMC bytes per "
                                           "CANDIDATE (one pass over A(k) serves both evaluations of a move; A(k) is 32 B per +-kz pair "
                                           "and is only read by the k sweep: a third of the 52 Nk algorithmic figure) over the same time"} if iso_gc else None),
+                    "frac_note": "the algorithmic 52 Nk per evaluation is three times what the sweep moves (it only READS A(k), 32 B per +-kz "
+                                 "pair, once per candidate), so this fraction can pass 1: the kernel's efficiency is "
+                                 "isolated.measured_traffic_frac (PMC bytes over the launch's own time); `measured` is the same bytes over "
+                                 "the launch's begin-to-end time in the four-lane pipeline",
                     "job_frac": evals_rank * (bytes_pair_eval + bytes_k_eval) / elapsed / 1e9 / HBM_PEAK_GBS,
                     "job_frac_note": "all evaluations x (36 N + 52 Nk) algorithmic bytes / timed_region_s / HBM peak"}
             # The k sweep only READS A(k) (32 B per +-kz pair): the bytes it really moves are a third of the 52 Nk
