@@ -321,6 +321,13 @@ int mgpu_trial_decide_wait(mgpu_engine *e, int lane, double *old_energy, double 
  * device-built rows, acceptance records).  The rows may be rewritten once the lane's trial has been waited for.  Replaces nothing in the reference (its candidates live in
  * primary%mol_com / site_offset, src/simulation_state.f90:115-116). */
 int mgpu_lane_site_buffer(mgpu_engine *e, int lane, int n_max, int site_stride, double **sites);
+/* Host threads the per-candidate loops INSIDE mgpu_*_submit, mgpu_*_wait and mgpu_commit_submit may use (default 1: the
+ * calling thread alone).  With n_threads > 1 a call with >= 1024 candidates cuts its loops into n_threads contiguous
+ * ranges run by an OpenMP team of the calling thread (LLVM's libomp, the runtime of the Fortran drivers: a driver's team
+ * is reused); items, results and the first error reported are those of the serial loop
+ * (tests/test_gpu_farm.py::test_host_team_is_the_serial_loop).  Set it to the size of the team each driver thread owns
+ * (mc_farm.f90 does).  Replaces nothing in the reference (its loop handles one candidate per step). */
+int mgpu_set_host_team(mgpu_engine *e, int n_threads);
 int mgpu_trial_submit(mgpu_engine *e, int lane, int n_candidates, const int *replica, const int *t,
                       const int *m, const double *sites, int site_stride);
 int mgpu_trial_wait(mgpu_engine *e, int lane, double *old_energy, double *new_energy);

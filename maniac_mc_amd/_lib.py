@@ -28,7 +28,7 @@ EXPORTS = [
     "mgpu_get_structure_factor", "mgpu_set_structure_factor", "mgpu_structure_factor_add", "mgpu_pair_energy_candidates",
     "mgpu_recip_energy_candidates", "mgpu_self_energy", "mgpu_intra_energy_candidates",
     "mgpu_trial_energy_candidates", "mgpu_commit_candidates", "mgpu_trial_submit", "mgpu_trial_wait",
-    "mgpu_commit_submit", "mgpu_lane_site_buffer", "mgpu_replica_set_frames", "mgpu_replica_get_frames", "mgpu_move_trial_submit", "mgpu_move_trial_decide_submit", "mgpu_gcmc_trial_decide_submit", "mgpu_trial_decide_wait", "mgpu_gcmc_trial_submit", "mgpu_gcmc_trial_wait", "mgpu_replica_replace_molecule",
+    "mgpu_commit_submit", "mgpu_lane_site_buffer", "mgpu_set_host_team", "mgpu_replica_set_frames", "mgpu_replica_get_frames", "mgpu_move_trial_submit", "mgpu_move_trial_decide_submit", "mgpu_gcmc_trial_decide_submit", "mgpu_trial_decide_wait", "mgpu_gcmc_trial_submit", "mgpu_gcmc_trial_wait", "mgpu_replica_replace_molecule",
     "mgpu_replica_set_num_molecules", "mgpu_chain_window_capacity", "mgpu_chain_window", "mgpu_chain_set_margin",
     "mgpu_chain_get_stats", "mgpu_chain_set_timing", "mgpu_chain_get_timing", "mgpu_comm_unique_id", "mgpu_comm_create",
     "mgpu_comm_destroy", "mgpu_comm_rank", "mgpu_allgather_block_stats", "mgpu_append_atom_records", "mgpu_format_fixed", "mgpu_phase_factors", "mgpu_synchronize", "mgpu_profile_enable", "mgpu_profile_reset",
@@ -51,7 +51,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
             return LIB_PATH
     # RCCL (librccl, /opt/rocm/lib) carries the path's one collective (mgpu_comm.cpp)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-o", LIB_PATH] + srcs + \
+    # -fopenmp: the host-side candidate loops of submit / wait / commit can use the caller's OpenMP team (libomp, as amdflang's)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-fopenmp", "-o", LIB_PATH] + srcs + \
           ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <omp.h>
 #include <string>
 #include <vector>
 
@@ -103,6 +104,8 @@ struct Lane {
     std::vector<int> build_kind;                              // candidate kinds of a device-built trial
     std::vector<double> h_lj, h_cc;                           // pair energies of the trial being collected
     std::vector<int> mark;                    // [n_replicas] scratch of the one-candidate-per-replica check
+    std::vector<int> commit_mark;             // [n_replicas]: the stamp of the commit_submit_impl call that last committed there
+    int commit_stamp = 0;
     // A trial whose acceptance is decided (and whose accepted candidates are committed) on the device: the flags arrive
     // with the energies; the engine's host mirrors (counts, range flags) follow when the lane is next synchronised
     int decided_n = 0;                        // candidates of such a trial not yet folded into the mirrors (0 = none)
@@ -181,6 +184,7 @@ struct mgpu_engine {
     std::vector<char> frozen_same;
     std::vector<int> frozen_diff;
     bool frozen_batch = true;
+    int host_team = 1;               // host threads the per-candidate loops of submit / wait / commit may use (mgpu_set_host_team)
     int frozen_chunk = 0;            // framework atoms per pair_frozen_kernel work unit; 0 = frozen_chunk_atoms' rule.  The chunk
                                      // partials are summed in order, so the chunking depends on the framework's size alone,
                                      // never on the batch (MGPU_FROZEN_CHUNK, <= 64, overrides)
@@ -312,6 +316,38 @@ void frozen_changed(mgpu_engine *e, int replica, int t) {
     };
     if (replica == 0) for (int r = 0; r < e->n_replicas; ++r) clear(r);
     else clear(replica);
+}
+
+// The per-candidate loops of a submit / wait / commit are cut into `parts` contiguous ranges (boundaries on multiples of
+// 32 candidates: the commit's accept mask is built a word per range) and run by an OpenMP team of the calling thread --
+// the same runtime as the Fortran drivers', whose nested hot team is reused.  One part = the serial loop.
+constexpr int kHostPartMin = 1024;          // candidates below which a team is not worth waking
+constexpr int kMaxHostParts = 16;
+static int host_parts(const mgpu_engine *e, int n) {
+    return (e->host_team > 1 && n >= kHostPartMin) ? std::min(e->host_team, kMaxHostParts) : 1;
+}
+static void part_range(int n, int parts, int part, int &c0, int &c1) {
+    const int words = (n + 31) / 32;
+    c0 = std::min(n, (int)((long long)words * part / parts) * 32);
+    c1 = std::min(n, (int)((long long)words * (part + 1) / parts) * 32);
+}
+template <class F>
+static void for_parts(int parts, F &&f) {
+    if (parts <= 1) { f(0); return; }
+#pragma omp parallel for num_threads(parts) schedule(static, 1)
+    for (int part = 0; part < parts; ++part) f(part);
+}
+// what a part has to say when a candidate is refused: the caller reports the lowest candidate's message (the serial loop's)
+struct PartError {
+    int c = -1, rc = MGPU_OK;
+    std::string msg;
+    void set(int cand, int code, const std::string &m) { if (c < 0) { c = cand; rc = code; msg = m; } }
+};
+static int report_first(const PartError *errs, int parts) {
+    const PartError *first = nullptr;
+    for (int q = 0; q < parts; ++q)
+        if (errs[q].c >= 0 && (!first || errs[q].c < first->c)) first = &errs[q];
+    return first ? set_error(first->rc, first->msg) : MGPU_OK;
 }
 
 int check_candidate(const mgpu_engine *e, int c, int replica, int t, int m, bool need_resident) {
@@ -1686,8 +1722,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     ln.ent_off.assign(n_pair, 0);
     ln.ent_stride.assign(n_pair, 2);
     ln.ent_ns.assign(n_pair, 1);
-    auto add_item = [&](Seg &sg, const PairItem &it) {     // returns the item's first entry
-        const int i = sg.n_items++;
+    auto put_item = [&](const Seg &sg, int i, const PairItem &it) {     // item i of the segment; returns its first entry
         pit[sg.first_item + i] = it;
         const int e0 = sg.first_entry + (sg.fused ? 2 * i : i);
         // partial records (double2) of the segment start at first_partial; [split][state] for fused items
@@ -1704,53 +1739,119 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
     };
     bool fast = true;                 // all replicas of this trial within the fast fold's range
     ln.cand_ok.assign(n, 1);          // and per candidate: would committing it keep its replica there
-    for (int c = 0; c < n; ++c) {
-        const int k = kind ? kind[c] : MGPU_MOVE;
-        const int mc = (k == MGPU_CREATION) ? -1 : m[c];
-        if ((rc = check_candidate(e, c, replica[c], t[c], mc, k != MGPU_CREATION))) return rc;
-        const int n1 = e->tp.n1[t[c]];
-        if (n1 > site_stride) return set_error(MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res");
-        n1_max = std::max(n1_max, n1);
-        int ci = 0;
-        while (cls_type[ci] != t[c]) ++ci;
-        ln.kinds[c] = k;
-        fast = fast && replica_in_range(e, replica[c]);
-        if (build) {
-            const size_t idx = (size_t)replica[c] * e->tp.n_res + t[c];
-            if (!e->d_com || !e->frames_ok[idx])
-                return set_error(MGPU_ERR_STATE, "move_trial_submit: no molecule frames for candidate " + std::to_string(c) +
-                                                     " (mgpu_replica_set_frames)");
-            const int mv = build->move[c];
-            if (mv < 1 || mv > 4 || (k == MGPU_MOVE) != (mv <= 2) || (k == MGPU_CREATION) != (mv == 3))
-                return set_error(MGPU_ERR_INVALID_ARG, "move_trial_submit: move code does not match the candidate kind");
-            // a built candidate's centre lies in the cell (ApplyPBC / uniform insertion); with tight frames its sites are
-            // within the fast fold's range
-            if (k != MGPU_DELETION) { ln.cand_ok[c] = e->frames_tight[idx]; fast = fast && ln.cand_ok[c]; }
-        } else if (k != MGPU_DELETION) {
-            ln.cand_ok[c] = sites_in_range(e, sites + (size_t)c * site_stride * 3, n1) ? 1 : 0;
-            fast = fast && ln.cand_ok[c];          // the candidate's own sites are swept in this launch
-        }
-        if (k != MGPU_MOVE) ln.self_of[c] = e->self_of_type[t[c]];
-        if (decide) {
-            const size_t idx = (size_t)replica[c] * e->tp.n_res + t[c];
-            if (k == MGPU_CREATION && e->h_nmol[idx] >= e->tp.cap[t[c]])
-                return set_error(MGPU_ERR_CAPACITY, "trial_decide_submit: residue type is at mol_capacity");
-            if (!build && k != MGPU_DELETION && e->d_com && e->frames_ok[idx])
-                return set_error(MGPU_ERR_STATE, "trial_decide_submit: this replica holds molecule frames: submit device-built trials");
-        }
-        const bool fz = k == MGPU_MOVE && seg_fused[ci] >= 0;
-        if (fz) {
-            const int e0 = add_item(segs[seg_fused[ci]], PairItem{replica[c], t[c], mc, c, 0});
+    // Two passes over the candidates, each cut into ranges run side by side (for_parts): the first validates a candidate,
+    // fills what belongs to it alone and counts the items it will add to its class's segments; the second, knowing every
+    // range's first item in every segment, writes the items -- in candidate order within a segment, as one loop would.
+    struct Part {
+        int n1_max = 1, n_intra = 0;
+        bool fast = true;
+        int n_fused[kMaxRes], n_single[kMaxRes];
+        int at_fused[kMaxRes], at_single[kMaxRes], at_intra = 0;
+    };
+    const int parts = host_parts(e, n);
+    Part part_of[kMaxHostParts];
+    PartError errs[kMaxHostParts];
+    auto class_of = [&](int ty) { int ci = 0; while (cls_type[ci] != ty) ++ci; return ci; };
+    // candidate c's pair and intra items at the places the running indices say
+    auto place = [&](int c, int k, int mc, int ci, int *i_f, int *i_s, int &i_intra) {
+        if (k == MGPU_MOVE && seg_fused[ci] >= 0) {
+            const int e0 = put_item(segs[seg_fused[ci]], i_f[ci]++, PairItem{replica[c], t[c], mc, c, 0});
             ln.pair_old[c] = e0; ln.pair_new[c] = e0 + 1;
         } else {
-            Seg &sg = segs[seg_single[ci]];
-            if (k != MGPU_CREATION) ln.pair_old[c] = add_item(sg, PairItem{replica[c], t[c], mc, -1, 0});
-            if (k != MGPU_DELETION) ln.pair_new[c] = add_item(sg, PairItem{replica[c], t[c], mc, c, 0});
+            const Seg &sg = segs[seg_single[ci]];
+            if (k != MGPU_CREATION) ln.pair_old[c] = put_item(sg, i_s[ci]++, PairItem{replica[c], t[c], mc, -1, 0});
+            if (k != MGPU_DELETION) ln.pair_new[c] = put_item(sg, i_s[ci]++, PairItem{replica[c], t[c], mc, c, 0});
         }
-        rit[c] = RecipItem{replica[c], t[c], mc, k, k == MGPU_DELETION ? -1 : c, 0, frame_at};   // one k sweep: old and new
-        if (k == MGPU_CREATION) { ln.intra_idx[c] = n_intra; iit[n_intra++] = PairItem{replica[c], t[c], -1, c, 0}; }
-        if (k == MGPU_DELETION) { ln.intra_idx[c] = n_intra; iit[n_intra++] = PairItem{replica[c], t[c], mc, -1, 0}; }
+        if (k == MGPU_CREATION) { ln.intra_idx[c] = i_intra; iit[i_intra++] = PairItem{replica[c], t[c], -1, c, 0}; }
+        if (k == MGPU_DELETION) { ln.intra_idx[c] = i_intra; iit[i_intra++] = PairItem{replica[c], t[c], mc, -1, 0}; }
+    };
+    for_parts(parts, [&](int q) {
+        Part &P = part_of[q];
+        for (int ci = 0; ci < n_cls; ++ci) P.n_fused[ci] = P.n_single[ci] = 0;
+        int c0, c1;
+        part_range(n, parts, q, c0, c1);
+        for (int c = c0; c < c1; ++c) {
+            const int k = kind ? kind[c] : MGPU_MOVE;
+            const int mc = (k == MGPU_CREATION) ? -1 : m[c];
+            if (const int r = check_candidate(e, c, replica[c], t[c], mc, k != MGPU_CREATION)) { errs[q].set(c, r, mgpu_last_error()); return; }
+            const int n1 = e->tp.n1[t[c]];
+            if (n1 > site_stride) { errs[q].set(c, MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res"); return; }
+            P.n1_max = std::max(P.n1_max, n1);
+            const int ci = class_of(t[c]);
+            ln.kinds[c] = k;
+            P.fast = P.fast && replica_in_range(e, replica[c]);
+            if (build) {
+                const size_t idx = (size_t)replica[c] * e->tp.n_res + t[c];
+                if (!e->d_com || !e->frames_ok[idx]) {
+                    errs[q].set(c, MGPU_ERR_STATE, "move_trial_submit: no molecule frames for candidate " + std::to_string(c) +
+                                                       " (mgpu_replica_set_frames)");
+                    return;
+                }
+                const int mv = build->move[c];
+                if (mv < 1 || mv > 4 || (k == MGPU_MOVE) != (mv <= 2) || (k == MGPU_CREATION) != (mv == 3)) {
+                    errs[q].set(c, MGPU_ERR_INVALID_ARG, "move_trial_submit: move code does not match the candidate kind");
+                    return;
+                }
+                // a built candidate's centre lies in the cell (ApplyPBC / uniform insertion); with tight frames its sites are
+                // within the fast fold's range
+                if (k != MGPU_DELETION) { ln.cand_ok[c] = e->frames_tight[idx]; P.fast = P.fast && ln.cand_ok[c]; }
+            } else if (k != MGPU_DELETION) {
+                ln.cand_ok[c] = sites_in_range(e, sites + (size_t)c * site_stride * 3, n1) ? 1 : 0;
+                P.fast = P.fast && ln.cand_ok[c];          // the candidate's own sites are swept in this launch
+            }
+            if (k != MGPU_MOVE) ln.self_of[c] = e->self_of_type[t[c]];
+            if (decide) {
+                const size_t idx = (size_t)replica[c] * e->tp.n_res + t[c];
+                if (k == MGPU_CREATION && e->h_nmol[idx] >= e->tp.cap[t[c]]) {
+                    errs[q].set(c, MGPU_ERR_CAPACITY, "trial_decide_submit: residue type is at mol_capacity");
+                    return;
+                }
+                if (!build && k != MGPU_DELETION && e->d_com && e->frames_ok[idx]) {
+                    errs[q].set(c, MGPU_ERR_STATE, "trial_decide_submit: this replica holds molecule frames: submit device-built trials");
+                    return;
+                }
+            }
+            rit[c] = RecipItem{replica[c], t[c], mc, k, k == MGPU_DELETION ? -1 : c, 0, frame_at};   // one k sweep: old and new
+            if (parts == 1) {            // one range: its counters ARE the items' places, no second pass
+                place(c, k, mc, ci, P.n_fused, P.n_single, P.n_intra);
+                continue;
+            }
+            if (k == MGPU_MOVE && seg_fused[ci] >= 0) P.n_fused[ci] += 1;
+            else P.n_single[ci] += (k != MGPU_CREATION) + (k != MGPU_DELETION);
+            if (k != MGPU_MOVE) P.n_intra += 1;
+        }
+    });
+    if ((rc = report_first(errs, parts))) return rc;
+    {
+        int run_f[kMaxRes] = {0}, run_s[kMaxRes] = {0};
+        for (int q = 0; q < parts; ++q) {
+            Part &P = part_of[q];
+            n1_max = std::max(n1_max, P.n1_max);
+            fast = fast && P.fast;
+            P.at_intra = n_intra;
+            n_intra += P.n_intra;
+            for (int ci = 0; ci < n_cls; ++ci) {
+                P.at_fused[ci] = run_f[ci]; run_f[ci] += P.n_fused[ci];
+                P.at_single[ci] = run_s[ci]; run_s[ci] += P.n_single[ci];
+            }
+        }
+        for (int ci = 0; ci < n_cls; ++ci) {
+            if (seg_fused[ci] >= 0) segs[seg_fused[ci]].n_items = run_f[ci];
+            if (seg_single[ci] >= 0) segs[seg_single[ci]].n_items = run_s[ci];
+        }
     }
+    if (parts > 1)
+        for_parts(parts, [&](int q) {
+            const Part &P = part_of[q];
+            int i_f[kMaxRes], i_s[kMaxRes], i_intra = P.at_intra;
+            for (int ci = 0; ci < n_cls; ++ci) { i_f[ci] = P.at_fused[ci]; i_s[ci] = P.at_single[ci]; }
+            int c0, c1;
+            part_range(n, parts, q, c0, c1);
+            for (int c = c0; c < c1; ++c) {
+                const int k = ln.kinds[c];
+                place(c, k, (k == MGPU_CREATION) ? -1 : m[c], class_of(t[c]), i_f, i_s, i_intra);
+            }
+        });
     if (build) {
         std::memcpy((char *)ln.h_in.p + build_at, build->move, (size_t)n * sizeof(int));
         std::memcpy((char *)ln.h_in.p + build_at + build_mv, build->u, (size_t)5 * n * sizeof(double));
@@ -1881,6 +1982,8 @@ static int trial_wait_impl(mgpu_engine *e, Lane &ln, double *old_energy, double 
     // [split][state], those of a single item [split].
     ln.h_lj.resize(np);
     ln.h_cc.resize(np);
+    const int team = host_parts(e, n);       // (both loops are independent per entry / per candidate)
+#pragma omp parallel for num_threads(team) schedule(static) if (team > 1)
     for (int i = 0; i < np; ++i) {
         double a = 0.0, b = 0.0;
         const double *p = h + ln.ent_off[i];
@@ -1891,6 +1994,7 @@ static int trial_wait_impl(mgpu_engine *e, Lane &ln, double *old_energy, double 
         ln.h_cc[i] = b * kEps0InvEvA / kKbEvK;
     }
     const double *lj = ln.h_lj.data(), *cc = ln.h_cc.data();
+#pragma omp parallel for num_threads(team) schedule(static) if (team > 1)
     for (int c = 0; c < n; ++c) {
         double *o = old_energy + (size_t)ncomp * c, *w = new_energy + (size_t)ncomp * c;
         for (int k = 0; k < ncomp; ++k) { o[k] = 0.0; w[k] = 0.0; }
@@ -1930,47 +2034,89 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
     if ((rc = ln.h_commit.reserve(site_bytes + (size_t)n * sizeof(RecipItem)))) return rc;
     RecipItem *items = (RecipItem *)((char *)ln.h_commit.p + site_bytes);
     int n_items = 0;
-    std::vector<char> seen(e->n_replicas, 0);
-    std::vector<int> new_counts;  // (index into h_nmol, value) pairs applied after validation
-    std::vector<int> range_lost;  // (replica, type) entries whose atoms leave the fast fold's range with this commit
+    // one accepted candidate per replica: ln.commit_mark[replica] holds the stamp of the call that last committed there (a
+    // fresh stamp per call instead of clearing n_replicas flags; exchanged atomically: the ranges below run side by side)
+    if ((int)ln.commit_mark.size() != e->n_replicas) { ln.commit_mark.assign(e->n_replicas, -1); ln.commit_stamp = 0; }
+    if (++ln.commit_stamp == 0x7fffffff) { std::fill(ln.commit_mark.begin(), ln.commit_mark.end(), -1); ln.commit_stamp = 1; }
+    const int stamp = ln.commit_stamp;
     bool any_sites = false;
     int n1_max = 1;
-    for (int c = 0; c < n; ++c) {
-        if (!accept[c]) continue;
-        if (kind[c] < MGPU_MOVE || kind[c] > MGPU_DELETION) return set_error(MGPU_ERR_INVALID_ARG, "commit: unknown candidate kind");
-        if (replica[c] < 0 || replica[c] >= e->n_replicas) return set_error(MGPU_ERR_INVALID_ARG, "commit: replica out of range");
-        if (seen[replica[c]]) return set_error(MGPU_ERR_INVALID_ARG, "commit: more than one accepted candidate for a replica");
-        seen[replica[c]] = 1;
-        if (t[c] < 0 || t[c] >= e->tp.n_res) return set_error(MGPU_ERR_INVALID_ARG, "commit: residue type out of range");
-        const int idx = replica[c] * e->tp.n_res + t[c], nm = e->h_nmol[idx];
-        RecipItem it{replica[c], t[c], m[c], kind[c], -1, nm};
-        if (kind[c] == MGPU_CREATION) {
-            if (nm >= e->tp.cap[t[c]]) return set_error(MGPU_ERR_CAPACITY, "commit: residue type is at mol_capacity");
-            it.m = nm;  // appended at the first free slot: num_residues + 1 (monte_carlo.f90:63, create_molecule.f90:64)
-            it.aux = nm + 1;
-        } else {
-            if ((rc = check_candidate(e, c, replica[c], t[c], m[c], true))) return rc;
-            if (kind[c] == MGPU_DELETION) it.aux = nm - 1;
-        }
-        if (kind[c] != MGPU_DELETION) {
-            any_sites = true;
-            it.src = c;
-            it.frame = built ? ln.last_trial_frame : 0;
-            // where the engine keeps molecule frames they must stay the mirror of the sites: a move / insertion given as
-            // bare sites cannot update them
-            if (!built && e->d_com && e->frames_ok[idx])
-                return set_error(MGPU_ERR_STATE, "commit: this replica holds molecule frames (mgpu_replica_set_frames): commit "
-                                                 "device-built trials from the lane's resident rows, or set the molecules again");
-            // the accepted sites become resident atoms: keep the replica's range flag honest
-            const bool ok = sites ? sites_in_range(e, sites + (size_t)c * site_stride * 3, e->tp.n1[t[c]])
-                                  : (c < (int)ln.cand_ok.size() && ln.cand_ok[c]);
-            if (!ok) range_lost.push_back(idx);
-            if (e->tp.n1[t[c]] > site_stride) return set_error(MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res");
-        }
-        n1_max = std::max(n1_max, e->tp.n1[t[c]]);
-        if (kind[c] != MGPU_MOVE) { new_counts.push_back(idx); new_counts.push_back(it.aux); }
-        items[n_items++] = it;
+    // two passes in ranges, as in trial_submit_impl: count the accepted candidates of every range, then validate them and
+    // write their items at the range's place -- the items keep candidate order
+    struct Part {
+        int n_acc = 0, at = 0, n1_max = 1;
+        bool any_sites = false;
+        std::vector<int> new_counts;  // (index into h_nmol, value) pairs applied after validation
+        std::vector<int> range_lost;  // (replica, type) entries whose atoms leave the fast fold's range with this commit
+    };
+    const int parts = host_parts(e, n);
+    Part part_of[kMaxHostParts];
+    PartError errs[kMaxHostParts];
+    if (parts > 1) {
+        for_parts(parts, [&](int q) {
+            int c0, c1, k = 0;
+            part_range(n, parts, q, c0, c1);
+            for (int c = c0; c < c1; ++c) k += accept[c] != 0;
+            part_of[q].n_acc = k;
+        });
+        for (int q = 0; q < parts; ++q) { part_of[q].at = n_items; n_items += part_of[q].n_acc; }
     }
+    for_parts(parts, [&](int q) {
+        Part &P = part_of[q];
+        int c0, c1, at = P.at;
+        part_range(n, parts, q, c0, c1);
+        for (int c = c0; c < c1; ++c) {
+            if (!accept[c]) continue;
+            if (kind[c] < MGPU_MOVE || kind[c] > MGPU_DELETION) { errs[q].set(c, MGPU_ERR_INVALID_ARG, "commit: unknown candidate kind"); return; }
+            if (replica[c] < 0 || replica[c] >= e->n_replicas) { errs[q].set(c, MGPU_ERR_INVALID_ARG, "commit: replica out of range"); return; }
+            int &mark = ln.commit_mark[replica[c]];
+            const int before = parts > 1 ? __atomic_exchange_n(&mark, stamp, __ATOMIC_RELAXED) : mark;
+            mark = stamp;
+            if (before == stamp) {
+                errs[q].set(c, MGPU_ERR_INVALID_ARG, "commit: more than one accepted candidate for a replica");
+                return;
+            }
+            if (t[c] < 0 || t[c] >= e->tp.n_res) { errs[q].set(c, MGPU_ERR_INVALID_ARG, "commit: residue type out of range"); return; }
+            const int idx = replica[c] * e->tp.n_res + t[c], nm = e->h_nmol[idx];
+            RecipItem it{replica[c], t[c], m[c], kind[c], -1, nm};
+            if (kind[c] == MGPU_CREATION) {
+                if (nm >= e->tp.cap[t[c]]) { errs[q].set(c, MGPU_ERR_CAPACITY, "commit: residue type is at mol_capacity"); return; }
+                it.m = nm;  // appended at the first free slot: num_residues + 1 (monte_carlo.f90:63, create_molecule.f90:64)
+                it.aux = nm + 1;
+            } else {
+                if (const int r = check_candidate(e, c, replica[c], t[c], m[c], true)) { errs[q].set(c, r, mgpu_last_error()); return; }
+                if (kind[c] == MGPU_DELETION) it.aux = nm - 1;
+            }
+            if (kind[c] != MGPU_DELETION) {
+                P.any_sites = true;
+                it.src = c;
+                it.frame = built ? ln.last_trial_frame : 0;
+                // where the engine keeps molecule frames they must stay the mirror of the sites: a move / insertion given as
+                // bare sites cannot update them
+                if (!built && e->d_com && e->frames_ok[idx]) {
+                    errs[q].set(c, MGPU_ERR_STATE, "commit: this replica holds molecule frames (mgpu_replica_set_frames): commit "
+                                                   "device-built trials from the lane's resident rows, or set the molecules again");
+                    return;
+                }
+                // the accepted sites become resident atoms: keep the replica's range flag honest
+                const bool ok = sites ? sites_in_range(e, sites + (size_t)c * site_stride * 3, e->tp.n1[t[c]])
+                                      : (c < (int)ln.cand_ok.size() && ln.cand_ok[c]);
+                if (!ok) P.range_lost.push_back(idx);
+                if (e->tp.n1[t[c]] > site_stride) { errs[q].set(c, MGPU_ERR_INVALID_ARG, "site_stride smaller than atoms_in_res"); return; }
+            }
+            P.n1_max = std::max(P.n1_max, e->tp.n1[t[c]]);
+            if (kind[c] != MGPU_MOVE) { P.new_counts.push_back(idx); P.new_counts.push_back(it.aux); }
+            items[at++] = it;
+        }
+        if (parts == 1) n_items = at;        // (one range: counted as it went)
+    });
+    if ((rc = report_first(errs, parts))) {
+        // (the stamps of this refused call must not make a repeat of it look like a duplicate)
+        for (int c = 0; c < n; ++c)
+            if (accept[c] && replica[c] >= 0 && replica[c] < e->n_replicas) ln.commit_mark[replica[c]] = -1;
+        return rc;
+    }
+    for (int q = 0; q < parts; ++q) { any_sites = any_sites || part_of[q].any_sites; n1_max = std::max(n1_max, part_of[q].n1_max); }
     if (n_items == 0) return MGPU_OK;
     if (any_sites && !sites && !reuse_sites) return set_error(MGPU_ERR_INVALID_ARG, "commit_candidates: sites is null");
     // Committing the lane's last trial from its resident rows: the trial's items are still on the device too,
@@ -1978,14 +2124,22 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
     if (!sites && reuse_sites && n == ln.last_trial_n && ln.d_trial_items && n <= 32 * kAcceptWords &&
         recip_by_rows(e, ln.trial_n1_max)) {
         AcceptBits bits{};
-        bool same = true;       // the caller promises the trial's candidates in the trial's order: verify
-        for (int c = 0; c < n; ++c) {
-            if (!accept[c]) continue;
-            const RecipItem &ti = ln.h_trial_items[c];
-            same = same && ti.replica == replica[c] && ti.t == t[c] && ti.kind == kind[c] &&
-                   (kind[c] == MGPU_CREATION || ti.m == m[c]);
-            bits.w[c >> 5] |= 1u << (c & 31);
-        }
+        bool same_of[kMaxHostParts];   // the caller promises the trial's candidates in the trial's order: verify
+        for_parts(parts, [&](int q) {  // (the ranges end on multiples of 32 candidates: a mask word belongs to one range)
+            bool same = true;
+            int c0, c1;
+            part_range(n, parts, q, c0, c1);
+            for (int c = c0; c < c1; ++c) {
+                if (!accept[c]) continue;
+                const RecipItem &ti = ln.h_trial_items[c];
+                same = same && ti.replica == replica[c] && ti.t == t[c] && ti.kind == kind[c] &&
+                       (kind[c] == MGPU_CREATION || ti.m == m[c]);
+                bits.w[c >> 5] |= 1u << (c & 31);
+            }
+            same_of[q] = same;
+        });
+        bool same = true;
+        for (int q = 0; q < parts; ++q) same = same && same_of[q];
         if (!same) return set_error(MGPU_ERR_INVALID_ARG, "commit_submit: candidates differ from the lane's last trial");
         if ((rc = launch_recip(e, ln, ln.d_trial_items, n, ln.trial_n1_max, site_stride, true, e->d_A, nullptr, nullptr, &bits)))
             return rc;
@@ -2009,8 +2163,11 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
         if ((rc = launch_recip(e, ln, (const RecipItem *)ln.d_items2.p, n_items, n1_max, site_stride, true, e->d_A, nullptr)))
             return rc;
     }
-    for (size_t i = 0; i < new_counts.size(); i += 2) e->h_nmol[new_counts[i]] = new_counts[i + 1];
-    for (int idx : range_lost) e->in_range[idx] = 0;
+    for (int q = 0; q < parts; ++q) {
+        const std::vector<int> &new_counts = part_of[q].new_counts;
+        for (size_t i = 0; i < new_counts.size(); i += 2) e->h_nmol[new_counts[i]] = new_counts[i + 1];
+        for (int idx : part_of[q].range_lost) e->in_range[idx] = 0;
+    }
     if (e->any_frozen)
         for (int c = 0; c < n; ++c)
             if (accept[c]) frozen_changed(e, replica[c], t[c]);
@@ -2199,6 +2356,12 @@ static int chain_max_candidates(const mgpu_engine *e) {
 int mgpu_chain_window_capacity(const mgpu_engine *e, int *max_candidates) {
     if (!e || !max_candidates) return set_error(MGPU_ERR_INVALID_ARG, "chain_window_capacity: null argument");
     *max_candidates = chain_max_candidates(e);
+    return MGPU_OK;
+}
+
+int mgpu_set_host_team(mgpu_engine *e, int n_threads) {
+    if (!e || n_threads < 1) return set_error(MGPU_ERR_INVALID_ARG, "set_host_team: bad argument");
+    e->host_team = std::min(n_threads, kMaxHostParts);
     return MGPU_OK;
 }
 

@@ -395,6 +395,10 @@ class Engine:
         """ewald_energy.f90:371-411"""
         return float(self.intra_energy_candidates(replica, residue_type, molecule_index, sites)[0])
 
+    def set_host_team(self, n_threads):
+        """Host threads the candidate loops inside submit / wait / commit may use (mgpu_set_host_team)."""
+        check(self.L.mgpu_set_host_team(self.h, C.c_int(int(n_threads))))
+
     def phase_factors(self, theta, k):
         """(cos, sin)(k * theta) as the device's phase tables hold them (mgpu_phase_factors; ewald_phase.f90:100-109)."""
         theta = np.ascontiguousarray(theta, dtype=np.float64)

@@ -255,6 +255,13 @@ module maniac_gpu
             type(c_ptr), intent(out) :: sites
             integer(c_int) :: rc
         end function
+        ! host threads the candidate loops inside submit / wait / commit may use (the calling driver's team)
+        function mgpu_set_host_team(e, n_threads) bind(C, name="mgpu_set_host_team") result(rc)
+            import :: c_ptr, c_int
+            type(c_ptr), value :: e
+            integer(c_int), value :: n_threads
+            integer(c_int) :: rc
+        end function
         ! mixed batches (moves, insertions, deletions); energies come back as rows of 5
         function mgpu_gcmc_trial_submit(e, lane, n, replica, t, m, kind, sites, site_stride) &
                 bind(C, name="mgpu_gcmc_trial_submit") result(rc)

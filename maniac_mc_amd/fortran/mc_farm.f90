@@ -856,6 +856,8 @@ contains
         F%lane_threads = n_drv > 1 .and. F%rng_kind /= 0 .and. .not. allocated(slog) .and. F%n_threads >= 2 * n_drv
         if (n_steps > 0 .and. F%lane_threads) then
             F%team = max(1, F%n_threads / n_drv)
+            rc = mgpu_set_host_team(F%engine, int(F%team, c_int))
+            if (rc /= MGPU_OK) return
             call omp_set_max_active_levels(2)
             rc_lane = MGPU_OK
             !$omp parallel num_threads(n_drv) private(d, g, step) proc_bind(spread)
@@ -877,6 +879,8 @@ contains
             if (rc == MGPU_OK) rc = mgpu_synchronize(F%engine)
         else if (n_steps > 0) then
             F%team = F%n_threads
+            rc = mgpu_set_host_team(F%engine, int(F%team, c_int))
+            if (rc /= MGPU_OK) return
             do g = 0, F%n_lanes - 1
                 rc = generate_and_submit(g)
                 if (rc /= MGPU_OK) return

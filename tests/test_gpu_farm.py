@@ -323,3 +323,80 @@ def test_device_decided_farm_is_the_host_decided_farm(case):
         assert np.max(np.abs(b.energy(r) - ref)) < farm_tol(ref, steps), (r, b.energy(r) - ref)
     for f in farms:
         f.close()
+
+
+def test_host_team_is_the_serial_loop():
+    """mgpu_set_host_team: the per-candidate loops inside submit / wait / commit cut into ranges run by an OpenMP team
+    (csrc/mgpu_engine.hip: for_parts).  Two engines on the same two-residue mixture, 1536 replicas, one with the
+    calling thread alone and one with a team of three (the ranges end inside the batch: 512-candidate ranges against
+    runs of kinds and types that do not): mixed batches of moves, insertions and deletions of both residue types give
+    the same energies bit for bit, the same commits (counts, coordinates, A(k)), and a refused batch names the same --
+    the lowest -- candidate."""
+    from maniac_mc_amd._lib import MGPU_CREATION, MGPU_DELETION, MGPU_MOVE
+    from maniac_mc_amd.engine import Engine
+    s = synth.mixture_box(seed=4)
+    R = 1536
+    engines = []
+    for team in (1, 3):
+        e = Engine.from_system(s, n_replicas=R, mol_capacity=[20, 16])
+        e.init_structure_factor(0, True)
+        for r in range(1, R):
+            e.replica_copy(r, 0)
+        e.set_host_team(team)
+        engines.append(e)
+    rng = np.random.default_rng(5)
+    n0 = [int(s.n_mol[0]), int(s.n_mol[1])]
+    results = []
+    for step in range(3):
+        t = rng.integers(0, 2, R).astype(np.int32)
+        kind = rng.choice([MGPU_MOVE, MGPU_MOVE, MGPU_CREATION, MGPU_DELETION], R).astype(np.int32)
+        rep = rng.permutation(R).astype(np.int32)
+        nm = np.array([engines[0].num_molecules(int(rep[c]), int(t[c])) for c in range(R)])
+        m = (rng.random(R) * np.minimum(nm, [n0[int(x)] for x in t])).astype(np.int32)       # a slot this script knows
+        sites = np.zeros((R, 3, 3))
+        for c in range(R):
+            base = s.all_sites(int(t[c]))[int(m[c])]
+            n1 = base.shape[0]
+            sites[c, :n1] = base + rng.uniform(-0.3, 0.3, 3)
+            if kind[c] == MGPU_CREATION:
+                sites[c, :n1] = base - base.mean(axis=0) + s.bounds_lo + rng.random(3) * np.diag(s.box_matrix)
+        acc = (rng.random(R) < 0.6).astype(np.int32)
+        out = []
+        for e in engines:
+            old, new = e.gcmc_trial(rep, t, m, kind, sites, lane=step % 2)
+            e.commit_lane(step % 2, rep, t, m, kind, acc)
+            out.append((old, new))
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]), step
+        results.append(out[0])
+    assert any(np.any(o != 0) for o, _ in results)
+    for r in (0, 1, 511, 512, 1023, 1024, R - 1):
+        for ty in (0, 1):
+            assert engines[0].num_molecules(r, ty) == engines[1].num_molecules(r, ty)
+            assert np.array_equal(engines[0].get_molecules(r, ty), engines[1].get_molecules(r, ty))
+        assert np.array_equal(engines[0].structure_factor(r), engines[1].structure_factor(r))
+    # a refused batch: candidates 700 and 1300 are both invalid; both engines name the lower one
+    rep = np.arange(R, dtype=np.int32)
+    t = np.zeros(R, np.int32)
+    kind = np.full(R, MGPU_MOVE, np.int32)
+    m = np.zeros(R, np.int32)
+    m[700] = 999
+    m[1300] = 998
+    sites = np.tile(s.all_sites(0)[0], (R, 1, 1))
+    msgs = []
+    for e in engines:
+        with pytest.raises(Exception) as ei:
+            e.gcmc_trial(rep, t, m, kind, sites)
+        msgs.append(str(ei.value))
+    assert msgs[0] == msgs[1] and "candidate 700" in msgs[0], msgs
+    # two accepted candidates for one replica (in different ranges of the team): refused by both, and a clean repeat passes
+    m[:] = 0
+    for e in engines:
+        e.gcmc_trial(rep, t, m, kind, sites)
+        bad = rep.copy()
+        bad[1400] = 3
+        with pytest.raises(Exception) as ei:
+            e.commit_lane(0, bad, t, m, kind, np.ones(R, np.int32), sites=sites)
+        assert "more than one accepted candidate" in str(ei.value)
+        e.commit_lane(0, rep, t, m, kind, np.ones(R, np.int32), sites=sites)
+    for e in engines:
+        e.close()

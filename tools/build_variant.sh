@@ -5,6 +5,6 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p maniac_mc_amd/variants
-hipcc --offload-arch=gfx950 -O3 -fPIC -shared -std=c++17 "$@" -o maniac_mc_amd/variants/libmaniac_hip_$name.so \
+hipcc --offload-arch=gfx950 -O3 -fPIC -shared -std=c++17 -fopenmp "$@" -o maniac_mc_amd/variants/libmaniac_hip_$name.so \
     maniac_mc_amd/csrc/mgpu_engine.hip maniac_mc_amd/csrc/mgpu_host_setup.cpp
 echo built maniac_mc_amd/variants/libmaniac_hip_$name.so

@@ -27,7 +27,7 @@ def main():
         del args[k:k + 2]
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "e.s")
-        p = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, SRC] + args,
+        p = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fopenmp", "-S", "--cuda-device-only", "-o", out, SRC] + args,
                            capture_output=True, text=True)
         if p.returncode != 0:
             sys.exit(p.stderr[-3000:])
