@@ -633,7 +633,7 @@ int launch_frozen(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items
     a = b = nullptr;
     if ((rc = prof_begin(e, ln, MGPU_KERNEL_PAIR, &a, &b))) return rc;      // counted with the pair sweep it completes
     hipExtLaunchKernelGGL(frozen_finalize_kernel, dim3((n_entries + 63) / 64), dim3(64), 0, ln.stream, a, b, 0,
-                          (const double2 *)d_scratch, n_entries, n_chunks, d_extra);
+                          (const double2 *)d_scratch, n_entries, (n_chunks + kPairWaves - 1) / kPairWaves, d_extra);
     if ((rc = prof_end(e, ln, MGPU_KERNEL_PAIR, a, b))) return rc;
     HIP_TRY(hipGetLastError());
     return MGPU_OK;

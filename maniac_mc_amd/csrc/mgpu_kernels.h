@@ -875,9 +875,9 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
 // sigma^2) of the candidate's sites against the atom's type are reloaded (LDS broadcast) only when the type changes: the
 // frozen layout keeps atoms of one type together.  The few OTHER atoms of a framework box (the adsorbates of each lane's
 // own replica) follow in the same wave with per-lane coordinates, so one kernel yields the item's whole pair energy.
-// Work = (item group, chunk); every (item, chunk) writes one partial (scratch laid out [chunk][entry])
-// {e_lj, e_coul} per state into `scratch`, and frozen_finalize_kernel adds a item's chunks in order -- one extra record
-// per entry for the host's ordered sum.  Items: PairItem of ONE residue type (the engine checks), unordered, orthorhombic.
+// Work = (item group, chunk); a workgroup adds the partials {e_lj, e_coul} of its eight chunks in chunk order and writes one
+// record per entry (scratch laid out [workgroup of the group][entry]); frozen_finalize_kernel adds an entry's records in
+// order -- one extra record per entry for the host's ordered sum.  Items: PairItem of ONE residue type (the engine checks), unordered, orthorhombic.
 // ------------------------------------------------------------------------------------------
 template <int NS, bool FUSED, bool FASTW>
 __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MGPU_PAIR_MINWAVES) void pair_frozen_kernel(
@@ -891,6 +891,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
     extern __shared__ __attribute__((aligned(16))) char s_coul[];     // (coul_last_row + 1) x 48 B
     __shared__ double2 s_pair[kMaxTypes * kMaxTypes];
     __shared__ double s_cand[NREG * 3 * 64];                          // the group's candidate sites, [site-state][x, y, z][lane]
+    __shared__ double2 s_part[kPairWaves * NST * 64];                 // the eight chunk partials of the group, [wave][state][lane]
     for (int i = threadIdx.x; i < (bx.coul_last_row + 1) * kCoulRowVec; i += kPairBlock)
         reinterpret_cast<double2 *>(s_coul)[i] = reinterpret_cast<const double2 *>(coul_tab_g)[i];
     const int nt = tp.n_types;
@@ -929,7 +930,8 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                                    : cand_sites[((size_t)(il.src < 0 ? 0 : il.src) * site_stride + a) * 3 + d];
         }
         __syncthreads();
-        if (chunk >= n_chunks) continue;                                    // (uniform per wave; the barriers are above)
+        do {
+        if (chunk >= n_chunks) break;                                       // (uniform per wave; the barriers are outside)
         const int item_id = grp * 64 + lane;
         const bool live = item_id < n_items;
         const PairItem it = items[live ? item_id : n_items - 1];
@@ -945,14 +947,14 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
             rz[sreg] = s_cand[(sreg * 3 + 2) * 64 + lane];
         }
         const int t_item = __builtin_amdgcn_readfirstlane(it.t);          // one residue type per launch
-        bool any_c = false;
+        bool any_c = false, q_on[NTY];                                    // uniform: one residue type per launch
 #pragma unroll
         for (int s = 0; s < NTY; ++s) {
             rq[s] = res_q[t_item * tp.max_atom + s];
             rty[s] = res_atype[t_item * tp.max_atom + s] * nt;
-            const bool on = fabs(rq[s]) >= kErrorTol;                     // energy_utils.f90:430
-            any_c = any_c || on;
-            rq[s] = on ? rq[s] : 0.0;
+            q_on[s] = fabs(rq[s]) >= kErrorTol;                           // energy_utils.f90:430
+            any_c = any_c || q_on[s];
+            rq[s] = q_on[s] ? rq[s] : 0.0;
         }
         // this chunk's atoms: one per lane
         const int a0 = chunk * chunk_atoms, na = min(chunk_atoms, n_atoms - a0);        // chunk_atoms <= 64
@@ -998,14 +1000,19 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                 unsigned sh_min = ~0u;
 #pragma unroll
                 for (int s = 0; s < NREG; ++s) {
-                    unsigned sh;
-                    g[s] = coul_lds(r2[s], coul_adj, sh);
-                    sh_min = min(sh_min, sh);
+                    // a site without charge (the oxygen of a four-site water) takes no table row: the reference skips the
+                    // pair (energy_utils.f90:430) and its sum is multiplied by q = 0 below
+                    g[s] = 0.0;
+                    if (q_on[s % NTY]) {
+                        unsigned sh;
+                        g[s] = coul_lds(r2[s], coul_adj, sh);
+                        sh_min = min(sh_min, sh);
+                    }
                 }
                 if (sh_min < (unsigned)bx.coul_idx_base) {   // r < 0.5 A for this lane: rare slow path
 #pragma unroll
                     for (int s = 0; s < NREG; ++s)
-                        if (r2[s] < kCoulSlowBelow) g[s] = coul_slow(r2[s], bx.alpha, false);
+                        if (q_on[s % NTY] && r2[s] < kCoulSlowBelow) g[s] = coul_slow(r2[s], bx.alpha, false);
                 }
 #pragma unroll
                 for (int s = 0; s < NREG; ++s) acc[s] = fma(qj, g[s], acc[s]);
@@ -1056,14 +1063,17 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                         unsigned sh_min = ~0u;
 #pragma unroll
                         for (int s = 0; s < NREG; ++s) {
-                            unsigned sh;
-                            g[s] = coul_lds(r2[s], coul_adj, sh);
-                            sh_min = min(sh_min, sh);
+                            g[s] = 0.0;
+                            if (q_on[s % NTY]) {
+                                unsigned sh;
+                                g[s] = coul_lds(r2[s], coul_adj, sh);
+                                sh_min = min(sh_min, sh);
+                            }
                         }
                         if (ok && sh_min < (unsigned)bx.coul_idx_base) {
 #pragma unroll
                             for (int s = 0; s < NREG; ++s)
-                                if (ok && r2[s] < kCoulSlowBelow) g[s] = coul_slow(r2[s], bx.alpha, false);
+                                if (ok && q_on[s % NTY] && r2[s] < kCoulSlowBelow) g[s] = coul_slow(r2[s], bx.alpha, false);
                         }
 #pragma unroll
                         for (int s = 0; s < NREG; ++s) acc[s] = ok ? fma(qj, g[s], acc[s]) : acc[s];
@@ -1084,13 +1094,29 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
                 }
             }
         }
-        if (live) {
 #pragma unroll
-            for (int st = 0; st < NST; ++st) {
-                double ec = 0.0;
+        for (int st = 0; st < NST; ++st) {
+            double ec = 0.0;
 #pragma unroll
-                for (int s = 0; s < NTY; ++s) ec = fma(rq[s], acc[st * NTY + s], ec);
-                scratch[(size_t)chunk * ((size_t)n_items * NST) + ((size_t)item_id * NST + st)] = make_double2(elj[st], ec);   // [chunk][entry]: the lanes' stores coalesce
+            for (int s = 0; s < NTY; ++s) ec = fma(rq[s], acc[st * NTY + s], ec);
+            s_part[(wave * NST + st) * 64 + lane] = make_double2(elj[st], ec);
+        }
+        } while (0);
+        // the workgroup's chunks summed in chunk order by one thread per (state, candidate): one record per entry and
+        // workgroup leaves for frozen_finalize_kernel, an eighth of the chunk records (sweep + finalize 58.2 -> 54.7 us at the
+        // bench's framework box)
+        __syncthreads();
+        const int wgc = b - grp * wg_per_group;
+        if ((int)threadIdx.x < NST * 64) {
+            const int st = threadIdx.x >> 6, id = grp * 64 + lane;
+            const int n_valid = min(kPairWaves, n_chunks - wgc * kPairWaves);
+            if (id < n_items) {
+                double ea = 0.0, eb = 0.0;
+                for (int wv = 0; wv < n_valid; ++wv) {
+                    const double2 pp = s_part[(wv * NST + st) * 64 + lane];
+                    ea += pp.x; eb += pp.y;
+                }
+                scratch[(size_t)wgc * ((size_t)n_items * NST) + ((size_t)id * NST + st)] = make_double2(ea, eb);   // [workgroup][entry]
             }
         }
     }
