@@ -797,7 +797,7 @@ def main():
             roof = {"bound": "valu", "basis": "algorithmic_flops", "bound_note": "fp64 vector issue (the contract's hbm / mfma do not apply: measured HBM-side "
                                                    "traffic is a fraction of the algorithmic bytes and there is no MFMA-shaped work; SURVEY 8(d))",
                     "kernel": "pair_frozen_kernel<4,...> (framework box: 64 candidates in the lanes of a wave against chunks of 32 framework atoms "
-                              "held as scalars, then each lane's own adsorbates; frozen_finalize_kernel adds the chunk partials)" if wl == "framework_water"
+                              "held as scalars, then each lane's own adsorbates; a group's last workgroup adds the chunk partials in order)" if wl == "framework_water"
                               else "pair_sweep_kernel<3,false,false,true,true> (old + new state of a trial move in one sweep, two-instruction fold)",
                     "achieved": job_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": job_tflops / FP64_VECTOR_PEAK_TFLOPS,

@@ -95,6 +95,7 @@ struct Lane {
     std::vector<int> ent_off, ent_stride, ent_ns;     // ... ent_ns[i] of them
     std::vector<char> ent_extra;          // entry i has an extra record (the framework part, pair_frozen_kernel) behind the energies
     DevBuf d_scratch;                     // chunk partials of pair_frozen_kernel
+    DevBuf d_tickets;                     // its per-group tickets: zero between launches (the kernel leaves them so)
     const RecipItem *d_trial_items = nullptr;   // RecipItems of the last trial, resident while last_trial_n != 0
     const RecipItem *h_trial_items = nullptr;   // their host image in h_in (valid until the next trial_submit)
     int trial_n1_max = 1;
@@ -117,6 +118,7 @@ struct Lane {
         if (commit_staged_ev) { (void)hipEventDestroy(commit_staged_ev); commit_staged_ev = nullptr; }
         d_items.release(); d_items2.release(); d_sites.release(); d_partials.release(); d_out.release();
         d_scratch.release();
+        d_tickets.release();
         h_in.release(); h_commit.release(); h_out.release();
     }
 };
@@ -590,7 +592,7 @@ int frozen_chunk_atoms(const mgpu_engine *e, int n_atoms) {
     return std::max(1, std::min(64, (n_atoms + n_slots - 1) / n_slots));
 }
 
-// The framework part of a launch segment, candidates in the lanes (pair_frozen_kernel + frozen_finalize_kernel): items of
+// The framework part of a launch segment, candidates in the lanes (pair_frozen_kernel): items of
 // ONE residue type with n1 register sites; one extra record {e_lj, e_coul} per entry lands in d_extra.
 int launch_frozen(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, int n1, int site_stride, bool fused, bool fast_fold,
                   int t_frozen, double2 *d_scratch, double2 *d_extra) {
@@ -602,15 +604,22 @@ int launch_frozen(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items
     const int n_wg_units = ((n_items + 63) / 64) * ((n_chunks + kPairWaves - 1) / kPairWaves);
     const bool ff = fast_fold && e->pair_fast_fold;
     hipEvent_t a = nullptr, b = nullptr;
-    int rc = prof_begin(e, ln, MGPU_KERNEL_PAIR, &a, &b);
-    if (rc) return rc;
+    int rc;
+    {
+        const size_t need = (size_t)((n_items + 63) / 64) * sizeof(int);
+        const void *before = ln.d_tickets.p;
+        if ((rc = ln.d_tickets.reserve(need))) return rc;
+        if (ln.d_tickets.p != before) HIP_TRY(hipMemsetAsync(ln.d_tickets.p, 0, ln.d_tickets.bytes, ln.stream));
+    }
+    if ((rc = prof_begin(e, ln, MGPU_KERNEL_PAIR, &a, &b))) return rc;
 #define MGPU_LAUNCH_FROZEN_1(NS, FU, FW)                                                                                \
     do {                                                                                                               \
         const int nb = resident_blocks<&pair_frozen_kernel<NS, FU, FW>>(ln, e->coul_bytes);                                \
         const int grid_f = std::max(1, std::min(n_wg_units, e->n_cu * nb));                                           \
         hipExtLaunchKernelGGL((pair_frozen_kernel<NS, FU, FW>), dim3(grid_f), dim3(kPairBlock), e->coul_bytes, ln.stream, a, b, 0, \
                               e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab,   \
-                              d_items, (const double *)ln.d_sites.p, site_stride, n_items, t_frozen, n_chunks, chunk_atoms, d_scratch); \
+                              d_items, (const double *)ln.d_sites.p, site_stride, n_items, t_frozen, n_chunks, chunk_atoms, d_scratch,    \
+                              (int *)ln.d_tickets.p, d_extra);                                                              \
     } while (0)
 #define MGPU_LAUNCH_FROZEN(NS)                                                                                          \
     do {                                                                                                               \
@@ -628,12 +637,6 @@ int launch_frozen(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items
     }
 #undef MGPU_LAUNCH_FROZEN
 #undef MGPU_LAUNCH_FROZEN_1
-    if ((rc = prof_end(e, ln, MGPU_KERNEL_PAIR, a, b))) return rc;
-    const int n_entries = n_items * (fused ? 2 : 1);
-    a = b = nullptr;
-    if ((rc = prof_begin(e, ln, MGPU_KERNEL_PAIR, &a, &b))) return rc;      // counted with the pair sweep it completes
-    hipExtLaunchKernelGGL(frozen_finalize_kernel, dim3((n_entries + 63) / 64), dim3(64), 0, ln.stream, a, b, 0,
-                          (const double2 *)d_scratch, n_entries, (n_chunks + kPairWaves - 1) / kPairWaves, d_extra);
     if ((rc = prof_end(e, ln, MGPU_KERNEL_PAIR, a, b))) return rc;
     HIP_TRY(hipGetLastError());
     return MGPU_OK;

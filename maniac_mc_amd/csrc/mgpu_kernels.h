@@ -876,15 +876,16 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
 // frozen layout keeps atoms of one type together.  The few OTHER atoms of a framework box (the adsorbates of each lane's
 // own replica) follow in the same wave with per-lane coordinates, so one kernel yields the item's whole pair energy.
 // Work = (item group, chunk); a workgroup adds the partials {e_lj, e_coul} of its eight chunks in chunk order and writes one
-// record per entry (scratch laid out [workgroup of the group][entry]); frozen_finalize_kernel adds an entry's records in
-// order -- one extra record per entry for the host's ordered sum.  Items: PairItem of ONE residue type (the engine checks), unordered, orthorhombic.
+// record per entry (scratch laid out [workgroup of the group][entry]); the group's last workgroup adds an entry's records in
+// workgroup order -- one extra record per entry for the host's ordered sum.  Items: PairItem of ONE residue type (the engine checks), unordered, orthorhombic.
 // ------------------------------------------------------------------------------------------
 template <int NS, bool FUSED, bool FASTW>
 __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MGPU_PAIR_MINWAVES) void pair_frozen_kernel(
     Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
     const char *__restrict__ coul_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
-    int site_stride, int n_items, int t_frozen, int n_chunks, int chunk_atoms, double2 *__restrict__ scratch) {
+    int site_stride, int n_items, int t_frozen, int n_chunks, int chunk_atoms, double2 *__restrict__ scratch,
+    int *__restrict__ tickets, double2 *__restrict__ extra) {
     constexpr int NTY = NS;
     constexpr int NST = FUSED ? 2 : 1;
     constexpr int NREG = NTY * NST;
@@ -892,6 +893,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
     __shared__ double2 s_pair[kMaxTypes * kMaxTypes];
     __shared__ double s_cand[NREG * 3 * 64];                          // the group's candidate sites, [site-state][x, y, z][lane]
     __shared__ double2 s_part[kPairWaves * NST * 64];                 // the eight chunk partials of the group, [wave][state][lane]
+    __shared__ int s_last;
     for (int i = threadIdx.x; i < (bx.coul_last_row + 1) * kCoulRowVec; i += kPairBlock)
         reinterpret_cast<double2 *>(s_coul)[i] = reinterpret_cast<const double2 *>(coul_tab_g)[i];
     const int nt = tp.n_types;
@@ -1103,42 +1105,42 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
         }
         } while (0);
         // the workgroup's chunks summed in chunk order by one thread per (state, candidate): one record per entry and
-        // workgroup leaves for frozen_finalize_kernel, an eighth of the chunk records (sweep + finalize 58.2 -> 54.7 us at the
-        // bench's framework box)
+        // workgroup, an eighth of the chunk records (sweep + finalize 58.2 -> 54.7 us at the bench's framework box) ...
         __syncthreads();
         const int wgc = b - grp * wg_per_group;
-        if ((int)threadIdx.x < NST * 64) {
-            const int st = threadIdx.x >> 6, id = grp * 64 + lane;
+        const int st_t = threadIdx.x >> 6, id_t = grp * 64 + lane;
+        const bool summing = (int)threadIdx.x < NST * 64 && id_t < n_items;
+        double2 *rec = scratch + ((size_t)id_t * NST + st_t);                        // + workgroup * n_items * NST: [workgroup][entry]
+        if (summing) {
             const int n_valid = min(kPairWaves, n_chunks - wgc * kPairWaves);
-            if (id < n_items) {
-                double ea = 0.0, eb = 0.0;
-                for (int wv = 0; wv < n_valid; ++wv) {
-                    const double2 pp = s_part[(wv * NST + st) * 64 + lane];
-                    ea += pp.x; eb += pp.y;
-                }
-                scratch[(size_t)wgc * ((size_t)n_items * NST) + ((size_t)id * NST + st)] = make_double2(ea, eb);   // [workgroup][entry]
+            double ea = 0.0, eb = 0.0;
+            for (int wv = 0; wv < n_valid; ++wv) {
+                const double2 pp = s_part[(wv * NST + st_t) * 64 + lane];
+                ea += pp.x; eb += pp.y;
             }
+            store_partial<true>(rec + (size_t)wgc * ((size_t)n_items * NST), ea, eb);
+        }
+        // ... and the group's LAST workgroup to get here adds the group's records in workgroup order into the entries'
+        // extra records (what a finalize kernel did in a launch of its own: 54.7 -> 53.7 us and one launch less).  Hand-off as in
+        // chain_window_kernel: agent-scope write-through stores, every storing wave waits for them, one lane per workgroup
+        // draws the group's ticket behind a barrier, the last one reads the records with agent-scope loads; it leaves the
+        // ticket at zero for the lane's next launch.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(&tickets[grp], 1) == wg_per_group - 1;
+        __syncthreads();
+        if (s_last) {
+            if (summing) {
+                double ea = 0.0, eb = 0.0;
+                for (int q = 0; q < wg_per_group; ++q) {
+                    const double *pr = reinterpret_cast<const double *>(rec + (size_t)q * ((size_t)n_items * NST));
+                    ea += load_sc1(pr); eb += load_sc1(pr + 1);
+                }
+                extra[(size_t)id_t * NST + st_t] = make_double2(ea, eb);
+            }
+            if (threadIdx.x == 0) __hip_atomic_store(&tickets[grp], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-}
-
-// ordered sum of an entry's chunk partials (pair_frozen_kernel) into its extra record
-__global__ void frozen_finalize_kernel(const double2 *__restrict__ scratch, int n_entries, int n_chunks, double2 *__restrict__ extra) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_entries) return;
-    double a = 0.0, b = 0.0;
-    // the adds keep chunk order; the loads of 16 chunks are in flight together (one at a time this was a 69-link latency
-    // chain: 20 us for a kernel that moves 3 MB)
-    int c = 0;
-    for (; c + 16 <= n_chunks; c += 16) {
-        double2 p[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) p[k] = scratch[(size_t)(c + k) * n_entries + i];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { a += p[k].x; b += p[k].y; }
-    }
-    for (; c < n_chunks; ++c) { const double2 p = scratch[(size_t)c * n_entries + i]; a += p.x; b += p.y; }
-    extra[i] = make_double2(a, b);
 }
 
 // Ordered sum of the split partials; Coulomb rescale e_coulomb * EPS0_INV_eVA / KB_eVK
