@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel register / spill / occupancy table of the HIP engine (cross-compiles for gfx950; no GPU needed).
 
-    python tools/kernel_resources.py [extra hipcc flags, e.g. -DMGPU_RECIP_EARLY_LOAD=1] [--filter substr]
+    python tools/kernel_resources.py [extra hipcc flags, e.g. -DMGPU_RECIP_MINWAVES=5] [--filter substr]
 """
 import os
 import re

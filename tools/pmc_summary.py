@@ -45,7 +45,7 @@ def main():
         for r in csv.DictReader(open(path)):
             k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").strip()
             dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
-    keep = [k for k in vals if "mgpu::" in k and ("pair_sweep" in k or "pair_flat" in k or "pair_frozen" in k or "frozen_finalize" in k or "recip" in k or "trial_k" in k)]
+    keep = [k for k in vals if "mgpu::" in k and ("pair_sweep" in k or "pair_flat" in k or "pair_frozen" in k or "recip" in k)]
     extra = (" " + os.environ.get("PMC_EXTRA", "")).rstrip()
     lines = [f"# rocprofv3 --pmc passes (separate runs, --kernel-trace only) of `python3 tools/bench_kernels.py --workload {wl} --reps 3 --replicas {repl}{extra}`, build {tag}, libmaniac_hip.so sha256 {sha[:16]}",
              "# per-dispatch means over the dispatches after each kernel's first; whole GPU", ""]
