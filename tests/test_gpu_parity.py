@@ -815,6 +815,44 @@ def test_framework_batch_kernel_matches_the_flat_sweep(three_site, refcpu_mod):
         e.close()
 
 
+def test_framework_batch_results_do_not_depend_on_the_batch():
+    """pair_frozen_kernel cuts the framework into chunks whose partials are summed in a fixed order (eight chunks per
+    workgroup in LDS, then the workgroups of a candidate group by the group's last one): the chunking follows from the
+    framework's size alone, so a candidate's energies are the same BITS whether it is evaluated alone, among 7 or among
+    200 others, in whatever lane and position -- the property that lets a chain be batched any way.  640 framework atoms
+    = 24 chunks of 27 (three workgroups per group, the last partly filled); 200 replicas with one candidate each
+    (moves, insertions, deletions of the 4-site water: single-state items; an uncharged oxygen, so one site takes no
+    Coulomb row)."""
+    s = synth.framework_water_box(n_water=12, n_frame=640, L=26.0, seed=8)
+    R = 200
+    eng = Engine.from_system(s, n_replicas=R)
+    eng.init_structure_factor(0, True)
+    for r in range(1, R):
+        eng.replica_copy(r, 0)
+    rng = np.random.default_rng(17)
+    L = np.diag(s.box_matrix)
+    n = int(s.n_mol[1])
+    base = s.all_sites(1)
+    m = rng.integers(0, n, R).astype(np.int32)
+    kinds = rng.choice([MGPU_MOVE, MGPU_CREATION, MGPU_DELETION], R).astype(np.int32)
+    cand = base[m] + rng.uniform(-0.4, 0.4, (R, 1, 3))
+    cr = kinds == MGPU_CREATION
+    cand[cr] = base[m[cr]] - base[m[cr]].mean(axis=1, keepdims=True) + (s.bounds_lo + L * rng.uniform(0.05, 0.95, (int(cr.sum()), 3)))[:, None, :]
+    rep = np.arange(R, dtype=np.int32)
+    tt = np.ones(R, np.int32)
+    old_all, new_all = eng.gcmc_trial(rep, tt, m, kinds, cand)
+    assert np.any(old_all != 0) and np.any(new_all != 0)
+    for lo, hi, lane in ((0, 1, 0), (1, 8, 1), (8, 73, 2), (73, 200, 3), (137, 138, 0)):
+        sl = slice(lo, hi)
+        o, w = eng.gcmc_trial(rep[sl], tt[sl], m[sl], kinds[sl], cand[sl], lane=lane)
+        assert np.array_equal(o, old_all[sl]) and np.array_equal(w, new_all[sl]), (lo, hi)
+    # ... and in another order
+    perm = rng.permutation(R)
+    o, w = eng.gcmc_trial(rep[perm], tt[perm], m[perm], kinds[perm], cand[perm])
+    assert np.array_equal(o, old_all[perm]) and np.array_equal(w, new_all[perm])
+    eng.close()
+
+
 def test_a_committed_framework_move_switches_the_batch_kernel_off():
     """pair_frozen_kernel sweeps replica 0's copy of the framework for every replica, which is only right while all
     replicas hold that copy.  set_molecules / replica_copy track it; so must a COMMIT that moves the framework on one
