@@ -57,8 +57,9 @@ extern "C" {
  *   MGPU_NO_FROZEN_BATCH=1      framework boxes keep one wave per candidate (pair_flat_kernel) instead of 64 candidates
  *                               per wave against chunks of the framework (pair_frozen_kernel; default where exactly one
  *                               frozen residue type exists and it is identical in every replica)
- *   MGPU_FROZEN_CHUNK=<n>       framework atoms per pair_frozen_kernel chunk, 1..64 (engine constant, default 32; the
- *                               chunk partials are summed in chunk order, so results are reproducible per value)
+ *   MGPU_FROZEN_CHUNK=<n>       framework atoms per pair_frozen_kernel chunk, 1..64 (default: from the framework's size
+ *                               alone -- the fewest multiple-of-eight chunks of <= 30 atoms; never from the batch: the
+ *                               chunk partials are summed in a fixed order, so results are reproducible per value)
  *   MGPU_PAIR_FUSE_MAX=<n>      largest molecule whose trial moves sweep old + new state in one pass (default 3; 4 and
  *                               5 select kernels of up to 256 VGPRs at half the occupancy: measured slower)
  * Threading rule: the per-lane asynchronous entry points (mgpu_*_submit, mgpu_*_wait, mgpu_commit_submit,
