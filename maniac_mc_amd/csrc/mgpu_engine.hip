@@ -389,7 +389,8 @@ bool replica_in_range(const mgpu_engine *e, int replica) {
 // persistent and stride over the n_items * nsplit work units, so a constant costs nothing when a launch has
 // more work units than resident waves.  Policy: never fewer than ~8 sweep units per wave.  A farm engine (>= 256
 // replicas) aims at one or two work units per resident wave for the launches a farm makes (a quarter to a half of
-// the replicas per launch): n_cu * 64 / n_replicas rounded down to a power of two, between 1 and 4 -- 4 at 2048
+// the replicas per launch): n_cu * 64 / n_replicas rounded down to a power of two, between 1 and 4 (up to 16 below 1024
+// chains, see below) -- 4 at 2048
 // replicas, 2 at 8192 (measured at the 10 125-atom box, 1024 fused items per launch: 4 -> 98.9 us, 8 -> 104.6 us,
 // 16 -> 116 us; 2048 items per launch on four lanes: 2 -> 6.94 M, 4 -> 6.79 M, 8 -> 6.52 M accepted moves/s).
 // A small engine (< 256 replicas: single chains, a handful of chains) is latency-bound: up to 32 waves per item, two sweep
@@ -410,8 +411,13 @@ int engine_nsplit(const mgpu_engine *e) {
         // candidate) are dominated by their tail: twice the waves per item fill the last round (round 3, framework box,
         // 3064 items per launch on 4096 resident waves: nsplit 2 = 1.5 rounds of 19 units, nsplit 4 = 3 rounds of 10)
         if (units <= 128) want *= 2;
+        // Below 1024 chains a launch (half the chains on two lanes) leaves most of the GPU idle at 4 waves per item and is
+        // a latency chain per step: a quarter of `want`, up to 16 (round 4, 10 125-atom box, two lanes, accepted moves/s at
+        // nsplit 4 / 8 / 16 / 32: 256 chains 0.99 / 1.24 / 1.42 / 1.37 M, 512: 1.96 / 2.40 / 2.37 / 2.12 M,
+        // 1024: 4.84 / 4.66 / 3.35 / 3.07 M, 2048: 6.00 / 5.77 / 4.29 / 3.71 M)
+        const int cap_want = e->n_replicas >= 1024 ? std::min(want, 4) : std::min(want / 4, 16);
         cap_split = 1;
-        while (cap_split * 2 <= std::min(want, 4)) cap_split *= 2;
+        while (cap_split * 2 <= cap_want) cap_split *= 2;
     }
     int ns = std::max(1, std::min(units / per_wave, cap_split));
     if (const char *ov = std::getenv("MGPU_PAIR_NSPLIT")) ns = std::max(1, std::min(std::atoi(ov), std::max(1, units)));
