@@ -1768,10 +1768,16 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
     // the energy sweeps request their first chunks of A(k) under the table phases; the commit, whose registers buy it a
     // fifth workgroup per CU, after them (measured at the SPC/E box: 40.9 us against 44.3 at four and 70 with spills)
     RecipInFlight<recip_chunk_tasks<COMMIT>()> inflight;
+    // An energy sweep's waves issue at raised priority while they build their tables (short, arithmetic, and what stands
+    // between the workgroup and its streaming pass) and at the default during the pass, where they mostly wait for A(k):
+    // the six workgroups of a CU fall out of step sooner.  SPC/E box 38.2 -> 36.7-37.6 us on three boxes (0.54 -> 0.55-0.56 of
+    // HBM peak), CO2 box 34.6 -> 34.5-34.9, framework box unchanged; raised priority for the PASS instead: 37.6 / 34.2.
+    if (!COMMIT) __builtin_amdgcn_s_setprio(3);
     recip_rows_tables(tp, bx, pos, res_q, rows, n_rows, it, cand_row, v, tid, true,
                       [&] { if (!COMMIT) recip_rows_prefetch<COMMIT>(inflight, trj, tw, n_tasks, A, tid); });
     if (COMMIT) recip_rows_prefetch<COMMIT>(inflight, trj, tw, n_tasks, A, tid);
     double acc = 0.0, acc0 = 0.0;
+    if (!COMMIT) __builtin_amdgcn_s_setprio(0);
     recip_rows_pass<COMMIT, BOTH>(v, trj, tw, n_tasks, A, tid, inflight, acc, acc0);
 
     if (!COMMIT) {
