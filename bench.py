@@ -695,7 +695,7 @@ def main():
     evals_now = evals_done() - evals0
     counts = None
     if wl == "spce":
-        hist = exchange.molecule_count_histogram([int(system.n_mol[0])] * R, nbins)
+        hist = exchange.molecule_count_histogram(np.full(R, int(system.n_mol[0]), dtype=np.int64), nbins)   # (an array: a 16 384-element Python list cost 0.8 ms of the timed region)
     else:
         counts = farm.counts()[:, 0]
         if wl == "co2_isotherm":

@@ -71,10 +71,8 @@ def max_over_ranks(value: float) -> float:
 
 def molecule_count_histogram(counts, nbins):
     """Histogram of the replicas' current molecule counts (the uptake histogram of an isotherm point)."""
-    h = np.zeros(nbins, dtype=np.int64)
     c = np.clip(np.asarray(counts, dtype=np.int64), 0, nbins - 1)
-    np.add.at(h, c, 1)
-    return h
+    return np.bincount(c, minlength=nbins).astype(np.int64, copy=False)
 
 
 class CAbiComm:
