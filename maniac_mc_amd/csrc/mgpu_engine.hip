@@ -625,7 +625,7 @@ int launch_frozen(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items
         hipExtLaunchKernelGGL((pair_frozen_kernel<NS, FU, FW>), dim3(grid_f), dim3(kPairBlock), e->coul_bytes, ln.stream, a, b, 0, \
                               e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab,   \
                               d_items, (const double *)ln.d_sites.p, site_stride, n_items, t_frozen, n_chunks, chunk_atoms, d_scratch,    \
-                              (int *)ln.d_tickets.p, d_extra);                                                              \
+                              (int *)ln.d_tickets.p, d_extra, (const double *)e->tp.slot_q, (const int *)e->tp.slot_ty);        \
     } while (0)
 #define MGPU_LAUNCH_FROZEN(NS)                                                                                          \
     do {                                                                                                               \

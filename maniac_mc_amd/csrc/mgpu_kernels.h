@@ -885,7 +885,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
     const char *__restrict__ coul_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
     int site_stride, int n_items, int t_frozen, int n_chunks, int chunk_atoms, double2 *__restrict__ scratch,
-    int *__restrict__ tickets, double2 *__restrict__ extra) {
+    int *__restrict__ tickets, double2 *__restrict__ extra, const double *__restrict__ slot_q, const int *__restrict__ slot_ty) {
     constexpr int NTY = NS;
     constexpr int NST = FUSED ? 2 : 1;
     constexpr int NREG = NTY * NST;
@@ -907,8 +907,9 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
     // the framework's atoms: every molecule of the frozen type of replica 0 (identical in all replicas)
     const int n_atoms = nmol[t_frozen] * tp.n1[t_frozen];
     const double *fx = pos + tp.seg_off[t_frozen], *fy = fx + tp.n_cap_atoms, *fz = fy + tp.n_cap_atoms;
-    const double *fq = tp.slot_q + tp.seg_off[t_frozen];
-    const int *fty = tp.slot_ty + tp.seg_off[t_frozen];
+    // (tp.slot_q / tp.slot_ty again as read-only arguments of their own: only those become scalar loads)
+    const double *__restrict__ fq = slot_q + tp.seg_off[t_frozen];
+    const int *__restrict__ fty = slot_ty + tp.seg_off[t_frozen];
 
     // A workgroup takes ONE group of 64 candidates and eight of its chunks (one per wave).  The candidates' sites -- per
     // lane a different replica: 64 separate cache lines per load -- are gathered ONCE per workgroup into LDS, each thread
@@ -958,13 +959,8 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
             any_c = any_c || q_on[s];
             rq[s] = q_on[s] ? rq[s] : 0.0;
         }
-        // this chunk's atoms: one per lane
+        // this chunk's atoms
         const int a0 = chunk * chunk_atoms, na = min(chunk_atoms, n_atoms - a0);        // chunk_atoms <= 64
-        const int ja = a0 + (lane < na ? lane : 0);
-        const double ax = fx[ja], ay = fy[ja], az = fz[ja];
-        double aq = fq[ja];
-        aq = fabs(aq) >= kErrorTol ? aq : 0.0;
-        const int aty = fty[ja];
 
         double acc[NREG], elj[NST];
 #pragma unroll
@@ -977,11 +973,15 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
 #pragma unroll
         for (int s = 0; s < NTY; ++s) { e4[s] = 0.0; sg2[s] = 0.0; lj_on[s] = false; }
         for (int k = 0; k < na; ++k) {
-            const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ax), k), __builtin_amdgcn_readlane(__double2loint(ax), k));
-            const double yj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ay), k), __builtin_amdgcn_readlane(__double2loint(ay), k));
-            const double zj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(az), k), __builtin_amdgcn_readlane(__double2loint(az), k));
-            const double qj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(aq), k), __builtin_amdgcn_readlane(__double2loint(aq), k));
-            const int tyj = __builtin_amdgcn_readlane(aty, k);
+            // the framework atom as SCALARS: x, y, z, q and type through the scalar cache (the arrays are read-only kernel
+            // arguments and the index is uniform), no vector instruction spent on broadcasting them (round 4: nine
+            // v_readlane per atom before; 53.9 -> 51.5 us; with the next atom's five loads requested a step ahead the scalar
+            // registers spill: 52.9)
+            const int jk = __builtin_amdgcn_readfirstlane(a0 + k);
+            const double xj = fx[jk], yj = fy[jk], zj = fz[jk];
+            double qj = fq[jk];
+            qj = fabs(qj) >= kErrorTol ? qj : 0.0;
+            const int tyj = fty[jk];
             if (tyj != cur_ty) {                                            // rare: the atoms are sorted by type
                 cur_ty = tyj;
 #pragma unroll
