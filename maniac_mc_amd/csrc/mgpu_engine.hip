@@ -202,6 +202,7 @@ struct mgpu_engine {
     bool pair_flat = false;
     int *d_atom_res = nullptr, *d_atom_mol = nullptr;
     double *d_atom_q = nullptr;
+    double *d_atom_q_on = nullptr;   // the same with charges below CoulombEnergy's threshold set to zero (pair_frozen_kernel's scalars)
     double2 *d_phase_tab = nullptr;  // [ktot][Ncap] scratch for S(k)
     double2 *d_S = nullptr;          // [Nk] scratch
     // lane 0 doubles as the synchronous path's stream and scratch
@@ -625,7 +626,7 @@ int launch_frozen(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items
         hipExtLaunchKernelGGL((pair_frozen_kernel<NS, FU, FW>), dim3(grid_f), dim3(kPairBlock), e->coul_bytes, ln.stream, a, b, 0, \
                               e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab,   \
                               d_items, (const double *)ln.d_sites.p, site_stride, n_items, t_frozen, n_chunks, chunk_atoms, d_scratch,    \
-                              (int *)ln.d_tickets.p, d_extra, (const double *)e->tp.slot_q, (const int *)e->tp.slot_ty);        \
+                              (int *)ln.d_tickets.p, d_extra, (const double *)e->d_atom_q_on, (const int *)e->tp.slot_ty);     \
     } while (0)
 #define MGPU_LAUNCH_FROZEN(NS)                                                                                          \
     do {                                                                                                               \
@@ -1055,6 +1056,7 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     HIP_TRY_E(hipMalloc(&e->d_atom_res, ncap * sizeof(int)));
     HIP_TRY_E(hipMalloc(&e->d_atom_mol, ncap * sizeof(int)));
     HIP_TRY_E(hipMalloc(&e->d_atom_q, ncap * sizeof(double)));
+    HIP_TRY_E(hipMalloc(&e->d_atom_q_on, ncap * sizeof(double)));
     HIP_TRY_E(hipMalloc(&e->d_phase_tab, (size_t)ktot * ncap * sizeof(double2)));
     HIP_TRY_E(hipMalloc(&e->d_S, e->n_slots * sizeof(double2)));
     HIP_TRY_E(hipMemset(e->d_S, 0, e->n_slots * sizeof(double2)));
@@ -1080,6 +1082,12 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     HIP_TRY_E(hipMemcpy(e->d_atom_res, a_res.data(), ncap * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY_E(hipMemcpy(e->d_atom_mol, a_mol.data(), ncap * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY_E(hipMemcpy(e->d_atom_q, a_q.data(), ncap * sizeof(double), hipMemcpyHostToDevice));
+    {
+        std::vector<double> a_q_on(a_q);
+        for (double &q : a_q_on)
+            if (!(std::fabs(q) >= kErrorTol)) q = 0.0;                   // energy_utils.f90:430
+        HIP_TRY_E(hipMemcpy(e->d_atom_q_on, a_q_on.data(), ncap * sizeof(double), hipMemcpyHostToDevice));
+    }
 #undef HIP_TRY_E
     e->self_of_type.resize(n_res);
     for (int t = 0; t < n_res; ++t) e->self_of_type[t] = self_energy_host(e, t);
@@ -1093,7 +1101,7 @@ int mgpu_engine_destroy(mgpu_engine *e) {
     for (auto &ln : e->lanes) if (ln.stream) (void)hipStreamSynchronize(ln.stream);
     for (void *p : {(void *)e->d_pos, (void *)e->d_nmol, (void *)e->d_A, (void *)e->d_kpack, (void *)e->d_kw,
                     (void *)e->d_pair_tab, (void *)e->d_coul_tab, (void *)e->d_res_q, (void *)e->d_res_atype, (void *)e->d_atom_res,
-                    (void *)e->d_atom_mol, (void *)e->d_atom_q, (void *)e->d_phase_tab, (void *)e->d_S, (void *)e->d_trj,
+                    (void *)e->d_atom_mol, (void *)e->d_atom_q, (void *)e->d_atom_q_on, (void *)e->d_phase_tab, (void *)e->d_S, (void *)e->d_trj,
                     (void *)e->d_tw, (void *)e->d_kslot, (void *)e->d_rrows, (void *)e->d_atom_ty, (void *)e->d_com, (void *)e->d_off})
         if (p) (void)hipFree(p);
     e->h_stage.release();

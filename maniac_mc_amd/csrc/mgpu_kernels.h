@@ -885,7 +885,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
     const char *__restrict__ coul_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
     int site_stride, int n_items, int t_frozen, int n_chunks, int chunk_atoms, double2 *__restrict__ scratch,
-    int *__restrict__ tickets, double2 *__restrict__ extra, const double *__restrict__ slot_q, const int *__restrict__ slot_ty) {
+    int *__restrict__ tickets, double2 *__restrict__ extra, const double *__restrict__ slot_q_on, const int *__restrict__ slot_ty) {
     constexpr int NTY = NS;
     constexpr int NST = FUSED ? 2 : 1;
     constexpr int NREG = NTY * NST;
@@ -907,8 +907,9 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
     // the framework's atoms: every molecule of the frozen type of replica 0 (identical in all replicas)
     const int n_atoms = nmol[t_frozen] * tp.n1[t_frozen];
     const double *fx = pos + tp.seg_off[t_frozen], *fy = fx + tp.n_cap_atoms, *fz = fy + tp.n_cap_atoms;
-    // (tp.slot_q / tp.slot_ty again as read-only arguments of their own: only those become scalar loads)
-    const double *__restrict__ fq = slot_q + tp.seg_off[t_frozen];
+    // (the slots' charges -- those below CoulombEnergy's threshold already zero -- and types as read-only arguments of
+    //  their own: only those become scalar loads; tp.slot_q / tp.slot_ty are members of a by-value struct)
+    const double *__restrict__ fq = slot_q_on + tp.seg_off[t_frozen];
     const int *__restrict__ fty = slot_ty + tp.seg_off[t_frozen];
 
     // A workgroup takes ONE group of 64 candidates and eight of its chunks (one per wave).  The candidates' sites -- per
@@ -979,8 +980,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
             // registers spill: 52.9)
             const int jk = __builtin_amdgcn_readfirstlane(a0 + k);
             const double xj = fx[jk], yj = fy[jk], zj = fz[jk];
-            double qj = fq[jk];
-            qj = fabs(qj) >= kErrorTol ? qj : 0.0;
+            const double qj = fq[jk];                                     // (thresholded on the host: zero below 1e-10)
             const int tyj = fty[jk];
             if (tyj != cur_ty) {                                            // rare: the atoms are sorted by type
                 cur_ty = tyj;
