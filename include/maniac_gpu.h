@@ -90,7 +90,10 @@ typedef struct mgpu_engine mgpu_engine;
 /* Message of the last failing call made by this thread ("" if none). */
 const char *mgpu_last_error(void);
 
-/* Library ABI version (bumped on any signature change). */
+/* Library ABI version (bumped on any signature change; a binding compares mgpu_abi_version() with the MGPU_ABI_VERSION
+ * it was built against).  2: chain windows, farm windows, comm, host team, formatter and phase-factor exports; the
+ * reciprocal update takes molecules of any size. */
+#define MGPU_ABI_VERSION 2
 int mgpu_abi_version(void);
 
 /* Number of visible HIP devices; MGPU_ERR_NO_DEVICE if the runtime reports none. */

@@ -12,10 +12,11 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmaniac_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["mgpu_engine.hip", "mgpu_host_setup.cpp", "mgpu_comm.cpp"]
-HEADERS = ["mgpu_kernels.h", "mgpu_internal.h"]
+SOURCES = ["mgpu_engine.hip", "mgpu_launch.hip", "mgpu_lanes.hip", "mgpu_windows.hip", "mgpu_host_setup.cpp", "mgpu_comm.cpp"]
+HEADERS = ["mgpu_kernels.h", "mgpu_internal.h", "mgpu_engine.h"]
 
 MGPU_OK = 0
+ABI_VERSION = 2          # include/maniac_gpu.h MGPU_ABI_VERSION: the library must report exactly this
 MGPU_MOVE, MGPU_CREATION, MGPU_DELETION, MGPU_NONE = 0, 1, 2, 3
 KERNEL_PAIR, KERNEL_RECIP, KERNEL_COMMIT, KERNEL_SFACTOR = 0, 1, 2, 3
 
@@ -52,10 +53,26 @@ def build(force: bool = False, verbose: bool = False) -> str:
             return LIB_PATH
     # RCCL (librccl, /opt/rocm/lib) carries the path's one collective (mgpu_comm.cpp)
     # -fopenmp: the host-side candidate loops of submit / wait / commit can use the caller's OpenMP team (libomp, as amdflang's)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-fopenmp", "-o", LIB_PATH] + srcs + \
+    # the translation units are compiled side by side (each instantiates the kernels it launches), then linked
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = os.path.join(_HERE, "..", "build", "hip_obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fopenmp"]
+
+    def compile_one(src):
+        obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
+        cmd = ["hipcc"] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), max(1, (os.cpu_count() or 2) // 2))) as pool:
+        objs = list(pool.map(compile_one, srcs))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-fopenmp", "-o", LIB_PATH] + objs + \
           ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB_PATH
 
@@ -72,11 +89,14 @@ def lib():
                                "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback")
         L = C.CDLL(LIB_PATH)
         L.mgpu_last_error.restype = C.c_char_p
+        L.mgpu_abi_version.restype = C.c_int
+        if L.mgpu_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {L.mgpu_abi_version()}, this package binds version {ABI_VERSION}: "
+                               "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
         for name in EXPORTS:
-            # (an A/B library of an earlier build -- tools/bench_kernels.py with MANIAC_HIP_LIB -- may lack newer symbols;
-            #  tests/test_host_setup.py checks that the in-tree library exports every one)
-            if name not in ("mgpu_last_error", "mgpu_host_prefetch") and hasattr(L, name):
-                getattr(L, name).restype = C.c_int
+            if name in ("mgpu_last_error", "mgpu_host_prefetch"):
+                continue
+            getattr(L, name).restype = C.c_int          # a missing export raises here, not at first use
         _lib = L
     return _lib
 

@@ -1,0 +1,210 @@
+// One-launch windows (include/maniac_gpu.h): a window of speculative steps of ONE chain (mgpu_chain_window) and one step of a
+// FARM of chains (mgpu_farm_window_*): evaluation, acceptance and commit in a single kernel, results through pinned host
+// memory the host polls.
+#include "mgpu_engine.h"
+
+extern "C" {
+
+// ---- single-chain windows --------------------------------------------------------------------
+
+// largest window the engine accepts, 0 where the one-launch path does not apply (triclinic box, molecules of more than
+// kMaxFusedSitesWide sites among the active types, per-k reciprocal form)
+static int chain_max_candidates(const mgpu_engine *e) {
+    if (e->bx.triclinic) return 0;
+    int n1_max = 1;
+    for (int t = 0; t < e->tp.n_res; ++t) {
+        if (!e->is_active[t]) continue;
+        if (e->tp.n1[t] > kMaxFusedSitesWide || e->tp.site_major[t]) return 0;
+        n1_max = std::max(n1_max, e->tp.n1[t]);
+    }
+    if (!recip_by_rows(e, n1_max)) return 0;
+    if (e->coul_bytes > 64 * 1024) return 0;
+    // the resolving workgroup stages every split partial of the window in LDS: 2 entries per candidate at most
+    const int by_lds = (int)((size_t)64 * 1024 / ((size_t)2 * e->pair_nsplit * sizeof(double2)));
+    return std::max(0, std::min(kChainMaxCand, by_lds));
+}
+
+int mgpu_chain_window_capacity(const mgpu_engine *e, int *max_candidates) {
+    if (!e || !max_candidates) return set_error(MGPU_ERR_INVALID_ARG, "chain_window_capacity: null argument");
+    *max_candidates = chain_max_candidates(e);
+    return MGPU_OK;
+}
+
+int mgpu_chain_set_margin(mgpu_engine *e, double relative_margin) {
+    if (!e || !(relative_margin >= 0.0)) return set_error(MGPU_ERR_INVALID_ARG, "chain_set_margin: bad argument");
+    e->chain.margin = relative_margin;
+    return MGPU_OK;
+}
+
+int mgpu_chain_set_timing(mgpu_engine *e, int on) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    e->chain.timing = on != 0;
+    return MGPU_OK;
+}
+
+// Stage times of the LAST window in microseconds since its first workgroup started (100 MHz wall clock of the device):
+//   us[0..3]   k role of candidate 0: start, phase tables built, k sweep summed, at the ticket
+//   us[4..7]   first pair workgroup:  start, Coulomb table staged, its work units swept, at the ticket
+//   us[8..14]  resolving workgroup:   last ticket drawn, acquire fence, partials reduced, decided, tag published,
+//                                     commit tables built, commit done (the last two 0 when nothing was accepted)
+int mgpu_chain_get_timing(mgpu_engine *e, double us[15]) {
+    if (!e || !us) return set_error(MGPU_ERR_INVALID_ARG, "chain_get_timing: null argument");
+    if (!e->chain.h_out) return set_error(MGPU_ERR_STATE, "chain_get_timing: no window has run");
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->lanes[0].stream));      // the commit's stamps are written behind the tag
+    const long long *ts = (const long long *)(e->chain.h_out + 10 * kChainMaxCand + 2);
+    const long long t0 = std::min(ts[0], ts[kChainStamps]);
+    const int first = ((const int *)(e->chain.h_out + 10 * (size_t)kChainMaxCand))[0];
+    int k = 0;
+    for (int i = 0; i < 4; ++i) us[k++] = (double)(ts[i] - t0) * 0.01;
+    for (int i = 0; i < 4; ++i) us[k++] = (double)(ts[kChainStamps + i] - t0) * 0.01;
+    for (int i = 0; i < 7; ++i) us[k++] = (i >= 5 && first < 0) ? 0.0 : (double)(ts[2 * kChainStamps + i] - t0) * 0.01;
+    return MGPU_OK;
+}
+
+int mgpu_chain_get_stats(const mgpu_engine *e, long long *windows, long long *undecided) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    if (windows) *windows = e->chain.windows;
+    if (undecided) *undecided = e->chain.undecided;
+    return MGPU_OK;
+}
+
+int mgpu_chain_window(mgpu_engine *e, int replica, int n, const int *t, const int *m, const int *kind, const int *link,
+                      const double *sites, int site_stride, const double *accept_u, const double *accept_pref,
+                      double temperature, double recip_energy, double *old_energy, double *new_energy, int *first_accepted,
+                      int *undecided) {
+    if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
+    if (!t || !m || !kind || !link || !sites || !accept_u || !accept_pref || !old_energy || !new_energy || !first_accepted || !undecided)
+        return set_error(MGPU_ERR_INVALID_ARG, "chain_window: null argument");
+    const int n_max = chain_max_candidates(e);
+    if (n_max == 0) return set_error(MGPU_ERR_STATE, "chain_window: not available for this engine (mgpu_chain_window_capacity)");
+    if (n < 1 || n > n_max) return set_error(MGPU_ERR_INVALID_ARG, "chain_window: window size out of range");
+    if (replica < 0 || replica >= e->n_replicas) return set_error(MGPU_ERR_INVALID_ARG, "chain_window: replica out of range");
+    if (!(temperature > 0.0)) return set_error(MGPU_ERR_INVALID_ARG, "chain_window: temperature must be positive");
+    int rc = use_device(e);
+    if (rc) return rc;
+    Lane &ln = e->lanes[0];
+    if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "chain_window: lane 0 still holds an un-waited trial");
+    mgpu_engine::Chain &ch = e->chain;
+    if (!ch.h_tag) {
+        HIP_TRY(hipHostMalloc((void **)&ch.h_out, sizeof(double) * (10 * kChainMaxCand + 2 + 3 * kChainStamps), hipHostMallocCoherent));
+        std::memset(ch.h_out, 0, sizeof(double) * (10 * kChainMaxCand + 2 + 3 * kChainStamps));
+        HIP_TRY(hipHostMalloc((void **)&ch.h_tag, 64, hipHostMallocCoherent));
+        *ch.h_tag = 0;
+        HIP_TRY(hipMalloc((void **)&ch.d_res, sizeof(ChainResult) * kChainMaxCand));
+        HIP_TRY(hipMalloc((void **)&ch.d_part, sizeof(double2) * 2 * kChainMaxCand * (size_t)e->pair_nsplit));
+        HIP_TRY(hipMalloc((void **)&ch.d_ticket, sizeof(int)));
+        HIP_TRY(hipMemset(ch.d_ticket, 0, sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&ch.d_topo, sizeof(Topo)));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    if (ch.topo_stale) {
+        if ((rc = sync_lane(e, ln))) return rc;
+        HIP_TRY(hipMemcpy(ch.d_topo, &e->tp, sizeof(Topo), hipMemcpyHostToDevice));
+        ch.topo_stale = false;
+    }
+    // ---- the window travels in the kernel arguments
+    ChainArgs g{};
+    bool fast = replica_in_range(e, replica);
+    char cand_ok[kChainMaxCand];
+    int n1_max = 1, n_ent = 0;
+    for (int c = 0; c < n; ++c) {
+        const int k = kind[c];
+        if (k < MGPU_MOVE || k > MGPU_DELETION) return set_error(MGPU_ERR_INVALID_ARG, "chain_window: unknown candidate kind");
+        if (t[c] < 0 || t[c] >= e->tp.n_res) return set_error(MGPU_ERR_INVALID_ARG, "chain_window: residue type out of range");
+        const int n1 = e->tp.n1[t[c]];
+        if (n1 > site_stride || n1 > kMaxFusedSitesWide || e->tp.site_major[t[c]])
+            return set_error(MGPU_ERR_INVALID_ARG, "chain_window: molecule too large for the one-launch path");
+        const size_t idx = (size_t)replica * e->tp.n_res + t[c];
+        if (e->d_com && e->frames_ok[idx])
+            return set_error(MGPU_ERR_STATE, "chain_window: this replica holds molecule frames (mgpu_replica_set_frames)");
+        const int lk = link[c];
+        if (lk < -2 || lk >= n) return set_error(MGPU_ERR_INVALID_ARG, "chain_window: bad link");
+        if (lk >= 0 && (k != MGPU_DELETION || link[lk] != -2 || kind[lk] != MGPU_CREATION || t[lk] != t[c]))
+            return set_error(MGPU_ERR_INVALID_ARG, "chain_window: an as-written deletion links to an energy-only creation row of its type");
+        if (lk == -2 && k != MGPU_CREATION) return set_error(MGPU_ERR_INVALID_ARG, "chain_window: energy-only rows are creation-kind");
+        const int mc = (k == MGPU_CREATION) ? -1 : m[c];
+        if ((rc = check_candidate(e, c, replica, t[c], mc, k != MGPU_CREATION))) return rc;
+        if (k == MGPU_CREATION && lk != -2 && e->h_nmol[idx] >= e->tp.cap[t[c]])
+            return set_error(MGPU_ERR_CAPACITY, "chain_window: residue type is at mol_capacity");
+        n1_max = std::max(n1_max, n1);
+        g.t[c] = t[c]; g.m[c] = mc; g.kind[c] = (signed char)k; g.link[c] = (signed char)lk;
+        g.u[c] = accept_u[c]; g.pref[c] = accept_pref[c];
+        const double *row = sites + (size_t)c * site_stride * 3;
+        cand_ok[c] = 1;
+        if (k != MGPU_DELETION) {
+            // the engine's site order for a frozen type is not the caller's: such types are inactive and never move
+            if (e->frozen[t[c]]) return set_error(MGPU_ERR_INVALID_ARG, "chain_window: frozen residue types do not move");
+            std::memcpy(&g.sites[c][0][0], row, (size_t)n1 * 3 * sizeof(double));
+            cand_ok[c] = sites_in_range(e, row, n1) ? 1 : 0;
+            if (lk != -2) fast = fast && cand_ok[c];
+        }
+        g.ent_old_of[c] = g.ent_new_of[c] = -1;
+        if (lk == -2) continue;
+        if (k != MGPU_CREATION) { g.ent_old_of[c] = (signed char)n_ent; g.ent_c[n_ent] = (unsigned char)c; g.ent_new[n_ent] = 0; ++n_ent; }
+        if (k != MGPU_DELETION) { g.ent_new_of[c] = (signed char)n_ent; g.ent_c[n_ent] = (unsigned char)c; g.ent_new[n_ent] = 1; ++n_ent; }
+    }
+    const int nsplit = e->pair_nsplit;
+    const size_t lds = std::max(std::max(e->coul_bytes, recip_rows_lds_bytes(e, n1_max)), (size_t)n_ent * nsplit * sizeof(double2));
+    if (lds > 64 * 1024) return set_error(MGPU_ERR_CAPACITY, "chain_window: the window does not fit the LDS budget");
+    ch.seq += 1;
+    for (int tt = 0; tt < e->tp.n_res; ++tt) g.self_of_type[tt] = e->self_of_type[tt];
+    g.stamps = ch.timing ? 1 : 0;
+    g.res = ch.d_res; g.partials = ch.d_part; g.ticket = ch.d_ticket;
+    g.host_out = ch.h_out; g.host_tag = ch.h_tag; g.seq = ch.seq;
+    g.n = n; g.n_ent = n_ent; g.nsplit = nsplit; g.replica = replica;
+    g.temperature = temperature; g.e_recip = recip_energy; g.margin = ch.margin;
+    const int grid = n + (n_ent * nsplit + kPairWaves - 1) / kPairWaves;
+    const bool ff = fast && e->pair_fast_fold;
+    ln.dirty = true;
+    ln.last_trial_n = 0;
+    ln.d_trial_items = nullptr;
+    ln.h_trial_items = nullptr;
+#define MGPU_LAUNCH_CHAIN(FL, FW)                                                                                          \
+    hipLaunchKernelGGL((chain_window_kernel<FL, FW>), dim3(grid), dim3(kChainBlock), lds, ln.stream, ch.d_topo, e->bx, e->d_pos, e->d_nmol, \
+                       e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab, e->d_trj, e->d_tw, e->n_rtasks, e->d_rrows, e->n_rrows, \
+                       e->d_A, g)
+    if (e->pair_flat) { if (ff) MGPU_LAUNCH_CHAIN(true, true); else MGPU_LAUNCH_CHAIN(true, false); }
+    else { if (ff) MGPU_LAUNCH_CHAIN(false, true); else MGPU_LAUNCH_CHAIN(false, false); }
+#undef MGPU_LAUNCH_CHAIN
+    HIP_TRY(hipGetLastError());
+    // ---- wait for the tag: the results are in host memory when it shows this window's number
+    {
+        volatile unsigned long long *tag = ch.h_tag;
+        long long spins = 0;
+        while (*tag != ch.seq) {
+            __builtin_ia32_pause();
+            if (++spins >= 20000 && (spins % 4096) == 0) {
+                // long past any window's run time: make sure the stream is still alive
+                const hipError_t q = hipStreamQuery(ln.stream);
+                if (q == hipSuccess && *tag != ch.seq) return set_error(MGPU_ERR_HIP, "chain_window: the kernel finished without publishing its results");
+                if (q != hipSuccess && q != hipErrorNotReady) return set_error(MGPU_ERR_HIP, std::string("chain_window: ") + hipGetErrorString(q));
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    for (int c = 0; c < n; ++c) {
+        std::memcpy(old_energy + 5 * (size_t)c, ch.h_out + 10 * (size_t)c, 5 * sizeof(double));
+        std::memcpy(new_energy + 5 * (size_t)c, ch.h_out + 10 * (size_t)c + 5, 5 * sizeof(double));
+    }
+    const int *hi = (const int *)(ch.h_out + 10 * (size_t)kChainMaxCand);
+    const int first = hi[0], und = hi[1];
+    *first_accepted = first;
+    *undecided = und;
+    ch.windows += 1;
+    if (und >= 0) ch.undecided += 1;
+    if (first >= 0) {
+        // the device is committing candidate `first` behind the tag: the host mirrors follow
+        const size_t idx = (size_t)replica * e->tp.n_res + t[first];
+        if (kind[first] == MGPU_CREATION) e->h_nmol[idx] += 1;
+        if (kind[first] == MGPU_DELETION) e->h_nmol[idx] -= 1;
+        if (kind[first] != MGPU_DELETION && !cand_ok[first]) e->in_range[idx] = 0;
+        // (an as-written deletion moves resident atoms only: the range flag stands)
+        frozen_changed(e, replica, t[first]);
+    }
+    return MGPU_OK;
+}
+
+
+}  // extern "C"

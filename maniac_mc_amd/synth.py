@@ -164,6 +164,33 @@ def rigid_adsorbate_box(n_mol=6, n_sites=24, L=26.0, seed=17, rc=10.0, tol=1e-5,
                   label=f"cage{n_sites}_{n_mol}mol")
 
 
+def large_adsorbate_box(n_sites=300, n_mol=3, L=44.0, seed=23, rc=12.0, tol=1e-5, temperature=300.0):
+    """A rigid adsorbate of MANY sites (default 300: a fullerene-like shell, sites >= 1.2 A apart, three atom types,
+    charges of both signs summing to zero; entirely synthetic): larger than any LDS phase table, so its reciprocal
+    update runs tile by tile and its intra-molecular sum a wave per molecule.  The reference moves, inserts and deletes
+    a residue of any max_atom_in_residue (src/ewald_phase.f90:383-420, src/prepare_utils.f90:233-235)."""
+    rng = np.random.default_rng(seed)
+    radius = float(np.sqrt(n_sites * 1.2 ** 2 * 1.6 / (4 * np.pi)))
+    pts = np.empty((0, 3))
+    while pts.shape[0] < n_sites:
+        v = rng.normal(size=3)
+        v *= radius * (1.0 + 0.08 * rng.uniform(-1, 1)) / np.linalg.norm(v)
+        if pts.shape[0] and np.min(np.linalg.norm(pts - v, axis=1)) < 1.2:
+            continue
+        pts = np.vstack([pts, v])
+    tmpl = pts - pts.mean(0)
+    types = (1 + (np.arange(n_sites) % 3)).astype(np.int32)
+    q = rng.choice([-0.3, -0.1, 0.0, 0.1, 0.3], n_sites)
+    q[q != 0.0] -= q.sum() / np.count_nonzero(q)          # neutral; the uncharged sites stay exactly uncharged
+    eps, sig = lorentz_berthelot([0.09, 0.06, 0.0], [3.3, 3.0, 0.0])
+    topo = Topology(atoms_in_res=[n_sites], atom_types=[types], charges=[q], is_active=[1], epsilon=eps, sigma=sig,
+                    names=["SHELL"])
+    com = _spread_points(rng, n_mol, L, min_sep=2 * radius + 4.0)
+    off = np.einsum("mij,aj->mai", _random_rotations(rng, n_mol), tmpl)
+    return System(topo, np.diag([L, L, L]), np.full(3, -L / 2), rc, tol, temperature, [com], [off],
+                  label=f"shell{n_sites}_{n_mol}mol")
+
+
 def _spread_points(rng, n, L, min_sep):
     """n points in [-L/2, L/2)^3 with pairwise minimum-image separation >= min_sep."""
     pts = np.empty((0, 3))

@@ -526,6 +526,102 @@ def test_per_k_kernel_is_the_only_path_for_a_24_site_adsorbate(refcpu_mod):
     eng.close()
 
 
+@pytest.mark.parametrize("n_sites", [128, 300])
+def test_large_adsorbate_moves_inserts_and_deletes(refcpu_mod, n_sites):
+    """A rigid adsorbate of 128 / 300 sites -- two table sets of 66-158 KiB, beyond any LDS budget: the per-k kernel passes
+    the sites through LDS in tiles (delta(k) in registers across the tiles) and the intra-molecular sum runs a wave per
+    molecule.  The reference sizes its tables by max_atom_in_residue (src/prepare_utils.f90:233-235) and moves, inserts and
+    deletes such a residue like any other (src/ewald_phase.f90:383-420, src/ewald_energy.f90:232-256, :371-411): trial
+    energies, a committed move, an insertion and a deletion (energies, A(k), coordinates after each commit) vs the oracle."""
+    s = synth.large_adsorbate_box(n_sites=n_sites, n_mol=3, L=44.0 if n_sites > 128 else 36.0)
+    n1 = int(s.topo.atoms_in_res[0])
+    assert n1 == n_sites
+    cap = 5
+    eng = Engine.from_system(s, n_replicas=2, mol_capacity=[cap])
+    ktot = int(eng.kmax.sum()) + 3
+    assert 2 * n1 * ktot * 16 > 64 * 1024, "this molecule is meant to overflow a 64 KiB table budget"
+    for r in range(2):
+        eng.init_structure_factor(r, True)
+    P = refcpu_mod.RefCPU(s, mol_capacity=cap)
+    e_sys = P.system_energy()
+    got = eng.system_energy(0)
+    for key in ("non_coulomb", "coulomb", "recip_coulomb", "ewald_self", "intra_coulomb"):
+        close(got[key], e_sys[key], f"{n1}-site system {key}")
+    P.init_amplitude(True)
+    P.set_energy_recip(e_sys["recip_coulomb"])
+    amp_close(eng.structure_factor(0), P.amplitude(), "S(k)")
+    rng = np.random.default_rng(5)
+    n = int(s.n_mol[0])
+    L = float(s.box_matrix[0, 0])
+    # --- a trial move (translation + rotation) of every molecule, one batch; molecule 1's is then committed on replica 1
+    sites = np.zeros((n, n1, 3)); exp_old = np.zeros((n, 3)); exp_new = np.zeros((n, 3))
+    A_after = None
+    for m in range(n):
+        com, off = P.get_molecule(0, m)
+        P.save_fourier(0, m)
+        exp_old[m] = P.old_energy(0, m, 0)[:3]
+        sites[m] = P.apply_pbc(com + rng.uniform(-0.3, 0.3, 3))[None, :] + off @ P.rotation_matrix(1 + m % 3, 0.05).T
+        P.set_molecule(0, m, sites[m, 0], sites[m] - sites[m, 0][None, :])
+        exp_new[m] = P.new_energy(0, m, 0)[:3]
+        if m == 1:
+            A_after = P.amplitude()
+        P.set_molecule(0, m, com, off)
+        P.restore_fourier(0, m)
+    old, new = eng.trial_energy_candidates(np.zeros(n, np.int32), np.zeros(n, np.int32), np.arange(n, dtype=np.int32), sites)
+    close(old, exp_old, f"{n1}-site old")
+    close(new, exp_new, f"{n1}-site new")
+    eng.commit_candidates([1], [0], [1], [MGPU_MOVE], sites[1:2], [1])
+    amp_close(eng.structure_factor(1), A_after, "A after the committed move")
+    assert np.array_equal(eng.get_molecules(1, 0)[1], sites[1])
+    # --- insertion: energies (intra term by the wave kernel), then committed on replica 0 and the oracle together
+    far = s.bounds_lo + np.array([0.5, 0.5, 0.5]) * L
+    for trial in range(200):                                # a place at least a molecule's diameter from the others
+        far = s.bounds_lo + rng.uniform(0.1, 0.9, 3) * L
+        d = s.com[0] - far
+        d -= L * np.rint(d / L)
+        if np.min(np.linalg.norm(d, axis=1)) > 2.2 * np.max(np.linalg.norm(s.offsets[0][0], axis=1)) + 1.0:
+            break
+    csite = far[None, :] + s.offsets[0][0] @ P.rotation_matrix(2, 0.9).T
+    exp_o = P.old_energy(0, n, 1)[:5]
+    P.set_num_residues(0, n + 1)
+    P.save_fourier(0, n)
+    P.set_molecule(0, n, csite[0], csite - csite[0][None, :])
+    exp_n = P.new_energy(0, n, 1)[:5]                       # (A(k) of the oracle now holds the inserted molecule)
+    o5, n5 = eng.gcmc_trial([0], [0], [-1], [MGPU_CREATION], csite[None], lane=0)
+    close(o5[0], exp_o, f"{n1}-site creation old")
+    close(n5[0], exp_n, f"{n1}-site creation new")
+    eng.commit_candidates([0], [0], [-1], [MGPU_CREATION], csite[None], [1])
+    assert eng.num_molecules(0, 0) == n + 1
+    amp_close(eng.structure_factor(0), P.amplitude(), "A after the committed insertion")
+    assert np.array_equal(eng.get_molecules(0, 0)[n], csite)
+    # --- deletion of molecule 0 of the now four: energies, then the swap-with-last commit
+    P.save_fourier(0, 0)
+    exp_o = P.old_energy(0, 0, 2)[:5]
+    o5, n5 = eng.gcmc_trial([0], [0], [0], [MGPU_DELETION], np.zeros((1, n1, 3)), lane=1)
+    close(o5[0], exp_o, f"{n1}-site deletion old")
+    last_sites = eng.get_molecules(0, 0)[n].copy()
+    eng.commit_candidates([0], [0], [0], [MGPU_DELETION], None, [1])
+    assert eng.num_molecules(0, 0) == n
+    assert np.array_equal(eng.get_molecules(0, 0)[0], last_sites)          # delete_molecule.f90:107-114
+    # the oracle's deletion: A <- A - S(molecule 0) (the intended physics the engine implements, SURVEY F3)
+    A_exp = P.amplitude() - mol_structure_factor(eng, s, P, 0)
+    amp_close(eng.structure_factor(0), A_exp, "A after the committed deletion")
+    eng.close()
+
+
+def mol_structure_factor(eng, s, P, m):
+    """S_mol(k) = sum_a q_a exp(i k . r_a) of the oracle's molecule m of type 0, in the reference's k order (numpy)."""
+    kv = eng.kvectors()
+    com, off = P.get_molecule(0, m)
+    r = com[None, :] + off
+    rcp = np.linalg.inv(np.asarray(s.box_matrix, float))          # box%reciprocal
+    theta = 2 * np.pi * (r @ rcp.T)                                # (n1, 3) fractional phases
+    k = np.stack([kv["kx"], kv["ky"], kv["kz"]], 1).astype(float)
+    ph = theta @ k.T                                               # (n1, nk)
+    q = np.asarray(s.topo.charges[0], float)
+    return (q[:, None] * np.exp(1j * ph)).sum(0)
+
+
 def test_structure_factor_add_primitive(refcpu_mod):
     """mgpu_structure_factor_add: A(k) += sum q exp(i k . sites) and nothing else (coordinates, counts); two adds of
     a molecule's own sites after its committed deletion restore 'A + S_mol' -- the composition the as-written host
@@ -860,7 +956,7 @@ def test_a_committed_framework_move_switches_the_batch_kernel_off():
     the commit the engine with the batch kernel must give what the engine without it gives (MGPU_NO_FROZEN_BATCH=1) --
     and the moved framework must be felt."""
     import os
-    s = synth.framework_water_box(n_water=12, n_frame=72, L=20.0, seed=6)      # (a commit's phase tables limit n1 to ~85 sites)
+    s = synth.framework_water_box(n_water=12, n_frame=200, L=20.0, seed=6)     # (200 sites: the commit's phase tables pass through LDS in tiles)
     engines = []
     for nobatch in (False, True):
         if nobatch:
@@ -880,7 +976,7 @@ def test_a_committed_framework_move_switches_the_batch_kernel_off():
     tt = np.ones(k, np.int32)
     kinds = np.full(k, MGPU_MOVE, np.int32)
     before = [e.gcmc_trial(rep, tt, m, kinds, cand) for e in engines]
-    frame = s.all_sites(0).copy()                         # (1, 72, 3): the framework is one molecule of type 0
+    frame = s.all_sites(0).copy()                         # (1, 200, 3): the framework is one molecule of type 0
     frame[0, 17] += np.array([0.4, -0.3, 0.2])
     for which, target in ((1, 1), (0, 0)):                # first a replica other than 0, then the reference copy itself
         for e in engines:

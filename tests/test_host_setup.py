@@ -27,7 +27,8 @@ def test_exports_match_header(hiplib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(hiplib, name), name
-    assert hiplib.mgpu_abi_version() == 1
+    m = re.search(r"#define MGPU_ABI_VERSION (\d+)", header)
+    assert m and hiplib.mgpu_abi_version() == int(m.group(1)) == _lib.ABI_VERSION
 
 
 @pytest.mark.parametrize("name", GOLDEN_FULL + ["spce1000_scalars", "spce3375_scalars", "framework2208_scalars"])
