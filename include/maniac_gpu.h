@@ -406,6 +406,45 @@ int mgpu_chain_set_timing(mgpu_engine *e, int on);
 int mgpu_chain_get_timing(mgpu_engine *e, double us[15]);
 
 /* ------------------------------------------------------------------------------------------
+ * Farm windows: ONE launch per lane step of a FARM of chains (few chains per GPU).
+ * Replaces, for every chain of a lane at once, one pass of MonteCarloLoop's body (src/monte_carlo.f90:40-86): the move
+ * drivers' geometry (src/translation.f90:93-112, src/monte_carlo_utils.f90:30-92, src/create_molecule.f90:166-207),
+ * ComputeOldEnergy / ComputeNewEnergy (src/monte_carlo_utils.f90:275-395), mc_acceptance_probability (:184-226) and
+ * AcceptMove / the Accept* of create_molecule.f90:100-112, delete_molecule.f90:100-142.
+ * Through the batched path (mgpu_move_trial_submit / wait, the rule in the driver, mgpu_commit_submit) a lock step of a
+ * farm is five launches, two copies and two host round trips: 45-110 us for ~10 us of arithmetic when the farm holds
+ * 8-512 chains.  Here the driver hands over, per chain, only the move it selected and the uniform numbers of the move's
+ * construction and of its acceptance test; one launch builds the candidates from the resident molecule frames
+ * (mgpu_replica_set_frames), evaluates them (the batched path's sums, bit for bit: same kernels' bodies, the engine's
+ * nsplit), applies the rule and commits accepted steps; the driver collects energies and verdicts from pinned host
+ * memory (per-chain tags: no copy, no stream synchronisation).  A lane may hold up to max_in_flight windows: a driver whose
+ * move selection does not depend on earlier outcomes (NVT) queues step i + 1 before it has seen step i.
+ *   move[c]     0: chain c does nothing this step; 1 translation, 2 rotation, 3 creation, 4 deletion (m ignored for 3)
+ *   forced      NULL, or per chain 0: the device applies the rule; 1 / 2: the driver has decided this step (accept /
+ *               reject) and the device obeys
+ *   u5          [n][5] the construction's uniform numbers (mgpu_move_trial_submit's)
+ *   accept_u / accept_pref   the test's uniform number and prefactor (mgpu_chain_window's)
+ * mgpu_farm_window_wait collects the lane's OLDEST window: old_energy / new_energy [n][5] as mgpu_gcmc_trial_wait fills
+ * them, verdict[c] = 0 rejected, 1 accepted and committed, 2 UNDECIDED, 4 nothing done (the replica waits for the driver's
+ * decision of an earlier step), 5 idle record.  Undecided: the draw lies within the engine's relative margin (16 ulp;
+ * mgpu_chain_set_margin) of the acceptance probability -- the device's exp (OCML) and the driver's (glibc) may differ in
+ * the last bits there -- or the probability is not a number: nothing is committed, the replica is marked, every window
+ * already queued for it does nothing (verdict 4), and the driver, having decided with its own exp, sends the step again
+ * with `forced` set.  The driver checks every other verdict against its own rule: every decision taken is its own.
+ * One record per replica and launch; a window with an insertion / deletion must be collected before the lane's next
+ * submit (the engine validates slots against its molecule counts).  A(k): a farm window leaves a replica's current A(k) in
+ * one of two buffers; every other entry point that touches A(k) copies it back first (mgpu_farm_window_flush does only
+ * that).  mgpu_farm_window_capacity: chains per launch (0: the path does not apply -- triclinic box, per-k reciprocal
+ * form, an active molecule of more than 5 sites) and windows per lane in flight. */
+int mgpu_farm_window_capacity(const mgpu_engine *e, int *max_chains, int *max_in_flight);
+int mgpu_farm_window_submit(mgpu_engine *e, int lane, int n, const int *replica, const int *t, const int *m, const int *move,
+                            const int *forced, const double *u5, const double *accept_u, const double *accept_pref,
+                            double t_step, double r_step, double temperature);
+int mgpu_farm_window_wait(mgpu_engine *e, int lane, double *old_energy, double *new_energy, int *verdict);
+int mgpu_farm_window_flush(mgpu_engine *e);
+int mgpu_farm_window_get_stats(const mgpu_engine *e, long long *windows, long long *undecided);
+
+/* ------------------------------------------------------------------------------------------
  * The path's one exchange step: replicas are farmed over the GPUs of a node, one process per GPU,
  * and never communicate while they run; once per block every rank contributes its chains' molecule-count histogram
  * (what the reference records per chain in number_<res>.dat, src/write_utils.f90:144-150) and a few running sums, and

@@ -31,7 +31,8 @@ EXPORTS = [
     "mgpu_trial_energy_candidates", "mgpu_commit_candidates", "mgpu_trial_submit", "mgpu_trial_wait",
     "mgpu_commit_submit", "mgpu_lane_site_buffer", "mgpu_set_host_team", "mgpu_replica_set_frames", "mgpu_replica_get_frames", "mgpu_move_trial_submit", "mgpu_move_trial_decide_submit", "mgpu_gcmc_trial_decide_submit", "mgpu_trial_decide_wait", "mgpu_gcmc_trial_submit", "mgpu_gcmc_trial_wait", "mgpu_replica_replace_molecule",
     "mgpu_replica_set_num_molecules", "mgpu_chain_window_capacity", "mgpu_chain_window", "mgpu_chain_set_margin",
-    "mgpu_chain_get_stats", "mgpu_chain_set_timing", "mgpu_chain_get_timing", "mgpu_comm_unique_id", "mgpu_comm_create",
+    "mgpu_chain_get_stats", "mgpu_chain_set_timing", "mgpu_chain_get_timing", "mgpu_farm_window_capacity", "mgpu_farm_window_submit",
+    "mgpu_farm_window_wait", "mgpu_farm_window_flush", "mgpu_farm_window_get_stats", "mgpu_comm_unique_id", "mgpu_comm_create",
     "mgpu_comm_destroy", "mgpu_comm_rank", "mgpu_allgather_block_stats", "mgpu_append_atom_records", "mgpu_format_fixed", "mgpu_phase_factors", "mgpu_synchronize", "mgpu_profile_enable", "mgpu_profile_reset",
     "mgpu_profile_get",
 ]

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <omp.h>
 #include <string>
 #include <vector>
@@ -113,7 +114,40 @@ struct Lane {
     size_t decided_at = 0;                    // byte offset of the flags in h_out
     hipEvent_t commit_staged_ev = nullptr;                    // recorded behind the H2D copies that read h_commit
     bool commit_staged = false;
+    // Farm windows (mgpu_farm_window_submit / _wait): up to kFarmDepth windows of this lane in flight.  The host-side blocks
+    // are rings (a window's records are read, and its results written, while the next window is being prepared); the
+    // device scratch is shared (a stream runs its kernels one after the other).
+    struct FarmWindow {
+        FarmRec *h_recs = nullptr;               // pinned [kFarmDepth][cap]
+        double *h_out = nullptr;                 // pinned [kFarmDepth][cap][kFarmOut]
+        unsigned long long *h_tag = nullptr;     // pinned [kFarmDepth][cap]
+        double2 *d_part = nullptr;               // [cap][2 nsplit]
+        ChainResult *d_res = nullptr;            // [cap]
+        int *d_tickets = nullptr;                // [cap], zero between launches
+        int cap = 0;
+        unsigned long long seq = 0;              // windows submitted so far
+        struct Pending {
+            unsigned long long seq;
+            int n, slot;
+            bool counts_change;                  // carries an insertion / deletion: must be waited before the next submit
+            std::vector<int> rep, t, kind;
+            std::vector<char> ok;                // the candidate's sites are within the fast fold's range
+        };
+        std::deque<Pending> pending;
+        void release() {
+            if (h_recs) (void)hipHostFree(h_recs);
+            if (h_out) (void)hipHostFree(h_out);
+            if (h_tag) (void)hipHostFree(h_tag);
+            if (d_part) (void)hipFree(d_part);
+            if (d_res) (void)hipFree(d_res);
+            if (d_tickets) (void)hipFree(d_tickets);
+            h_recs = nullptr; h_out = nullptr; h_tag = nullptr; d_part = nullptr; d_res = nullptr; d_tickets = nullptr;
+            cap = 0;
+            pending.clear();
+        }
+    } farm;
     void release() {
+        farm.release();
         if (commit_staged_ev) { (void)hipEventDestroy(commit_staged_ev); commit_staged_ev = nullptr; }
         d_items.release(); d_items2.release(); d_sites.release(); d_partials.release(); d_out.release();
         d_scratch.release();
@@ -122,6 +156,8 @@ struct Lane {
     }
 };
 constexpr int kLanes = 4;
+constexpr int kFarmDepth = 4;           // farm windows a lane may have in flight
+constexpr int kFarmMaxChains = 1024;   // chains per farm window
 
 }  // namespace mgpu
 
@@ -225,6 +261,15 @@ struct mgpu_engine {
         long long windows = 0, undecided = 0;
         bool timing = false;                         // stage stamps wanted (mgpu_chain_set_timing)
     } chain;
+    // farm windows (mgpu_farm_window_*): the other A(k) buffer of every replica, which of the two is current, and the
+    // per-replica stall flag, all allocated on first use; `dirty` = some replica's current A(k) may live in d_A_alt (every
+    // entry point that reads or writes A(k) outside a farm window first copies it back: farm_window_normalize)
+    struct Farm {
+        double2 *d_A_alt = nullptr;
+        int *d_acur = nullptr, *d_stalled = nullptr;
+        bool dirty = false;
+        long long windows = 0, undecided = 0;
+    } farm;
     // profiling
     bool profiling = false;
 };
@@ -250,6 +295,8 @@ bool any_frozen(const mgpu_engine *e, int n, const int *t);
 int upload_sites(Lane &ln, const double *sites, int n_rows, int site_stride);
 int upload_sites(mgpu_engine *e, const double *sites, int n_rows, int site_stride, const int *t);
 double self_energy_host(const mgpu_engine *e, int t);
+int farm_window_normalize(mgpu_engine *e);      // mgpu_windows.hip
+int chain_topo(mgpu_engine *e, const Topo **d_topo);   // the engine's Topo in device memory (mgpu_windows.hip)
 // mgpu_launch.hip
 int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, int common_n1, int site_stride,
                 int nsplit, double *d_lj, double *d_c, bool ordered = false, double2 *host_partials = nullptr,

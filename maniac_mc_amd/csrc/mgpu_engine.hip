@@ -67,6 +67,8 @@ int sync_all_lanes(mgpu_engine *e) {
     for (auto &ln : e->lanes)
         if (&ln == &e->lanes[0] || ln.dirty || !ln.pending.empty())
             if (int rc = sync_lane(e, ln)) return rc;
+    // farm windows leave a replica's current A(k) in either of its two buffers: back into the primary one
+    if (e->farm.dirty) return farm_window_normalize(e);
     return MGPU_OK;
 }
 
@@ -589,7 +591,8 @@ int mgpu_engine_destroy(mgpu_engine *e) {
     e->h_stage.release();
     for (void *p : {(void *)e->chain.h_out, (void *)e->chain.h_tag})
         if (p) (void)hipHostFree(p);
-    for (void *p : {(void *)e->chain.d_res, (void *)e->chain.d_part, (void *)e->chain.d_ticket, (void *)e->chain.d_topo})
+    for (void *p : {(void *)e->chain.d_res, (void *)e->chain.d_part, (void *)e->chain.d_ticket, (void *)e->chain.d_topo,
+                    (void *)e->farm.d_A_alt, (void *)e->farm.d_acur, (void *)e->farm.d_stalled})
         if (p) (void)hipFree(p);
     for (auto &ln : e->lanes) {
         ln.release();

@@ -154,6 +154,7 @@ static int trial_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replica
                              const TrialDecide *decide = nullptr) {
     if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "trial_submit: the lane still holds an un-waited trial");
     int rc;
+    if (e->farm.dirty && (rc = farm_window_normalize(e))) return rc;       // (farm windows ran before: A(k) back into its primary buffer)
     if (decide) {
         if (!(decide->temperature > 0.0)) return set_error(MGPU_ERR_INVALID_ARG, "trial_decide_submit: temperature must be positive");
         // one candidate per replica: the workgroups commit independently
@@ -569,6 +570,7 @@ static int commit_submit_impl(mgpu_engine *e, Lane &ln, int n, const int *replic
     int rc;
     const size_t site_bytes = sites ? (size_t)n * site_stride * 3 * sizeof(double) : 0;
     if (ln.n_submitted != 0) return set_error(MGPU_ERR_STATE, "commit_submit: wait for the lane's trial first");
+    if (e->farm.dirty && (rc = farm_window_normalize(e))) return rc;
     ln.dirty = true;
     // committing a device-built trial from its resident rows: the rows carry the candidates' frames
     const bool built = !sites && reuse_sites && ln.last_trial_built && n == ln.last_trial_n;

@@ -185,6 +185,39 @@ class Engine:
         check(self.L.mgpu_trial_decide_wait(self.h, C.c_int(lane), _d(old), _d(new), _i(acc)))
         return old, new, acc
 
+    def farm_window_capacity(self):
+        n = C.c_int(0); d = C.c_int(0)
+        check(self.L.mgpu_farm_window_capacity(self.h, C.byref(n), C.byref(d)))
+        return n.value, d.value
+
+    def farm_window_submit(self, replica, t, m, move, u, translation_step, rotation_step, accept_u, accept_pref, temperature,
+                           forced=None, lane=0):
+        """mgpu_farm_window_submit: one launch evaluates, decides and commits one step of every chain given."""
+        m = _ints(m); n = m.shape[0]
+        replica = _ints(replica, n); t = _ints(t, n); move = _ints(move, n)
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(n, 5)
+        au = np.ascontiguousarray(accept_u, dtype=np.float64).reshape(n)
+        ap = np.ascontiguousarray(accept_pref, dtype=np.float64).reshape(n)
+        fo = _ints(0 if forced is None else forced, n)
+        check(self.L.mgpu_farm_window_submit(self.h, C.c_int(lane), C.c_int(n), _i(replica), _i(t), _i(m), _i(move), _i(fo), _d(u),
+                                             _d(au), _d(ap), C.c_double(translation_step), C.c_double(rotation_step),
+                                             C.c_double(temperature)))
+        return n
+
+    def farm_window_wait(self, n, lane=0):
+        """The lane's oldest window: (old[n,5], new[n,5], verdict[n])."""
+        old = np.zeros((n, 5)); new = np.zeros((n, 5)); v = np.zeros(n, np.int32)
+        check(self.L.mgpu_farm_window_wait(self.h, C.c_int(lane), _d(old), _d(new), _i(v)))
+        return old, new, v
+
+    def farm_window_flush(self):
+        check(self.L.mgpu_farm_window_flush(self.h))
+
+    def farm_window_stats(self):
+        w = C.c_longlong(0); u = C.c_longlong(0)
+        check(self.L.mgpu_farm_window_get_stats(self.h, C.byref(w), C.byref(u)))
+        return w.value, u.value
+
     def gcmc_trial_decide(self, replica, t, m, kind, sites, accept_u, accept_pref, temperature, lane=0):
         """Host-built rows, decided and committed on the device: (old[n,5], new[n,5], accepted[n])."""
         n, replica, t, m, sites = self._cand(replica, t, m, sites)

@@ -28,6 +28,7 @@ module maniac_gpu
     integer(c_int), parameter :: MGPU_OK = 0
     integer(c_int), parameter :: MGPU_MOVE = 0, MGPU_CREATION = 1, MGPU_DELETION = 2, MGPU_NONE = 3
     integer(c_int), parameter :: MGPU_LANES = 4
+    integer(c_int), parameter :: MGPU_FARM_DEPTH = 4                 ! farm windows a lane may have in flight (kFarmDepth)
 
     interface
         function mgpu_last_error() bind(C, name="mgpu_last_error") result(p)
@@ -245,6 +246,32 @@ module maniac_gpu
             integer(c_int), value :: lane
             real(c_double), intent(out) :: old_energy(*), new_energy(*)
             integer(c_int), intent(out) :: accepted(*)
+            integer(c_int) :: rc
+        end function
+        ! farm windows: one launch per lane step of a farm of chains (include/maniac_gpu.h)
+        function mgpu_farm_window_capacity(e, max_chains, max_in_flight) bind(C, name="mgpu_farm_window_capacity") result(rc)
+            import :: c_ptr, c_int
+            type(c_ptr), value :: e
+            integer(c_int), intent(out) :: max_chains, max_in_flight
+            integer(c_int) :: rc
+        end function
+        function mgpu_farm_window_submit(e, lane, n, replica, t, m, move, forced, u5, accept_u, accept_pref, &
+                                         translation_step, rotation_step, temperature) &
+                bind(C, name="mgpu_farm_window_submit") result(rc)
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: e
+            integer(c_int), value :: lane, n
+            integer(c_int), intent(in) :: replica(*), t(*), m(*), move(*), forced(*)
+            real(c_double), intent(in) :: u5(*), accept_u(*), accept_pref(*)
+            real(c_double), value :: translation_step, rotation_step, temperature
+            integer(c_int) :: rc
+        end function
+        function mgpu_farm_window_wait(e, lane, old_energy, new_energy, verdict) bind(C, name="mgpu_farm_window_wait") result(rc)
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: e
+            integer(c_int), value :: lane
+            real(c_double), intent(out) :: old_energy(*), new_energy(*)
+            integer(c_int), intent(out) :: verdict(*)
             integer(c_int) :: rc
         end function
         ! pinned staging of a lane's next trial: candidate rows built in place are not copied again

@@ -48,6 +48,7 @@ module mc_farm
     public :: mfarm_create, mfarm_run, mfarm_destroy, mfarm_get_energy, mfarm_get_molecule, mfarm_recalibrate
     public :: mfarm_get_timers, mfarm_set_gcmc, mfarm_get_counts, mfarm_get_counters, mfarm_set_triclinic
     public :: mfarm_rng_sample, mfarm_set_drivers, mfarm_configure, mfarm_select, mfarm_exchange_block
+    public :: mfarm_window_mode, mfarm_set_window_depth
 
     real(real64), parameter :: PI = 3.14159265358979323846_real64
     real(real64), parameter :: TWOPI = 2.0_real64 * PI
@@ -77,6 +78,18 @@ module mc_farm
         real(real64), allocatable :: acc_u(:), acc_pref(:) ! device-decided trials: the test's number and prefactor
         real(real64), allocatable :: old_e(:), new_e(:)    ! (ne * nc) rows packed by the engine
         real(real64), allocatable :: u(:, :)
+        ! ---- window mode (mfarm_configure(3)): one launch per lane step, up to F%depth windows of the lane in flight.
+        ! A window carries one record per chain of the lane; w_live = 1 where the record is a step of the chain (0: filler).
+        ! Per chain: issued / resolved count its steps of the current mfarm_run; pend_* is a FIFO of draws to send (again)
+        ! before any fresh one -- an UNDECIDED step with the host's decision (pend_forced, its front entry), then the steps
+        ! whose windows were already in flight behind it and did nothing.
+        integer :: w_head = 0, w_count = 0
+        integer, allocatable :: w_live(:, :), w_ia(:, :), w_mv(:, :), w_slot(:, :), w_forced(:, :)    ! (n, 0:depth-1)
+        real(real64), allocatable :: w_u(:, :, :)                                                     ! (NRAND, n, 0:depth-1)
+        integer, allocatable :: issued(:), resolved(:), pend_n(:), pend_forced(:)
+        real(real64), allocatable :: pend_u(:, :, :)                                                  ! (NRAND, depth + 1, n)
+        integer(c_int), allocatable :: forced(:), verdict(:)
+        integer(int64) :: outstanding = 0, in_flight = 0          ! steps of the run not yet resolved / records in flight
         ! per-lane accumulators (lanes may run on different host threads), folded into the farm's totals by mfarm_run
         integer(int64) :: trials = 0, accepted = 0, skipped = 0, counters(8) = 0, ticks(7) = 0
     end type lane_buffers
@@ -112,6 +125,13 @@ module mc_farm
         ! no gathers from it, no candidate rows to stage
         logical :: device_build = .false.
         logical :: device_accept = .false.       ! ... and the engine applies the acceptance rule and commits (mfarm_configure(2))
+        ! window mode (mfarm_configure(3)): ONE launch per lane step (mgpu_farm_window_submit): the engine builds, evaluates,
+        ! decides with the driver's draws and commits; the driver selects the moves, checks every decision against its own
+        ! rule and decides itself whatever the device left undecided.  depth: windows of a lane in flight (1 with
+        ! insertion / deletion: the selection then depends on the last outcome)
+        logical :: window = .false.
+        integer :: depth = 2
+        integer(int64) :: undecided = 0
         integer(int64), allocatable :: cxs(:, :)           ! (4, R) xoshiro256+ state of every chain
     end type farm_state
 
@@ -123,6 +143,7 @@ module mc_farm
     type(farm_state), pointer, save :: F => farms(0)
     logical, save :: want_device_build = .false.           ! consumed by the next mfarm_create (mfarm_configure)
     logical, save :: want_device_accept = .false.
+    logical, save :: want_window = .false.
 
     interface
         function c_posix_memalign(ptr, alignment, bytes) bind(C, name="posix_memalign") result(rc)
@@ -254,6 +275,16 @@ contains
         F%cap_total = tot
         F%device_build = want_device_build
         F%device_accept = want_device_build .and. want_device_accept
+        F%window = .false.
+        if (want_device_build .and. want_window) then
+            ! where the one-launch path does not apply (triclinic box, large molecules) the farm stays on the batched path
+            rc = mgpu_farm_window_capacity(engine, k, i)
+            g = n_lanes
+            if (g <= 0) g = 2
+            g = max(1, min(g, int(MGPU_LANES), int(n_replicas)))
+            F%window = rc == MGPU_OK .and. k >= (n_replicas + g - 1) / g        ! a lane's chains fit one launch
+            rc = MGPU_OK
+        end if
         if (.not. F%device_build) call alloc_mirror(3 + 3 * max_n1, tot, int(n_replicas))
         allocate(F%energy(5, n_replicas))
         F%n_threads = max(1, int(n_threads))
@@ -393,6 +424,14 @@ contains
         allocate(L%sel_ia(n), L%sel_mv(n), L%sel_slot(n))
         allocate(L%new_com(3, n), L%new_off(3, max_n1, n))
         allocate(L%old_e(5 * n), L%new_e(5 * n), L%u(NRAND, n), L%mvc(n), L%u5(5, n), L%acc_u(n), L%acc_pref(n))
+        if (F%window) then
+            allocate(L%w_live(n, 0:MGPU_FARM_DEPTH - 1), L%w_ia(n, 0:MGPU_FARM_DEPTH - 1), L%w_mv(n, 0:MGPU_FARM_DEPTH - 1), &
+                     L%w_slot(n, 0:MGPU_FARM_DEPTH - 1), L%w_forced(n, 0:MGPU_FARM_DEPTH - 1), &
+                     L%w_u(NRAND, n, 0:MGPU_FARM_DEPTH - 1), L%issued(n), L%resolved(n), L%pend_n(n), L%pend_forced(n), &
+                     L%pend_u(NRAND, MGPU_FARM_DEPTH + 1, n), L%forced(n), L%verdict(n))
+            L%pend_n = 0; L%pend_forced = 0; L%issued = 0; L%resolved = 0
+            L%w_head = 0; L%w_count = 0; L%outstanding = 0; L%in_flight = 0
+        end if
         rc = mgpu_lane_site_buffer(F%engine, int(g, c_int), int(n, c_int), int(max_n1, c_int), staged)
         if (rc == MGPU_OK .and. c_associated(staged)) then
             call c_f_pointer(staged, L%sites, [3, max_n1, n])
@@ -422,6 +461,9 @@ contains
                            F%lane(g)%new_off, F%lane(g)%old_e, F%lane(g)%new_e, F%lane(g)%u, F%lane(g)%mvc, F%lane(g)%u5, &
                            F%lane(g)%acc_u, F%lane(g)%acc_pref)
                 if (allocated(F%lane(g)%sites_own)) deallocate(F%lane(g)%sites_own)
+                if (allocated(F%lane(g)%w_live)) deallocate(F%lane(g)%w_live, F%lane(g)%w_ia, F%lane(g)%w_mv, F%lane(g)%w_slot, &
+                    F%lane(g)%w_forced, F%lane(g)%w_u, F%lane(g)%issued, F%lane(g)%resolved, F%lane(g)%pend_n, &
+                    F%lane(g)%pend_forced, F%lane(g)%pend_u, F%lane(g)%forced, F%lane(g)%verdict)
                 nullify(F%lane(g)%sites)
             end if
         end do
@@ -811,6 +853,269 @@ contains
     end function resolve_and_commit
 
     !---------------------------------------------------------------------------
+    ! Window mode.  Move selection for chain r from its draws u and its counts: monte_carlo.f90:50-75, exactly
+    ! generate_and_submit's phase 1 (slot 0 = the selections that are no-ops in the reference).
+    !---------------------------------------------------------------------------
+    subroutine select_move(r, u, ia, mv, slot)
+        integer, intent(in) :: r
+        real(real64), intent(in) :: u(NRAND)
+        integer, intent(out) :: ia, mv, slot
+        integer :: n
+        real(real64) :: draw
+        ia = min(int(u(1) * F%n_active) + 1, F%n_active)              ! PickRandomResidueType
+        n = F%cnt(ia, r)
+        draw = u(3)
+        if (draw <= F%p_translation) then
+            mv = MV_TRANSLATION
+        else if (draw <= F%p_rotation + F%p_translation) then
+            mv = MV_ROTATION
+        else if (u(10) <= PROB_CREATE_DELETE) then
+            mv = MV_CREATION
+        else
+            mv = MV_DELETION
+        end if
+        if (.not. F%gcmc .and. mv > MV_ROTATION) mv = MV_ROTATION
+        slot = 0
+        if (mv == MV_ROTATION .and. F%n1(ia) == 1) then
+            if (.not. F%gcmc) then
+                mv = MV_TRANSLATION                                     ! NVT farm of atoms: always translate
+                if (n > 0) slot = min(int(u(2) * n) + 1, n)
+            end if                                                      ! GCMC: rotation.f90:45 returns
+        else if (mv == MV_CREATION) then
+            if (n < F%cap(ia)) slot = n + 1                             ! monte_carlo.f90:63; full: the reference aborts
+        else
+            if (n > 0) slot = min(int(u(2) * n) + 1, n)                 ! PickRandomMoleculeIndex; 0: the drivers return
+        end if
+    end subroutine select_move
+
+    ! what mc_acceptance_probability multiplies exp(-dE / T) by (monte_carlo_utils.f90:184-226), as resolve_and_commit forms it
+    pure function acceptance_prefactor(mv, ia, r) result(pref)
+        integer, intent(in) :: mv, ia, r
+        real(real64) :: pref
+        select case (mv)
+        case (MV_CREATION)
+            pref = F%fugacity(ia, r) * F%volume / real(F%cnt(ia, r) + 1, real64)
+        case (MV_DELETION)
+            pref = (real(F%cnt(ia, r) - 1, real64) + 1.0_real64) / (F%fugacity(ia, r) * F%volume)
+        case default
+            pref = 1.0_real64
+        end select
+    end function acceptance_prefactor
+
+    ! Queue the lane's next window: one record per chain -- a step waiting to be sent again, else the chain's next step
+    ! (fresh draws, in the chain's own order), else a filler.
+    function issue_window(g, n_target) result(rc)
+        integer, intent(in) :: g, n_target
+        integer(c_int) :: rc
+        integer :: i, b, r, ia, mv, slot, k, d
+        integer(int64) :: c0, c1, c2
+        type(lane_buffers), pointer :: L
+        L => F%lane(g)
+        rc = MGPU_OK
+        call system_clock(c0)
+        b = mod(L%w_head + L%w_count, MGPU_FARM_DEPTH)
+        ! rng_kind 0: the intrinsic generator, serially, for the chains that take a fresh step
+        if (F%rng_kind == 0) then
+            do i = 1, L%n
+                if (L%pend_n(i) == 0 .and. L%issued(i) < n_target) call random_number(L%w_u(:, i, b))
+            end do
+        end if
+        !$omp parallel do num_threads(F%team) schedule(static) private(i, r, ia, mv, slot, k, d) if (F%team > 1 .and. L%n >= 256)
+        do i = 1, L%n
+            r = L%first + i
+            L%rep(i) = int(r - 1, c_int)
+            L%forced(i) = 0
+            if (L%pend_n(i) > 0) then
+                L%w_u(:, i, b) = L%pend_u(:, 1, i)
+                do k = 2, L%pend_n(i)
+                    L%pend_u(:, k - 1, i) = L%pend_u(:, k, i)
+                end do
+                L%pend_n(i) = L%pend_n(i) - 1
+                L%forced(i) = int(L%pend_forced(i), c_int)
+                L%pend_forced(i) = 0
+            else if (L%issued(i) < n_target) then
+                if (F%rng_kind /= 0) call chain_random(r, L%w_u(:, i, b))
+                L%issued(i) = L%issued(i) + 1
+            else
+                L%w_live(i, b) = 0                                      ! nothing left for this chain: a filler
+                L%t(i) = 0; L%m(i) = 0; L%mvc(i) = 0
+                L%acc_u(i) = 0.0_real64; L%acc_pref(i) = 1.0_real64
+                L%u5(:, i) = 0.0_real64
+                cycle
+            end if
+            call select_move(r, L%w_u(:, i, b), ia, mv, slot)
+            L%w_live(i, b) = 1
+            L%w_ia(i, b) = ia; L%w_mv(i, b) = mv; L%w_slot(i, b) = slot; L%w_forced(i, b) = L%forced(i)
+            L%t(i) = int(F%res_type(ia), c_int)
+            L%m(i) = int(max(slot, 1) - 1, c_int)
+            L%mvc(i) = int(merge(mv, 0, slot > 0), c_int)               ! a no-op selection: the engine does nothing for it
+            do d = 1, 5
+                L%u5(d, i) = L%w_u(3 + d, i, b)                         ! u4..u6 displacement / position, u7 angle, u8 axis
+            end do
+            L%acc_u(i) = L%w_u(9, i, b)
+            L%acc_pref(i) = acceptance_prefactor(mv, ia, r)
+        end do
+        !$omp end parallel do
+        call system_clock(c1)
+        rc = mgpu_farm_window_submit(F%engine, int(g, c_int), int(L%n, c_int), L%rep, L%t, L%m, L%mvc, L%forced, L%u5, &
+                                     L%acc_u, L%acc_pref, F%translation_step, F%rotation_step, F%temperature)
+        call system_clock(c2)
+        L%in_flight = L%in_flight + count(L%w_live(1:L%n, b) == 1)
+        L%w_count = L%w_count + 1
+        L%ticks(1) = L%ticks(1) + (c1 - c0)
+        L%ticks(2) = L%ticks(2) + (c2 - c1)
+    end function issue_window
+
+    ! Collect the lane's oldest window and follow its outcomes: every verdict the device took is checked against the
+    ! driver's own rule (mc_acceptance_probability, monte_carlo_utils.f90:184-226); what the device left undecided the
+    ! driver decides and sends again.
+    function resolve_window(g) result(rc)
+        integer, intent(in) :: g
+        integer(c_int) :: rc
+        integer :: i, b, r, ia, mv, slot, k, o, v
+        integer(int64) :: c0, c1, c2
+        integer(int64) :: k_tt, k_t, k_rt, k_r, k_ct, k_c, k_dt, k_d, n_skip, n_done, n_und
+        real(real64) :: e_old, e_new, delta_e, probability
+        logical :: yes, bad
+        type(lane_buffers), pointer :: L
+        L => F%lane(g)
+        rc = MGPU_OK
+        call system_clock(c0)
+        b = L%w_head
+        rc = mgpu_farm_window_wait(F%engine, int(g, c_int), L%old_e, L%new_e, L%verdict)
+        if (rc /= MGPU_OK) return
+        call system_clock(c1)
+        k_tt = 0; k_t = 0; k_rt = 0; k_r = 0; k_ct = 0; k_c = 0; k_dt = 0; k_d = 0; n_skip = 0; n_done = 0; n_und = 0
+        bad = .false.
+        do i = 1, L%n
+            if (L%w_live(i, b) == 0) cycle
+            L%in_flight = L%in_flight - 1
+            r = L%first + i
+            ia = L%w_ia(i, b); mv = L%w_mv(i, b); slot = L%w_slot(i, b)
+            v = L%verdict(i)
+            if (slot == 0) then
+                ! a no-op selection (empty type, full type, rotation of an atom): the step is spent
+                n_skip = n_skip + 1
+                n_done = n_done + 1
+                L%resolved(i) = L%resolved(i) + 1
+                cycle
+            end if
+            if (v == 4) then
+                ! the window ran behind an undecided step of this chain and did nothing: send the step again, in order
+                L%pend_n(i) = L%pend_n(i) + 1
+                L%pend_u(:, L%pend_n(i), i) = L%w_u(:, i, b)
+                cycle
+            end if
+            o = 5 * (i - 1)
+            e_old = 0.0_real64
+            e_new = 0.0_real64
+            do k = 1, 5                                                   ! old%total, new%total
+                e_old = e_old + L%old_e(o + k)
+                e_new = e_new + L%new_e(o + k)
+            end do
+            delta_e = e_new - e_old
+            probability = min(1.0_real64, acceptance_prefactor(mv, ia, r) * exp(-delta_e / F%temperature))
+            yes = L%w_u(9, i, b) <= probability
+            if (v == 2) then
+                ! left to the driver: its decision goes back with the step (in front of anything already waiting)
+                do k = L%pend_n(i), 1, -1
+                    L%pend_u(:, k + 1, i) = L%pend_u(:, k, i)
+                end do
+                L%pend_u(:, 1, i) = L%w_u(:, i, b)
+                L%pend_n(i) = L%pend_n(i) + 1
+                L%pend_forced(i) = merge(1, 2, yes)
+                n_und = n_und + 1
+                cycle
+            end if
+            if (L%w_forced(i, b) /= 0) then
+                yes = L%w_forced(i, b) == 1                               ! the driver's earlier decision, obeyed
+                if ((v == 1) .neqv. yes) bad = .true.
+            else if ((v == 1) .neqv. yes) then
+                bad = .true.                                              ! outside the margin the two rules cannot differ
+            end if
+            select case (mv)
+            case (MV_CREATION)
+                k_ct = k_ct + 1
+            case (MV_DELETION)
+                k_dt = k_dt + 1
+            case (MV_TRANSLATION)
+                k_tt = k_tt + 1
+            case default
+                k_rt = k_rt + 1
+            end select
+            if (v == 1) then
+                select case (mv)
+                case (MV_CREATION)
+                    F%cnt(ia, r) = F%cnt(ia, r) + 1
+                    k_c = k_c + 1
+                case (MV_DELETION)
+                    F%cnt(ia, r) = F%cnt(ia, r) - 1
+                    k_d = k_d + 1
+                case (MV_TRANSLATION)
+                    k_t = k_t + 1
+                case default
+                    k_r = k_r + 1
+                end select
+                ! monte_carlo_utils.f90:416-419, create_molecule.f90:107-112, delete_molecule.f90:137-142
+                do k = 1, 5
+                    F%energy(k, r) = F%energy(k, r) + L%new_e(o + k) - L%old_e(o + k)
+                end do
+            end if
+            n_done = n_done + 1
+            L%resolved(i) = L%resolved(i) + 1
+        end do
+        L%counters = L%counters + [k_tt, k_t, k_rt, k_r, k_ct, k_c, k_dt, k_d]
+        L%accepted = L%accepted + k_t + k_r + k_c + k_d
+        L%trials = L%trials + k_tt + k_rt + k_ct + k_dt
+        L%skipped = L%skipped + n_skip
+        L%outstanding = L%outstanding - n_done
+        F%undecided = F%undecided + n_und
+        L%w_head = mod(L%w_head + 1, MGPU_FARM_DEPTH)
+        L%w_count = L%w_count - 1
+        call system_clock(c2)
+        L%ticks(3) = L%ticks(3) + (c1 - c0)
+        L%ticks(4) = L%ticks(4) + (c2 - c1)
+        if (bad) rc = 7                   ! a device decision the driver's rule contradicts: never outside the margin
+    end function resolve_window
+
+    ! n_steps move selections of every chain through windows: the lanes take turns; a lane keeps up to `depth` windows in
+    ! flight while it has steps to send and collects its oldest one each turn.
+    function run_windows(n_steps) result(rc)
+        integer, intent(in) :: n_steps
+        integer(c_int) :: rc
+        integer :: g, depth
+        logical :: busy
+        type(lane_buffers), pointer :: L
+        rc = MGPU_OK
+        depth = max(1, min(F%depth, int(MGPU_FARM_DEPTH)))
+        if (F%gcmc) depth = 1             ! the next selection depends on this step's outcome (counts)
+        do g = 0, F%n_lanes - 1
+            L => F%lane(g)
+            if (L%n == 0) cycle
+            L%issued = 0; L%resolved = 0
+            L%outstanding = int(L%n, int64) * int(n_steps, int64)
+            L%in_flight = 0
+        end do
+        do
+            busy = .false.
+            do g = 0, F%n_lanes - 1
+                L => F%lane(g)
+                if (L%n == 0) cycle
+                do while (L%w_count < depth .and. L%outstanding - L%in_flight > 0)
+                    rc = issue_window(g, n_steps)
+                    if (rc /= MGPU_OK) return
+                end do
+                if (L%w_count > 0) then
+                    rc = resolve_window(g)
+                    if (rc /= MGPU_OK) return
+                end if
+                if (L%outstanding > 0) busy = .true.
+            end do
+            if (.not. busy) exit
+        end do
+    end function run_windows
+
+    !---------------------------------------------------------------------------
     ! Advance every chain by n_steps move selections.  out = trials, accepted, skipped selections.
     !---------------------------------------------------------------------------
     function mfarm_run(n_steps, out) bind(C, name="mfarm_run") result(rc)
@@ -854,7 +1159,14 @@ contains
         end if
         n_drv = max(1, min(n_drv, F%n_lanes))
         F%lane_threads = n_drv > 1 .and. F%rng_kind /= 0 .and. .not. allocated(slog) .and. F%n_threads >= 2 * n_drv
-        if (n_steps > 0 .and. F%lane_threads) then
+        if (n_steps > 0 .and. F%window) then
+            F%lane_threads = .false.
+            F%team = F%n_threads
+            rc = mgpu_set_host_team(F%engine, int(F%team, c_int))
+            if (rc /= MGPU_OK) return
+            rc = run_windows(int(n_steps))
+            if (rc /= MGPU_OK) return
+        else if (n_steps > 0 .and. F%lane_threads) then
             F%team = max(1, F%n_threads / n_drv)
             rc = mgpu_set_host_team(F%engine, int(F%team, c_int))
             if (rc /= MGPU_OK) return
@@ -953,7 +1265,22 @@ contains
         integer(c_int), value :: device_build
         want_device_build = device_build /= 0
         want_device_accept = device_build == 2               ! 2: the engine also decides and commits
+        want_window = device_build == 3                      ! 3: one launch per lane step (mgpu_farm_window_submit)
     end subroutine mfarm_configure
+
+    ! window mode of the selected farm: out(1) = 1 if its steps go through mgpu_farm_window_submit, out(2) = windows of a
+    ! lane in flight, out(3) = steps the device left to the driver so far
+    subroutine mfarm_window_mode(out) bind(C, name="mfarm_window_mode")
+        real(c_double), intent(out) :: out(3)
+        out(1) = merge(1.0_real64, 0.0_real64, F%window)
+        out(2) = real(merge(1, F%depth, F%gcmc), real64)
+        out(3) = real(F%undecided, real64)
+    end subroutine mfarm_window_mode
+
+    subroutine mfarm_set_window_depth(depth) bind(C, name="mfarm_set_window_depth")
+        integer(c_int), value :: depth
+        F%depth = max(1, min(int(depth), int(MGPU_FARM_DEPTH)))
+    end subroutine mfarm_set_window_depth
 
     ! Driver threads of mfarm_run (1: the calling thread drives all lanes in lock step; d > 1: d threads, each driving
     ! lanes d0, d0 + d, ... with a team of n_threads / d).  Measured on MI355X (round 3): two drivers on four lanes lift the

@@ -76,7 +76,8 @@ class FortranFarm:
     def __init__(self, system: System, n_replicas: int, device: int = 0, seed: int = 1,
                  translation_step: float = 0.3, rotation_step: float = 0.3, p_translation: float = 0.5,
                  rng_kind: int = 1, n_threads: int = 8, mol_capacity=None, gcmc=None,
-                 n_lanes: int = 2, n_drivers: int = 1, device_build: bool = False, device_accept: bool = False):
+                 n_lanes: int = 2, n_drivers: int = 1, device_build: bool = False, device_accept: bool = False,
+                 window: bool = False, window_depth: int = 2):
         self.H = lib()
         # mc_farm.f90 keeps up to MAX_FARMS farms; every call below selects this farm's slot first
         free = [k for k in range(FortranFarm.MAX_FARMS) if k not in FortranFarm._slots]
@@ -126,7 +127,11 @@ class FortranFarm:
         self._select()
         # device_accept (with device_build): the engine also applies the acceptance rule and commits accepted candidates
         self.device_accept = bool(device_accept) and self.device_build
-        self.H.mfarm_configure(C.c_int((2 if self.device_accept else 1) if self.device_build else 0))
+        # window (with device_build): one launch per lane step (mgpu_farm_window_submit): the engine builds, evaluates, decides
+        # with the driver's draws and commits; the driver checks every decision.  Falls back to the batched path where the
+        # one-launch kernel does not apply (mgpu_farm_window_capacity).
+        want_window = bool(window) and self.device_build and not self.device_accept
+        self.H.mfarm_configure(C.c_int((3 if want_window else (2 if self.device_accept else 1)) if self.device_build else 0))
         rc = self.H.mfarm_create(self.eng.h, C.c_int(self.R), C.c_int(len(active)), self.active.ctypes.data_as(_ip),
                                  n1.ctypes.data_as(_ip), nmol.ctypes.data_as(_ip), cap.ctypes.data_as(_ip),
                                  C.c_int(max_n1), com.ctypes.data_as(_dp), off.ctypes.data_as(_dp),
@@ -141,6 +146,10 @@ class FortranFarm:
             mat = np.asfortranarray(system.box_matrix, dtype=np.float64)
             rcp = np.asfortranarray(reciprocal, dtype=np.float64)
             self.H.mfarm_set_triclinic(mat.ctypes.data_as(_dp), rcp.ctypes.data_as(_dp), C.c_double(volume))
+        self.H.mfarm_set_window_depth(C.c_int(int(window_depth)))
+        mode = np.zeros(3)
+        self.H.mfarm_window_mode(mode.ctypes.data_as(_dp))
+        self.window = bool(mode[0])
         self.H.mfarm_set_drivers(C.c_int(max(1, int(n_drivers))))     # host threads that share the lanes (mc_farm.f90)
         self.n_drivers = max(1, int(n_drivers))
         self.max_n1 = max_n1
@@ -172,6 +181,13 @@ class FortranFarm:
         rc = self.H.mfarm_run(C.c_int(n_steps), self.stats.ctypes.data_as(_dp))
         _lib.check(rc)
         return int(self.stats[1] - before)
+
+    def window_mode(self):
+        """(window mode on, windows of a lane in flight, steps the device left to the driver so far)."""
+        self._select()
+        mode = np.zeros(3)
+        self.H.mfarm_window_mode(mode.ctypes.data_as(_dp))
+        return bool(mode[0]), int(mode[1]), int(mode[2])
 
     def recalibrate(self):
         self._select()

@@ -593,6 +593,7 @@ def test_large_adsorbate_moves_inserts_and_deletes(refcpu_mod, n_sites):
     eng.commit_candidates([0], [0], [-1], [MGPU_CREATION], csite[None], [1])
     assert eng.num_molecules(0, 0) == n + 1
     amp_close(eng.structure_factor(0), P.amplitude(), "A after the committed insertion")
+    P.set_energy_recip(exp_n[2])                            # AcceptCreationMove: energy%recip_coulomb follows (create_molecule.f90:107-112)
     assert np.array_equal(eng.get_molecules(0, 0)[n], csite)
     # --- deletion of molecule 0 of the now four: energies, then the swap-with-last commit
     P.save_fourier(0, 0)

@@ -10,7 +10,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "maniac_mc_amd", "csrc", "mgpu_engine.hip")
+SRCS = [os.path.join(ROOT, "maniac_mc_amd", "csrc", f) for f in ("mgpu_engine.hip", "mgpu_launch.hip", "mgpu_lanes.hip", "mgpu_windows.hip")]
 
 
 def main():
@@ -20,11 +20,18 @@ def main():
         i = args.index("--filter")
         flt = args[i + 1]
         del args[i:i + 2]
+    err = ""
     with tempfile.TemporaryDirectory() as d:
-        p = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Rpass-analysis=kernel-resource-usage", "-c", SRC,
-                            "-o", os.path.join(d, "e.o")] + args, capture_output=True, text=True, cwd=d)
-    if p.returncode != 0:
-        sys.exit(p.stderr[-4000:])
+        for src in SRCS:
+            p = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fopenmp", "-Rpass-analysis=kernel-resource-usage", "-c", src,
+                                "-o", os.path.join(d, "e.o")] + args, capture_output=True, text=True, cwd=d)
+            if p.returncode != 0:
+                sys.exit(p.stderr[-4000:])
+            err += p.stderr
+
+    class P:
+        stderr = err
+    p = P
     blocks = re.split(r"remark: [^\n]*Function Name: ", p.stderr)[1:]
     names = [b.split("\n")[0].split()[0] for b in blocks]
     dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.splitlines()
