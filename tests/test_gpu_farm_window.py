@@ -93,7 +93,7 @@ def test_farm_window_is_the_batched_device_built_step(name, R):
             assert np.all((v == V_ACC) | (v == V_REJ)) and np.array_equal(v == V_ACC, acc != 0)
             n_acc += int(acc.sum())
         _same_state(a, b, s, R)
-    assert 0 < n_acc < 8 * R
+    assert 0 < n_acc <= 8 * R
     assert b.farm_window_stats() == (8, 0)
     a.close(); b.close()
 
@@ -151,12 +151,13 @@ def test_undecided_steps_stall_the_chain_until_the_host_decides():
     m, move, u, au = _nvt_records(rng, s, R, 0)
     m2, move2, u2, au2 = _nvt_records(rng, s, R, 0)
     move[R - 1] = 0                                           # an idle chain is not stalled by anything
+    move2[R - 1] = 0
     b.farm_window_submit(rep, tt, m, move, u, 0.4, 0.4, au, np.ones(R), T)
     b.farm_window_submit(rep, tt, m2, move2, u2, 0.4, 0.4, au2, np.ones(R), T)          # in flight behind the undecided one
     o, w, v = b.farm_window_wait(R)
     assert np.all(v[:R - 1] == V_UND) and v[R - 1] == V_IDLE
     o_skip, w_skip, v2 = b.farm_window_wait(R)
-    assert np.all(v2[:R - 1] == V_STALLED) and v2[R - 1] in (V_ACC, V_REJ)
+    assert np.all(v2[:R - 1] == V_STALLED) and v2[R - 1] == V_IDLE
     # the host's decision (its own exp) for step 1; the batched path gives the energies to decide from -- the same ones
     live = move != 0
     o1, w1 = a.move_trial(rep[live], tt[live], m[live], move[live], u[live], 0.4, 0.4)
@@ -169,16 +170,13 @@ def test_undecided_steps_stall_the_chain_until_the_host_decides():
     o3, w3, v3 = b.farm_window_wait(R)
     assert np.array_equal(o3[live], o1) and np.array_equal(w3[live], w1)
     assert np.array_equal(v3[live] == V_ACC, yes) and np.all((v3[live] == V_ACC) | (v3[live] == V_REJ))
-    # chain R - 1 took step 2 on the window engine only: bring the twin along, then compare everything
-    o4, w4 = a.move_trial([R - 1], [0], [m2[R - 1]], [move2[R - 1]], u2[R - 1:R], 0.4, 0.4)
-    a.commit_lane(0, [R - 1], [0], [m2[R - 1]], [0], [1 if v2[R - 1] == V_ACC else 0])
     _same_state(a, b, s, R)
     assert b.farm_window_stats()[1] == R - 1
     # and with the margin back the chains run on
     b.chain_set_margin(16 * np.finfo(float).eps)
     b.farm_window_submit(rep, tt, m2, move2, u2, 0.4, 0.4, au2, np.ones(R), T)
     _, _, v5 = b.farm_window_wait(R)
-    assert np.all((v5 == V_ACC) | (v5 == V_REJ))
+    assert np.all((v5[:R - 1] == V_ACC) | (v5[:R - 1] == V_REJ)) and v5[R - 1] == V_IDLE
     a.close(); b.close()
 
 
@@ -191,6 +189,8 @@ def test_farm_window_refusals():
     with pytest.raises(_lib.MgpuError):                       # no molecule frames
         e.farm_window_submit([0, 1], [0, 0], [1, 2], [1, 1], np.zeros((2, 5)), 0.3, 0.3, ones, ones, 300.0)
     for r in range(3):
+        if r:
+            e.replica_copy(r, 0)
         e.set_frames(r, 0, s.com[0], s.offsets[0])
     with pytest.raises(_lib.MgpuError):                       # two records for one replica
         e.farm_window_submit([1, 1], [0, 0], [1, 2], [1, 1], np.zeros((2, 5)), 0.3, 0.3, ones, ones, 300.0)
