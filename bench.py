@@ -329,18 +329,26 @@ def cpu_baseline_gcmc(system, t_act, p_move, translation_step, rotation_step, fu
 
 
 def replicas_sweep(system, counts, device, host_threads, seconds, t_step, r_step):
-    """Throughput against the number of chains a GPU holds (same SPC/E step, same Fortran farm, device-built moves, the
-    rule in Fortran): a farm of R chains advances in lock step, so few chains mean few candidates per launch and the
-    step is a host <-> device latency chain, not arithmetic."""
+    """Throughput against the number of chains a GPU holds (same SPC/E step, same Fortran farm, device-built moves).  A farm
+    of R chains advances in lock step.  Up to 1024 chains a lane step is ONE launch (window mode: mgpu_farm_window_submit --
+    the engine builds, evaluates, decides with the driver's draws and commits; mc_farm.f90 checks every decision against its
+    own rule and keeps two windows in flight); above, the batched path (evaluation launches, the rule in Fortran, a commit
+    launch), which a launch of a thousand chains or more fills."""
     from maniac_mc_amd.fortran_host import FortranFarm
     out = []
     for R in counts:
-        # lanes: measured round 4 at the 10 125-atom box, accepted moves/s with 1 / 2 / 4 lanes: 8 chains 0.115 / 0.098 / 0.10 M,
-        # 64: 0.72 / 0.75 / 0.69, 512: 2.6 / 2.8 / 1.3, 1024: - / 4.9 / 3.4, 2048: - / 6.3 / 5.7, 4096: - / 7.2 / 6.2,
-        # 8192: - / 6.9 / 7.4, 16384: - / 7.2 / 7.7 (a lane's launch should fill the GPU: at nsplit 4 that takes ~1000 chains)
-        lanes = 1 if R < 16 else (2 if R < 8192 else 4)
+        # batched path, lanes: measured round 4 at the 10 125-atom box, accepted moves/s with 1 / 2 / 4 lanes: 8 chains 0.115 / 0.098 /
+        # 0.10 M, 64: 0.72 / 0.75 / 0.69, 512: 2.6 / 2.8 / 1.3, 1024: - / 4.9 / 3.4, 2048: - / 6.3 / 5.7, 4096: - / 7.2 / 6.2,
+        # 8192: - / 6.9 / 7.4, 16384: - / 7.2 / 7.7 (a lane's launch should fill the GPU: at nsplit 4 that takes ~1000 chains).
+        # window mode, round 5 (profiles/r05/farm_window_nsplit.txt): one lane up to 256 chains, two from 512
+        window = R <= 1024
+        if window:
+            lanes = 1 if R < 512 else 2
+        else:
+            lanes = 2 if R < 8192 else 4
         farm = FortranFarm(system, R, device=device, seed=77, translation_step=t_step, rotation_step=r_step, p_translation=0.5,
-                           n_threads=max(1, min(host_threads, 2 if R < 512 else 4)), n_lanes=lanes, n_drivers=1, device_build=True)
+                           n_threads=max(1, min(host_threads, 2 if R < 512 else 4)), n_lanes=lanes, n_drivers=1, device_build=True,
+                           window=window, window_depth=2)
         try:
             farm.run(20)
             chunk = 50
@@ -357,7 +365,11 @@ def replicas_sweep(system, counts, device, host_threads, seconds, t_step, r_step
                     break
             out.append({"replicas": R, "lanes": farm.n_lanes, "value": acc / el, "unit": "accepted MC moves/s",
                         "trial_moves_per_s": steps * R / el, "steps": steps, "us_per_step": el / steps * 1e6,
-                        "per_chain_steps_per_s": steps / el, "engine_nsplit_note": "engine constant of this replica count"})
+                        "per_chain_steps_per_s": steps / el,
+                        "path": ("window: one launch per lane step, two in flight (mgpu_farm_window_submit)" if farm.window
+                                 else "batched: mgpu_move_trial_submit / wait, rule in Fortran, mgpu_commit_submit"),
+                        "steps_left_to_the_driver": farm.window_mode()[2],
+                        "engine_nsplit_note": "engine constant of this replica count"})
         finally:
             farm.close()
     return out
@@ -534,7 +546,7 @@ def main():
     if args.configs is None:
         args.configs = 1 if default_run else 0
     if args.replicas_sweep is None:
-        args.replicas_sweep = "1,8,64,512,4096" if default_run else ""
+        args.replicas_sweep = "1,8,64,512,1024,4096" if default_run else ""
     if args.replicas is None:
         args.replicas = WORKLOADS[wl]["replicas"]
     if args.lanes is None:

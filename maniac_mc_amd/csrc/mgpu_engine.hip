@@ -144,7 +144,7 @@ bool replica_in_range(const mgpu_engine *e, int replica) {
 // chains, see below) -- 4 at 2048
 // replicas, 2 at 8192 (measured at the 10 125-atom box, 1024 fused items per launch: 4 -> 98.9 us, 8 -> 104.6 us,
 // 16 -> 116 us; 2048 items per launch on four lanes: 2 -> 6.94 M, 4 -> 6.79 M, 8 -> 6.52 M accepted moves/s).
-// A small engine (< 256 replicas: single chains, a handful of chains) is latency-bound: up to 32 waves per item, two sweep
+// A small engine (< 48 replicas: single chains, a handful of chains) is latency-bound: up to 32 waves per item, two sweep
 // units per wave (round 4, one chain, stage stamps of mgpu_chain_window: 10 125-atom box 59 -> 32 waves 16.7 -> 15.2 us to
 // the window's results, 128 waves 15.1 us with a longer reduction; framework box 5 -> 32 waves 21.1 -> 12.1 us).
 // MGPU_PAIR_NSPLIT overrides it (tuning only; read once at engine creation).
@@ -155,7 +155,19 @@ int engine_nsplit(const mgpu_engine *e) {
         units += e->tp.site_major[t] ? cap * ((n1 + 63) / 64) : n1 * ((cap + 63) / 64);
     }
     int cap_split = 32, per_wave = 2;
-    if (e->n_replicas >= 256) {
+    if (e->n_replicas >= 48 && e->n_replicas <= 1024) {
+        // The farm-window regime (round 5: one launch per lane step, mgpu_farm_window_submit; a launch carries 2 nsplit pair
+        // waves per chain): the launch should fill the GPU's 4096 wave slots about once -- fewer waves leave it idle, more
+        // run in rounds whose fixed costs (table staging, per-plane latency) add up.  Measured at the 10 125-atom box, one
+        // lane, two windows in flight, accepted moves/s at nsplit 2 / 4 / 8 / 16 / 32: 64 chains 0.85 / 1.32 / 1.72 / 2.04 /
+        // 1.45 M, 128: 1.65 / 2.53 / 3.29 / 2.55 / 2.00 M, 256: 3.17 / 4.73 / 4.10 / 3.39 / 2.44 M, 512: 5.87 / 5.49 (6.06 on
+        // two lanes) / 4.51 / 3.79 / 2.63 M, 1024: 5.58-5.91 / 5.26-5.64 / 4.34-4.91 / 3.56 / 2.06 M
+        // (profiles/r05/farm_window_nsplit.txt).  The batched path of such an engine is the fallback only (it preferred
+        // 16 / 8 / 4 at 256 / 512 / 1024 chains: 1.42 / 2.40 / 4.84 M).
+        const int want = (e->n_replicas < 512 ? 1024 : 2048) / e->n_replicas;
+        cap_split = 2;
+        while (cap_split * 2 <= std::min(want, 32)) cap_split *= 2;
+    } else if (e->n_replicas >= 256) {
         per_wave = 8;
         int want = std::max(1, e->n_cu * 64 / e->n_replicas);
         // Short work units (the grand-canonical boxes: a few dozen units per item, and a launch carries 1.5 items per

@@ -2472,12 +2472,19 @@ __device__ __forceinline__ void farm_resolve(const Topo &tp, const BoxDev &bx, d
             else verdict = rec.acc_u <= pr ? kFarmVerdictAccepted : kFarmVerdictRejected;
         }
     }
-    // ---- energies + verdict into pinned host memory, the tag behind them
-    if (lane < 5) ho[lane] = o[lane];
-    else if (lane < 10) ho[lane] = w[lane - 5];
-    else if (lane == 10) ho[10] = (double)verdict;
-    __threadfence_system();
-    if (lane == 0) __hip_atomic_store(g.host_tag + c, g.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ---- energies + verdict into pinned host memory, the tag behind them.  No system-scope FENCE: a fence writes back the
+    // XCD's whole L2 -- every chain's freshly stored A + delta -- once per chain (measured: 256 chains per launch took as
+    // long as 512, ~94 us, and two lanes' launches ran at half speed).  The block is fine-grained host memory: the stores
+    // are system-scope write-through stores, the wave waits for them to be acknowledged, then stores the tag.
+    {
+        double val = 0.0;
+        if (lane < 5) val = o[lane];
+        else if (lane < 10) val = w[lane - 5];
+        else if (lane == 10) val = (double)verdict;
+        if (lane < kFarmOut) __hip_atomic_store(ho + lane, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(g.host_tag + c, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // ---- the chain's device state: ticket, stall flag, and the accepted step itself
     if (lane == 0) {
         __hip_atomic_store(g.tickets + c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
