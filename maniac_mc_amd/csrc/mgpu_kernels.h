@@ -2426,9 +2426,12 @@ static_assert(sizeof(BoxDev) + sizeof(FarmArgs) + 160 <= 4096, "a farm window mu
 
 // One chain resolved by ONE WAVE (all 64 lanes arrive): `scratch` = 4 nsplit + 4 doubles of LDS of its own.
 __device__ __forceinline__ void farm_resolve(const Topo &tp, const BoxDev &bx, double *__restrict__ pos, int *__restrict__ nmol,
-                                             const FarmArgs &g, const FarmRec &rec, int skip, int c, int lane, double *scratch) {
+                                             const FarmArgs &g, const FarmRec &rec, int c, int lane, double *scratch) {
     double *ho = g.host_out + (size_t)kFarmOut * c;
     int verdict;
+    // the roles sweep whatever the replica's stall flag says (they only read, and the k role's A + delta goes to the buffer
+    // that is NOT current): the flag is looked at here, once, beside the partials -- not on every role's critical path
+    const int skip = rec.move == 0 || (rec.forced == 0 && g.stalled[rec.replica] != 0);
     double o[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, w[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     const int kind = rec.move <= 2 ? 0 : (rec.move == 3 ? 1 : 2);
     if (skip) {
@@ -2546,39 +2549,36 @@ __global__ __launch_bounds__(kChainBlock, 1) void farm_window_kernel(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = g.n, ns = g.nsplit, wpc = 2 * ns, expected = wpc + 1;
+    // Workgroup -> (chain, role): pair workgroups first, 8 consecutive work units each (a workgroup may serve several
+    // chains), then one k workgroup per chain.  (Measured and dropped, round 5: a chain's workgroups congruent modulo 8 --
+    // one XCD, one L2 per chain under the observed round-robin placement: no gain at 8 chains, 64 chains 2.05 -> 1.86 M,
+    // 512: 5.5 -> 3.9 M on one lane: a chain's work units read DISJOINT atoms, so one L2 saves nothing and its channels
+    // become the chain's bottleneck.)
     const int n_pair_wg = (n * wpc + kPairWaves - 1) / kPairWaves;
     const bool k_role = (int)blockIdx.x >= n_pair_wg;
-    // chains this workgroup works for: [c_lo, c_lo + n_c)
-    int c_lo, n_c;
+    int c_lo, n_c, w0 = 0, w1 = 0;             // chains [c_lo, c_lo + n_c) and global pair work units [w0, w1) of this workgroup
     if (k_role) { c_lo = (int)blockIdx.x - n_pair_wg; n_c = 1; }
     else {
-        const int w0 = (int)blockIdx.x * kPairWaves, w1 = min(w0 + kPairWaves, n * wpc) - 1;
-        c_lo = w0 / wpc; n_c = w1 / wpc - c_lo + 1;
+        w0 = (int)blockIdx.x * kPairWaves;
+        w1 = min(w0 + kPairWaves, n * wpc);
+        c_lo = w0 / wpc; n_c = (w1 - 1) / wpc - c_lo + 1;
     }
     // ---- records: ten 8-byte words per chain from the kernel arguments (few chains) or from pinned host memory
     {
         const double *src = reinterpret_cast<const double *>((n <= kFarmInline ? g.inline_recs : g.recs) + c_lo);
         if (tid < 10 * n_c) reinterpret_cast<double *>(s_rec)[tid] = src[tid];
     }
-    __syncthreads();
-    int my_acur = 0, my_stalled = 0;
-    if (tid < n_c) {
-        const FarmRec &r = s_rec[tid];
-        if (r.move != 0) { my_stalled = g.stalled[r.replica]; my_acur = g.acur[r.replica]; }
-    }
     if (!k_role) {
-        // (the table staging runs under the two loads above)
+        // (the table staging runs under the records' load)
         for (int i = tid; i < (bx.coul_last_row + 1) * kCoulRowVec; i += kChainBlock)
             reinterpret_cast<double2 *>(s_dyn)[i] = reinterpret_cast<const double2 *>(coul_tab_g)[i];
         const int nt = tp.n_types;
         for (int i = tid; i < nt * nt; i += kChainBlock) s_pair[i] = pair_tab[i];
         if (FLAT && tid < kMaxGrp) s_grp[tid] = make_int4(tp.grp_start[tid], tp.grp_cnt[tid], tp.grp_ty[tid], 0);
     }
-    if (tid < n_c) {
-        const FarmRec &r = s_rec[tid];
-        s_skip[tid] = (r.move == 0 || (my_stalled != 0 && r.forced == 0)) ? 1 : 0;
-        if (tid == 0) s_acur = my_acur;
-    }
+    __syncthreads();
+    if (tid < n_c) s_skip[tid] = s_rec[tid].move == 0 ? 1 : 0;          // (a stalled replica is the resolver's business)
+    if (k_role && tid == 0) s_acur = s_rec[0].move != 0 ? g.acur[s_rec[0].replica] : 0;
     __syncthreads();
 
     if (k_role) {
@@ -2626,9 +2626,9 @@ __global__ __launch_bounds__(kChainBlock, 1) void farm_window_kernel(
         }
     } else {
         // ---------------- pair role: one wave per (chain, entry, split); entry 0 = the resident molecule, 1 = the candidate
-        const int wg = (int)blockIdx.x * kPairWaves + wave;
+        const int wg = w0 + wave;
         const int c = wg / wpc, j = wg - c * wpc;
-        if (c < n && !s_skip[c - c_lo]) {
+        if (wg < w1 && !s_skip[c - c_lo]) {
             const FarmRec &rec = s_rec[c - c_lo];
             const int kind = rec.move <= 2 ? 0 : (rec.move == 3 ? 1 : 2);
             const int ent = j / ns, split = j - ent * ns;
@@ -2676,7 +2676,6 @@ __global__ __launch_bounds__(kChainBlock, 1) void farm_window_kernel(
     if (tid < n_c) {
         int count = 1;
         if (!k_role) {
-            const int w0 = (int)blockIdx.x * kPairWaves, w1 = min(w0 + kPairWaves, n * wpc);
             const int a = max(w0, (c_lo + tid) * wpc), b = min(w1, (c_lo + tid + 1) * wpc);
             count = b - a;
         }
@@ -2685,7 +2684,7 @@ __global__ __launch_bounds__(kChainBlock, 1) void farm_window_kernel(
     __syncthreads();
     if (wave < n_c && s_resolve[wave]) {
         double *scratch = reinterpret_cast<double *>(s_dyn) + (size_t)wave * (4 * ns + 4);
-        farm_resolve(tp, bx, pos, nmol, g, s_rec[wave], s_skip[wave], c_lo + wave, lane, scratch);
+        farm_resolve(tp, bx, pos, nmol, g, s_rec[wave], c_lo + wave, lane, scratch);
     }
 }
 
