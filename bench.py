@@ -500,10 +500,12 @@ def main():
                     help="1: the engine keeps the molecules' frames and builds the trial moves on the device (no host mirror, no "
                          "candidate rows staged); 0: the Fortran driver builds them from its mirror (default: see WORKLOADS)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
-    ap.add_argument("--exchange", choices=["torch", "c-abi"], default="torch",
-                    help="the per-block all-gather of counters + uptake histogram: through torch.distributed (default: the "
-                         "tested path) or through the C ABI (mgpu_comm_create / mgpu_allgather_block_stats: RCCL called from "
-                         "libmaniac_hip.so, what a Fortran host uses; the id travels over the torch.distributed group)")
+    ap.add_argument("--exchange", choices=["torch", "c-abi"], default=None,
+                    help="the per-block all-gather of counters + uptake histogram: through the C ABI (mgpu_comm_create / "
+                         "mgpu_allgather_block_stats: RCCL called from libmaniac_hip.so, what a Fortran host uses; the id travels "
+                         "over the torch.distributed group) -- the default with --host fortran and the nccl backend -- or through "
+                         "torch.distributed (the default otherwise).  If the C-ABI communicator cannot be created on every rank "
+                         "within 90 s the ranks agree to fall back to torch.distributed and the line's `exchange` block says so.")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-timing", type=int, default=1, choices=[0, 1],
@@ -578,7 +580,12 @@ def main():
                float(len(pts)), float(pts[0] if pts else -1)]
         table, _ = exchange.gather_block_stats(row)
         if rank == 0:
+            # the exchange block a real run's line carries (values are placeholders here: no engine ran)
+            want = args.exchange or ("c-abi" if (args.host == "fortran" and args.dist_backend == "nccl") else "torch")
             print(json.dumps({"dry_run": True, "n_gpus": world, "workload": wl,
+                              "exchange": {"path": "torch", "would_default_to": want, "ranks_seen": int(table.shape[0]),
+                                           "per_rank_value": [0.0] * int(table.shape[0]),
+                                           "per_rank_device": [int(r[2]) for r in table]},
                               "ranks": [dict(rank=int(r[0]), local_rank=int(r[1]), device=int(r[2]), host_threads=int(r[3]),
                                              replicas=int(r[4]), fugacity_points=int(r[5]), first_point=int(r[6]))
                                         for r in table]}))
@@ -683,11 +690,33 @@ def main():
 
     from maniac_mc_amd import exchange
     comm = None
+    exchange_note = None
+    if args.exchange is None:
+        args.exchange = "c-abi" if (args.host == "fortran" and (world == 1 or args.dist_backend == "nccl")) else "torch"
     if args.exchange == "c-abi":
         uid = [exchange.CAbiComm.unique_id() if (rank == 0 and world > 1) else None]
         if world > 1:
             dist.broadcast_object_list(uid, src=0)
-        comm = exchange.CAbiComm(device=device, rank=rank, world=world, unique_id=uid[0])
+        # RCCL's communicator creation is collective: made on a side thread with a deadline, and the ranks then AGREE (over
+        # the torch.distributed group) whether every one of them has it -- a rank that failed or is still waiting makes all
+        # of them use the torch.distributed gather instead, and the line says so
+        import threading
+        box = {}
+
+        def make():
+            try:
+                box["comm"] = exchange.CAbiComm(device=device, rank=rank, world=world, unique_id=uid[0])
+            except Exception as exc:                       # noqa: BLE001 -- reported in the line
+                box["error"] = str(exc)
+        th = threading.Thread(target=make, daemon=True)
+        th.start()
+        th.join(90.0)
+        ok = 1.0 if "comm" in box else 0.0
+        all_ok = exchange.min_over_ranks(ok) if world > 1 else ok
+        if all_ok >= 1.0:
+            comm = box["comm"]
+        else:
+            exchange_note = box.get("error") or ("this rank's communicator was not ready after 90 s" if not ok else "another rank has no communicator")
     gather = comm.gather_block_stats if comm is not None else exchange.gather_block_stats
 
     def fence():
@@ -715,7 +744,7 @@ def main():
                                    for p in range(ISOTHERM_POINTS)])
         else:
             hist = exchange.molecule_count_histogram(counts, nbins)
-    sums_by_rank, hist_by_rank = gather([float(accepted), trials_now, evals_now], hist)
+    sums_by_rank, hist_by_rank = gather([float(accepted), trials_now, evals_now, float(device)], hist)
     fence()
     elapsed = exchange.max_over_ranks(time.perf_counter() - t0)
     tot_acc, tot_trials, tot_evals = (float(sums_by_rank[:, k].sum()) for k in range(3))
@@ -938,10 +967,16 @@ def main():
                                 "N_min": int(nn[hist_pts[p] > 0].min()) if hist_pts[p].sum() else None,
                                 "N_max": int(nn[hist_pts[p] > 0].max()) if hist_pts[p].sum() else None}
                                for p in range(ISOTHERM_POINTS)]
-        if wl != "spce":
-            out["exchange"] = {"collective": "all_gather", "backend": args.dist_backend if world > 1 else None,
-                               "through": "C ABI (mgpu_allgather_block_stats, RCCL from libmaniac_hip.so)" if comm is not None else "torch.distributed",
-                               "bytes_per_rank": int(hist.nbytes + 24), "per": "block (= the timed region)"}
+        # what the gathered table says about the run itself: one row per rank, in rank order
+        out["exchange"] = {"collective": "all_gather", "backend": args.dist_backend if world > 1 else None,
+                           "path": "c-abi" if comm is not None else "torch",
+                           "through": "C ABI (mgpu_allgather_block_stats, RCCL from libmaniac_hip.so)" if comm is not None else "torch.distributed",
+                           "ranks_seen": int(sums_by_rank.shape[0]),
+                           "per_rank_value": [float(sums_by_rank[r, 0]) / elapsed for r in range(sums_by_rank.shape[0])],
+                           "per_rank_device": [int(sums_by_rank[r, 3]) for r in range(sums_by_rank.shape[0])],
+                           "bytes_per_rank": int(hist.nbytes + 32), "per": "block (= the timed region)"}
+        if exchange_note:
+            out["exchange"]["c_abi_fallback"] = exchange_note
         if timers0 is not None:
             out["host_seconds"] = {k: v - timers0[k] for k, v in timers1.items()}   # timed region only
     farm.close()

@@ -138,6 +138,12 @@ int mgpu_coulomb_table_eval(double alpha, double r2_max, int n, const double *r2
  * reference seeds ONE intrinsic generator with seed + 37 (i - 1) (random_utils.f90:33-56); a farm needs R
  * statistically independent streams instead (host utility, no device involved). */
 int mgpu_rng_seed_streams(long long seed, int n_streams, long long *state);
+/* The next n_per uniform numbers in [0, 1) of each of n_streams CONSECUTIVE streams (state = the first stream's four
+ * words; out[n_streams][n_per]): xoshiro256+, the top 53 bits of s0 + s3 times 2^-53 -- the numbers of mc_farm.f90's
+ * chain_random, bit for bit, four streams abreast (AVX2 where the CPU has it).  A farm draws ten numbers per chain and
+ * step (src/random_utils.f90:13-56 is the reference's one serial generator); generated one stream at a time that was a
+ * quarter of a grand-canonical farm's host time. */
+int mgpu_rng_fill(long long *state, int n_streams, int n_per, double *out);
 /* Software prefetch of `bytes` bytes at p into the calling core's caches (host utility for Fortran callers, which
  * have no prefetch intrinsic: the farm driver announces the mirror records it is about to gather). */
 void mgpu_host_prefetch(const void *p, int bytes);

@@ -23,7 +23,7 @@ KERNEL_PAIR, KERNEL_RECIP, KERNEL_COMMIT, KERNEL_SFACTOR = 0, 1, 2, 3
 # every symbol include/maniac_gpu.h declares (tests check the library exports each of them)
 EXPORTS = [
     "mgpu_last_error", "mgpu_abi_version", "mgpu_device_count", "mgpu_box_prepare", "mgpu_ewald_setup",
-    "mgpu_ewald_kvectors", "mgpu_coulomb_table_eval", "mgpu_rng_seed_streams", "mgpu_host_prefetch", "mgpu_engine_create", "mgpu_engine_destroy", "mgpu_engine_get_ewald",
+    "mgpu_ewald_kvectors", "mgpu_coulomb_table_eval", "mgpu_rng_seed_streams", "mgpu_rng_fill", "mgpu_host_prefetch", "mgpu_engine_create", "mgpu_engine_destroy", "mgpu_engine_get_ewald",
     "mgpu_engine_get_kvectors", "mgpu_replica_set_molecules", "mgpu_replica_get_molecules",
     "mgpu_replica_num_molecules", "mgpu_replica_copy", "mgpu_system_energy", "mgpu_init_structure_factor",
     "mgpu_get_structure_factor", "mgpu_set_structure_factor", "mgpu_structure_factor_add", "mgpu_pair_energy_candidates",

@@ -69,6 +69,10 @@ def max_over_ranks(value: float) -> float:
     return float(t.item())
 
 
+def min_over_ranks(value: float) -> float:
+    return -max_over_ranks(-float(value))
+
+
 def molecule_count_histogram(counts, nbins):
     """Histogram of the replicas' current molecule counts (the uptake histogram of an isotherm point)."""
     c = np.clip(np.asarray(counts, dtype=np.int64), 0, nbins - 1)

@@ -100,6 +100,13 @@ module maniac_gpu
             integer(c_long_long), intent(out) :: state(*)
             integer(c_int) :: rc
         end function
+        function mgpu_rng_fill(state, n_streams, n_per, u) bind(C, name="mgpu_rng_fill") result(rc)
+            import :: c_int, c_long_long, c_double
+            integer(c_long_long), intent(inout) :: state(*)
+            integer(c_int), value :: n_streams, n_per
+            real(c_double), intent(out) :: u(*)
+            integer(c_int) :: rc
+        end function
         function mgpu_replica_replace_molecule(e, replica, t, m_dst, m_src) &
                 bind(C, name="mgpu_replica_replace_molecule") result(rc)
             import :: c_ptr, c_int

@@ -59,6 +59,7 @@ module mc_farm
     real(real64), parameter :: PROB_CREATE_DELETE = 0.5d0
     integer, parameter :: MIN_TRIALS_FOR_RECALIBRATION = 500
     integer, parameter :: NRAND = 10                      ! uniform numbers consumed per trial
+    integer, parameter :: RNG_BLOCK = 256                 ! chains per mgpu_rng_fill call
     ! internal move codes; engine kinds are MGPU_MOVE / MGPU_CREATION / MGPU_DELETION
     integer, parameter :: MV_TRANSLATION = 1, MV_ROTATION = 2, MV_CREATION = 3, MV_DELETION = 4
 
@@ -534,10 +535,17 @@ contains
         !            random access is DRAM / TLB-latency bound and the threads overlap the misses -- and
         !            build the move.
         !$omp parallel num_threads(F%team) private(i, j, k, n1, d, x, axis, a, r, ia, slot, v, frac, n, mv, draw)
+        ! the chains' own generators, blocks of RNG_BLOCK consecutive chains at a time (mgpu_rng_fill: four streams abreast)
+        if (F%rng_kind /= 0) then
+            !$omp do schedule(static)
+            do i = 1, L%n, RNG_BLOCK
+                k = mgpu_rng_fill(F%cxs(:, L%first + i), int(min(RNG_BLOCK, L%n - i + 1), c_int), int(NRAND, c_int), L%u(:, i))
+            end do
+            !$omp end do
+        end if
         !$omp do schedule(static)
         do i = 1, L%n
             r = L%first + i
-            if (F%rng_kind /= 0) call chain_random(r, L%u(:, i))
             ia = min(int(L%u(1, i) * F%n_active) + 1, F%n_active)      ! PickRandomResidueType
             n = F%cnt(ia, r)
             draw = L%u(3, i)
@@ -909,6 +917,7 @@ contains
         integer(c_int) :: rc
         integer :: i, b, r, ia, mv, slot, k, d
         integer(int64) :: c0, c1, c2
+        logical :: filled
         type(lane_buffers), pointer :: L
         L => F%lane(g)
         rc = MGPU_OK
@@ -918,6 +927,13 @@ contains
         if (F%rng_kind == 0) then
             do i = 1, L%n
                 if (L%pend_n(i) == 0 .and. L%issued(i) < n_target) call random_number(L%w_u(:, i, b))
+            end do
+        end if
+        ! the usual case -- every chain takes a fresh step -- draws in blocks (mgpu_rng_fill: four streams abreast)
+        filled = F%rng_kind /= 0 .and. all(L%pend_n(1:L%n) == 0) .and. all(L%issued(1:L%n) < n_target)
+        if (filled) then
+            do i = 1, L%n, RNG_BLOCK
+                k = mgpu_rng_fill(F%cxs(:, L%first + i), int(min(RNG_BLOCK, L%n - i + 1), c_int), int(NRAND, c_int), L%w_u(:, i, b))
             end do
         end if
         !$omp parallel do num_threads(F%team) schedule(static) private(i, r, ia, mv, slot, k, d) if (F%team > 1 .and. L%n >= 256)
@@ -934,7 +950,7 @@ contains
                 L%forced(i) = int(L%pend_forced(i), c_int)
                 L%pend_forced(i) = 0
             else if (L%issued(i) < n_target) then
-                if (F%rng_kind /= 0) call chain_random(r, L%w_u(:, i, b))
+                if (F%rng_kind /= 0 .and. .not. filled) call chain_random(r, L%w_u(:, i, b))
                 L%issued(i) = L%issued(i) + 1
             else
                 L%w_live(i, b) = 0                                      ! nothing left for this chain: a filler

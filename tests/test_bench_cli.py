@@ -30,6 +30,10 @@ def test_gpus_2_dry_run_spawns_two_ranks_and_gathers_a_rank_ordered_table():
     assert [r["first_point"] for r in d["ranks"]] == [0, 1]            # fugacity points dealt round-robin
     assert sum(r["fugacity_points"] for r in d["ranks"]) == 8
     assert all(r["host_threads"] >= 1 for r in d["ranks"])
+    # the keys a scaling run's line carries: which gather ran, how many ranks it saw, every rank's device
+    ex = d["exchange"]
+    assert ex["ranks_seen"] == 2 and ex["per_rank_device"] == [0, 1] and len(ex["per_rank_value"]) == 2
+    assert ex["would_default_to"] == "torch"                           # gloo rehearsal; with nccl + the Fortran host: c-abi
 
 
 def test_world_size_must_match_gpus_flag():
@@ -61,6 +65,11 @@ def test_isotherm_two_gloo_ranks_on_one_gpu_histogram_matches_rank_counts(tmp_pa
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["config"]["workload"].startswith("co2_isotherm")
     assert d["value"] > 0 and len(d["isotherm"]) == 8
+    # the gathered table describes the run: both ranks seen, in rank order, each with its own rate and device
+    ex = d["exchange"]
+    assert ex["path"] == "torch" and ex["ranks_seen"] == 2 and ex["per_rank_device"] == [0, 0]
+    assert len(ex["per_rank_value"]) == 2 and all(v > 0 for v in ex["per_rank_value"])
+    assert abs(sum(ex["per_rank_value"]) - d["value"]) <= 1e-6 * d["value"]
     counts = {p: [] for p in range(8)}
     for r in range(2):
         z = np.load(tmp_path / f"rank{r}.npz")

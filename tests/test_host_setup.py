@@ -234,3 +234,28 @@ def test_atom_record_formatter_is_the_fortran_runtimes(tmp_path):
     bad = xyz.copy(); bad[3, 1] = np.nan
     assert L.mgpu_append_atom_records(p1.encode(), C.c_int(m), C.c_int(1), None, ty.ctypes.data_as(ip), None, bad.ctypes.data_as(dp)) != 0
     assert open(p1).read() == want1                       # nothing was written by the failed call
+
+
+def test_rng_fill_is_the_scalar_generator(hiplib):
+    """mgpu_rng_fill (four xoshiro256+ streams abreast, AVX2 where the CPU has it) against the recurrence written out in
+    Python integers -- the numbers of mc_farm.f90's chain_random: top 53 bits of s0 + s3 times 2^-53 -- for stream counts
+    around the vector width, and the states it leaves behind."""
+    import ctypes as C
+    M = (1 << 64) - 1
+    for n in (1, 3, 4, 7, 33):
+        st = np.zeros((n, 4), dtype=np.int64)
+        assert hiplib.mgpu_rng_seed_streams(C.c_longlong(1234), C.c_int(n), st.ctypes.data_as(C.POINTER(C.c_longlong))) == 0
+        ref_state = [[int(x) & M for x in row] for row in st]
+        per = 11
+        out = np.zeros((n, per))
+        assert hiplib.mgpu_rng_fill(st.ctypes.data_as(C.POINTER(C.c_longlong)), C.c_int(n), C.c_int(per),
+                                    out.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        for r in range(n):
+            s0, s1, s2, s3 = ref_state[r]
+            for i in range(per):
+                assert out[r, i] == float(((s0 + s3) & M) >> 11) * 2.0 ** -53, (n, r, i)
+                t = (s1 << 17) & M
+                s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3
+                s2 ^= t
+                s3 = ((s3 << 45) | (s3 >> 19)) & M
+            assert [int(x) & M for x in st[r]] == [s0, s1, s2, s3], (n, r)
