@@ -201,8 +201,6 @@ struct mgpu_engine {
     int pair_blocks_per_cu = kPairBlock >= 1024 ? 1 : 2;      // resident pair-sweep workgroups per CU (VGPR / LDS bound)
     int pair_nsplit = 1;             // waves per pair-sweep item: an engine constant (see engine_nsplit)
     std::vector<double> self_of_type; // ComputeEwaldSelfInteractionSingleMol per residue type (host constant)
-    bool pair_fuse = true;           // trial moves sweep old + new together (MGPU_PAIR_NO_FUSE=1: tuning / A-B only)
-    int pair_fuse_max = kMaxFusedSites;   // largest molecule whose trial moves are fused (MGPU_PAIR_FUSE_MAX: up to kMaxFusedSitesWide)
     bool pair_fast_fold = true;      // two-instruction minimum-image fold where the atoms' range allows it (MGPU_PAIR_EXACT_FOLD=1: off)
     bool recip_force_per_k = false;  // MGPU_RECIP_PER_K=1: per-k reciprocal kernel even where the row form fits (tests)
     double *d_res_q = nullptr;
@@ -222,9 +220,6 @@ struct mgpu_engine {
     std::vector<int> frozen_diff;
     bool frozen_batch = true;
     int host_team = 1;               // host threads the per-candidate loops of submit / wait / commit may use (mgpu_set_host_team)
-    int frozen_chunk = 0;            // framework atoms per pair_frozen_kernel work unit; 0 = frozen_chunk_atoms' rule.  The chunk
-                                     // partials are summed in order, so the chunking depends on the framework's size alone,
-                                     // never on the batch (MGPU_FROZEN_CHUNK, <= 64, overrides)
     // molecule frames (mgpu_replica_set_frames): com [R][3][n_mol_slots], off [R][3][Ncap]; allocated on first use
     double *d_com = nullptr, *d_off = nullptr;
     std::vector<char> frames_ok;     // [R][n_res]: the frames of (replica, type) mirror its sites

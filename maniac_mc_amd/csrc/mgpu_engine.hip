@@ -347,7 +347,6 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     e->frozen_same.assign((size_t)n_replicas * n_res, 0);
     e->frozen_diff.assign(n_res, n_replicas);
     e->frozen_batch = std::getenv("MGPU_NO_FROZEN_BATCH") == nullptr;
-    if (const char *ov = std::getenv("MGPU_FROZEN_CHUNK")) e->frozen_chunk = std::max(1, std::min(std::atoi(ov), 64));
     e->frames_tight.assign((size_t)n_replicas * n_res, 0);
     // Layout of the big inactive residues and the register-site pair kernel go together: "frozen" (sites sorted by
     // atom type, one group per type present) + pair_flat_kernel, or site-major + pair_sweep_kernel.  Default: flat
@@ -396,7 +395,7 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
         for (int t = 0; t < n_res; ++t) framework = framework || (tp.n1[t] >= 64 && is_active[t] == 0);
         bool want_flat = framework;
         if (const char *ov = std::getenv("MGPU_PAIR_FLAT")) want_flat = std::atoi(ov) != 0;
-        build_layout(want_flat && std::getenv("MGPU_NO_FROZEN") == nullptr);
+        build_layout(want_flat);
         bool ok = e->box_type != 3 && (int)grp_tab.size() <= kMaxGrp;
         int planes = 0;                        // one lane of a wave builds one plane's record
         for (int t = 0; t < n_res; ++t) {
@@ -412,9 +411,7 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
             tp.grp_ty[g] = g < grp_tab.size() ? grp_tab[g].z : 0;
         }
     }
-    e->pair_fuse = std::getenv("MGPU_PAIR_NO_FUSE") == nullptr;
     e->pair_fast_fold = std::getenv("MGPU_PAIR_EXACT_FOLD") == nullptr;
-    if (const char *ov = std::getenv("MGPU_PAIR_FUSE_MAX")) e->pair_fuse_max = std::max(1, std::min(std::atoi(ov), kMaxFusedSitesWide));
     e->recip_force_per_k = std::getenv("MGPU_RECIP_PER_K") != nullptr;
 
     BoxDev &bx = e->bx;

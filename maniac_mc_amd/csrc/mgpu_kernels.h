@@ -50,7 +50,7 @@ constexpr int kMaxTypes = 16;     // atom types (LDS pair table 16 x 16 x 16 B =
 constexpr int kMaxGrp = 32;       // atom-type groups of all frozen residues of a topology together
 constexpr int kFlatMaxPlanes = 64;  // planes of a replica pair_flat_kernel handles (one lane builds one plane's record)
 constexpr int kMaxFusedSites = 3; // trial moves of molecules up to this size sweep old + new together (2 NS register sites) at 4 waves per SIMD
-constexpr int kMaxFusedSitesWide = 5;   // ... and up to this size in the wide instantiations (<= 256 VGPRs, 2 waves per SIMD; engine switch)
+constexpr int kMaxFusedSitesWide = 5;   // largest molecule of the register-site sweeps (larger ones: the LDS-staged NS = 0 sweep)
 
 struct Topo {
     int n_res;
@@ -206,10 +206,12 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // Index path, two instructions (round 4; it was four): sh = the high word of s shifted down to (exponent | 6 mantissa bits),
 // address = sh * 48 + tab_adj in ONE v_mad_u32_u24, where tab_adj = table - idx_base * 48 (coul_tab_adjusted) carries the
 // subtraction of the table's first index.  There is NO clamp: a minimum-image r^2 cannot lie beyond the table (it is built
-// up to the box's largest minimum-image distance), and an s BELOW the table (r < 0.5 A: sh < idx_base) makes the 32-bit
-// address wrap far outside the workgroup's LDS allocation, where ds_read returns zeros and raises nothing
-// (tools/probe_lds_oob.hip, measured on MI355X) -- the caller replaces those lanes by the slow path anyway: it keeps
-// the smallest sh of a unit (`sh_min`: v_min3_u32, one instruction per two or three terms) and compares once.
+// up to the box's largest minimum-image distance), and an s BELOW the table (r < 0.5 A: sh < idx_base) makes the address
+// fall outside the table -- just below it into the workgroup's other LDS arrays, or wrapped far outside the allocation.
+// Such a read raises nothing (tools/probe_lds_oob.hip, measured on MI355X) but its VALUE IS UNDEFINED (stale LDS bytes
+// near the allocation, zeros far from it): every caller MUST look at `sh_out` and replace those lanes by the slow path --
+// it keeps the smallest sh of a unit (`sh_min`: v_min3_u32, one instruction per two or three terms) and compares once.
+// (`sh_out` is a reference parameter, not a return value to ignore: a call site that drops it does not compile.)
 __device__ __forceinline__ const char *coul_tab_adjusted(const char *tab, int idx_base) {
     return tab - (size_t)idx_base * sizeof(CoulRow);
 }
@@ -556,7 +558,7 @@ __device__ __forceinline__ void pair_sweep_item(
 }
 
 template <int NS, bool ORDERED, bool TRI, bool FUSED = false, bool FASTW = false>
-__global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MGPU_PAIR_MINWAVES) void pair_sweep_kernel(
+__global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_sweep_kernel(
     Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
     const char *__restrict__ coul_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
@@ -834,7 +836,7 @@ __device__ __forceinline__ void pair_flat_item(
 }
 
 template <int NS, bool FUSED, bool FASTW>
-__global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MGPU_PAIR_MINWAVES) void pair_flat_kernel(
+__global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_flat_kernel(
     Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
     const char *__restrict__ coul_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,
@@ -880,7 +882,7 @@ __global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MG
 // workgroup order -- one extra record per entry for the host's ordered sum.  Items: PairItem of ONE residue type (the engine checks), unordered, orthorhombic.
 // ------------------------------------------------------------------------------------------
 template <int NS, bool FUSED, bool FASTW>
-__global__ __launch_bounds__(kPairBlock, (FUSED && NS > kMaxFusedSites) ? 2 : MGPU_PAIR_MINWAVES) void pair_frozen_kernel(
+__global__ __launch_bounds__(kPairBlock, MGPU_PAIR_MINWAVES) void pair_frozen_kernel(
     Topo tp, BoxDev bx, const double *__restrict__ pos, const int *__restrict__ nmol,
     const double *__restrict__ res_q, const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab,
     const char *__restrict__ coul_tab_g, const PairItem *__restrict__ items, const double *__restrict__ cand_sites,

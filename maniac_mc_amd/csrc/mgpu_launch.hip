@@ -25,13 +25,13 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
                 bool skip_frozen) {
     const int n_work = n_items * nsplit;
     int rc = MGPU_OK;
-    if (fused && (!host_partials || ordered || e->bx.triclinic || common_n1 < 1 || common_n1 > e->pair_fuse_max))
+    if (fused && (!host_partials || ordered || e->bx.triclinic || common_n1 < 1 || common_n1 > kMaxFusedSites))
         return set_error(MGPU_ERR_STATE, "launch_pair: fused sweep needs register sites, an orthorhombic box and a partials buffer");
     if (!host_partials && (rc = ln.d_partials.reserve((size_t)n_work * sizeof(double2)))) return rc;
     double2 *d_part = host_partials ? host_partials : (double2 *)ln.d_partials.p;
     // persistent waves: 2 workgroups of 8 waves per CU (VGPRs: 4 waves per SIMD at <= 128), never more
     // workgroups than there is work for
-    const int per_cu = (fused && common_n1 > kMaxFusedSites) ? 1 : e->pair_blocks_per_cu;
+    const int per_cu = e->pair_blocks_per_cu;
     const int grid = std::max(1, std::min((n_work + kPairWaves - 1) / kPairWaves, e->n_cu * per_cu));
     hipEvent_t a = nullptr, b = nullptr;
     rc = prof_begin(e, ln, MGPU_KERNEL_PAIR, &a, &b);
@@ -67,9 +67,7 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
         switch (common_n1) {
             case 1: MGPU_LAUNCH_FLAT(1, true); break;
             case 2: MGPU_LAUNCH_FLAT(2, true); break;
-            case 3: MGPU_LAUNCH_FLAT(3, true); break;
-            case 4: MGPU_LAUNCH_FLAT(4, true); break;
-            default: MGPU_LAUNCH_FLAT(5, true); break;
+            default: MGPU_LAUNCH_FLAT(3, true); break;      // (fused items have at most kMaxFusedSites sites: checked above)
         }
     } else if (flat) {
         switch (common_n1) {
@@ -83,9 +81,7 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
         switch (common_n1) {
             case 1: MGPU_PAIR_FF(1, true); break;
             case 2: MGPU_PAIR_FF(2, true); break;
-            case 3: MGPU_PAIR_FF(3, true); break;
-            case 4: MGPU_PAIR_FF(4, true); break;   // wide instantiations: 2 waves per SIMD, one workgroup per CU
-            default: MGPU_PAIR_FF(5, true); break;
+            default: MGPU_PAIR_FF(3, true); break;
         }
     } else if (e->bx.triclinic) {
         if (ordered) MGPU_LAUNCH_PAIR(0, true, true);
@@ -125,7 +121,6 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
 // 1531 evaluations 52.2 / 42.4 / 42.3 / 46.2 / 47.6, 3066: 66.6 / 60.4 / 62.1 / 68.7 / 72.0, 6156: 106.5 / 105.0 / 110.8 /
 // 111.2 / 97.6 -> 28 atoms (80 chunk slots, 79 used).
 int frozen_chunk_atoms(const mgpu_engine *e, int n_atoms) {
-    if (e->frozen_chunk > 0) return e->frozen_chunk;
     const int n_slots = kPairWaves * std::max(1, (n_atoms + kPairWaves * 30 - 1) / (kPairWaves * 30));
     return std::max(1, std::min(64, (n_atoms + n_slots - 1) / n_slots));
 }
@@ -166,13 +161,21 @@ int launch_frozen(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items
         else if (ff) MGPU_LAUNCH_FROZEN_1(NS, false, true);                                                            \
         else MGPU_LAUNCH_FROZEN_1(NS, false, false);                                                                   \
     } while (0)
+    // (fused items have at most kMaxFusedSites sites: trial_submit_impl sends larger molecules' moves as two single-state items)
+#define MGPU_LAUNCH_FROZEN_SINGLE(NS)                                                                                   \
+    do {                                                                                                               \
+        if (ff) MGPU_LAUNCH_FROZEN_1(NS, false, true);                                                                 \
+        else MGPU_LAUNCH_FROZEN_1(NS, false, false);                                                                   \
+    } while (0)
+    if (fused && n1 > kMaxFusedSites) return set_error(MGPU_ERR_STATE, "launch_frozen: fused items have at most three sites");
     switch (n1) {
         case 1: MGPU_LAUNCH_FROZEN(1); break;
         case 2: MGPU_LAUNCH_FROZEN(2); break;
         case 3: MGPU_LAUNCH_FROZEN(3); break;
-        case 4: MGPU_LAUNCH_FROZEN(4); break;
-        default: MGPU_LAUNCH_FROZEN(5); break;
+        case 4: MGPU_LAUNCH_FROZEN_SINGLE(4); break;
+        default: MGPU_LAUNCH_FROZEN_SINGLE(5); break;
     }
+#undef MGPU_LAUNCH_FROZEN_SINGLE
 #undef MGPU_LAUNCH_FROZEN
 #undef MGPU_LAUNCH_FROZEN_1
     if ((rc = prof_end(e, ln, MGPU_KERNEL_PAIR, a, b))) return rc;

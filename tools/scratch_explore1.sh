@@ -1,6 +1,12 @@
-mkdir -p gpurun_out/r5e
-for bc in 0 1 0 1; do
-echo "== by_chain $bc" >> gpurun_out/r5e/speed2.txt
-MGPU_FARM_BY_CHAIN=$bc timeout -k 10 200 python tools/farm_window_speed.py --replicas 8,64,256,512 --modes w2 --lanes 1,2 --seconds 0.4 >> gpurun_out/r5e/speed2.txt 2>&1
-done
-cat gpurun_out/r5e/speed2.txt
+mkdir -p gpurun_out/r5f
+( time python bench.py --steps 20 --warmup 5 ) > gpurun_out/r5f/bench_default.txt 2> gpurun_out/r5f/bench_default.err
+tail -c 1500 gpurun_out/r5f/bench_default.err
+python - <<'PY'
+import json
+d=json.loads([l for l in open('gpurun_out/r5f/bench_default.txt') if l.startswith('{')][-1])
+print('value', d['value'], 'ms/step', d['ms_per_step'])
+for r in d.get('replicas_sweep', []): print(r)
+print(d.get('single_chain'))
+print({k:(v.get('value') if isinstance(v,dict) else v) for k,v in d.get('configs',{}).items()})
+print(d.get('exchange'))
+PY
