@@ -1,12 +1,2 @@
-mkdir -p gpurun_out/r5f
-( time python bench.py --steps 20 --warmup 5 ) > gpurun_out/r5f/bench_default.txt 2> gpurun_out/r5f/bench_default.err
-tail -c 1500 gpurun_out/r5f/bench_default.err
-python - <<'PY'
-import json
-d=json.loads([l for l in open('gpurun_out/r5f/bench_default.txt') if l.startswith('{')][-1])
-print('value', d['value'], 'ms/step', d['ms_per_step'])
-for r in d.get('replicas_sweep', []): print(r)
-print(d.get('single_chain'))
-print({k:(v.get('value') if isinstance(v,dict) else v) for k,v in d.get('configs',{}).items()})
-print(d.get('exchange'))
-PY
+mkdir -p gpurun_out/r5g
+timeout -k 10 600 python -m pytest tests/test_gpu_windows_oracle.py tests/test_gpu_farm_window.py tests/test_gpu_chain.py tests/test_gpu_parity.py tests/test_bench_cli.py -q -m gpu -x > gpurun_out/r5g/tests.log 2>&1; tail -15 gpurun_out/r5g/tests.log
