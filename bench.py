@@ -403,7 +403,7 @@ def config_legs(args, device):
     process has closed its farm; a child is an ordinary `bench.py --workload ...` run and prints its own JSON line)."""
     import subprocess
     out = {}
-    for wl in ("co2_gcmc", "framework_water", "co2_isotherm"):
+    for wl in ("co2_gcmc", "framework_water", "co2_isotherm", "spce_triclinic", "adsorbate24"):
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", str(args.config_steps), "--warmup", "20",
                "--sustained-steps", "0", "--configs", "0", "--replicas-sweep", "", "--cpu-budget", "1.0", "--cpu-all-cores-budget", "0",
                "--device", str(device)]
@@ -470,7 +470,14 @@ WORKLOADS = {
     "co2_gcmc": dict(replicas=16384, lanes=4, drivers=3, threads=6, device_build=1, device_accept=0, config="configs[2]: GCMC of CO2 in a 50 A box, insertion / deletion at one fugacity"),
     "framework_water": dict(replicas=8192, lanes=4, drivers=3, threads=6, device_build=1, device_accept=0, config="configs[3] stand-in: 2208-atom framework + 4-site water, full move set"),
     "co2_isotherm": dict(replicas=16384, lanes=4, drivers=3, threads=6, device_build=1, device_accept=0, config="configs[4]: 8 fugacity points dealt over the ranks"),
+    # the two regimes the parity tests exercise that had never been timed (round 5): a TRICLINIC box -- the metric's
+    # 10 125-atom SPC/E box with the tilt of the spce_triclinic_nvt fixture; ComputeDistance's 27-image search,
+    # src/geometry_utils.f90:397-411 -- and a molecule beyond the register-site sweeps and the row-form k sweep (a 24-site
+    # rigid adsorbate: LDS-staged NS = 0 sweep, per-k reciprocal kernel)
+    "spce_triclinic": dict(replicas=4096, lanes=4, drivers=1, threads=4, device_build=0, device_accept=0, config="the metric's SPC/E box, triclinic (tilt 3.0 / -2.0 / 1.5 A): parity-tested regime, timed"),
+    "adsorbate24": dict(replicas=4096, lanes=4, drivers=1, threads=4, device_build=0, device_accept=0, config="64 rigid 24-site adsorbates (1536 atoms) in a 60 A box: parity-tested regime, timed"),
 }
+NVT_WORKLOADS = ("spce", "spce_triclinic", "adsorbate24")
 
 
 def main():
@@ -612,7 +619,7 @@ def main():
         from maniac_mc_amd.fortran_host import FortranFarm as Farm
     else:
         from maniac_mc_amd.farm import ReplicaFarm as Farm
-    if wl != "spce" and args.host != "fortran":
+    if wl not in NVT_WORKLOADS and args.host != "fortran":
         sys.exit("bench.py: the grand-canonical workloads run on the Fortran farm")
     if args.device_build is None:
         args.device_build = WORKLOADS[wl].get("device_build", 0)
@@ -624,8 +631,20 @@ def main():
     R = args.replicas
     iso_pts, fug_grid, point_of_chain = None, None, None
     t_act, p_move, fug_one = 0, 1.0, None        # active residue type, share of translation + rotation, the fugacity
-    if wl == "spce":
-        system = synth.spce_box(args.n_side)
+    if wl in NVT_WORKLOADS:
+        if wl == "spce":
+            system = synth.spce_box(args.n_side)
+        elif wl == "spce_triclinic":
+            system = synth.spce_box(args.n_side)
+            L = float(system.box_matrix[0, 0])
+            # rows a = (lx, 0, 0), b = (xy, ly, 0), c = (xz, yz, lz), as the reference's reader stores them (readers_utils.f90:242-245)
+            system.box_matrix = np.array([[L, 0.0, 0.0], [3.0, L, 0.0], [-2.0, 1.5, L]])
+            # the molecules' centres sheared with the cell (fractional coordinates kept; the distance routine's cell vectors
+            # are the matrix's columns, geometry_utils.f90:126-129), so that the periodic images still fit each other
+            frac = (system.com[0] - system.bounds_lo[None, :]) / L
+            system.com[0] = system.bounds_lo[None, :] + frac @ system.box_matrix.T
+        else:
+            system = synth.rigid_adsorbate_box(n_mol=64, L=60.0, seed=17)
         t_step, r_step = 0.3, 0.3
         moves = "50% translation / 50% rotation, 0.3 A / 0.3 rad, 300 K"
         farm = Farm(system, R, device=device, seed=1000 + rank,
@@ -735,7 +754,7 @@ def main():
     trials_now = float(farm.trials - trials0) if hasattr(farm, "trials") else float(args.steps * R)
     evals_now = evals_done() - evals0
     counts = None
-    if wl == "spce":
+    if wl in NVT_WORKLOADS:
         hist = exchange.molecule_count_histogram(np.full(R, int(system.n_mol[0]), dtype=np.int64), nbins)   # (an array: a 16 384-element Python list cost 0.8 ms of the timed region)
     else:
         counts = farm.counts()[:, 0]
@@ -781,7 +800,7 @@ def main():
     iso_us = None
     if not args.kernel_timing:
         eng.profile_enable(True)           # the isolated legs below are timed either way
-    if rank == 0 and args.host == "fortran" and wl == "spce":
+    if rank == 0 and args.host == "fortran" and wl in NVT_WORKLOADS:
         rng = np.random.default_rng(5)
         n_l = max(1, R // farm.n_lanes)
         m_iso = rng.integers(0, int(system.n_mol[0]), n_l).astype(np.int32)
@@ -792,7 +811,7 @@ def main():
         n_iso, ms_iso = eng.profile_get(_lib.KERNEL_PAIR)
         iso_us = ms_iso / max(1, n_iso) * 1e3
     iso_gc = None
-    if rank == 0 and wl != "spce" and args.device_build:
+    if rank == 0 and wl not in NVT_WORKLOADS and args.device_build:
         # grand-canonical workloads: one lane's batch of device-built trials (the farm's move mix on the chains' current
         # states) launched alone, evaluation only
         rng = np.random.default_rng(5)
@@ -830,7 +849,7 @@ def main():
             k["share_of_kernel_time"] = k["total_ms"] / ms_all if ms_all else None
         k_launches = max(1, n_rec)
         evals_per_k_launch = evals_rank / k_launches             # one k sweep per lane step covers every candidate of it
-        pair_dominant = wl in ("spce", "framework_water")
+        pair_dominant = wl in NVT_WORKLOADS or wl == "framework_water"
         if pair_dominant:
             # Pair sweep: bound by fp64 vector issue, not by HBM (measured HBM-side traffic is a fraction of the
             # algorithmic bytes).  achieved = ALGORITHMIC flops (64 per site-atom pair term) over time.
@@ -842,7 +861,9 @@ def main():
                                                    "traffic is a fraction of the algorithmic bytes and there is no MFMA-shaped work; SURVEY 8(d))",
                     "kernel": "pair_frozen_kernel<4,...> (framework box: 64 candidates in the lanes of a wave against chunks of 32 framework atoms "
                               "held as scalars, then each lane's own adsorbates; a group's last workgroup adds the chunk partials in order)" if wl == "framework_water"
-                              else "pair_sweep_kernel<3,false,false,true,true> (old + new state of a trial move in one sweep, two-instruction fold)",
+                              else {"spce": "pair_sweep_kernel<3,false,false,true,true> (old + new state of a trial move in one sweep, two-instruction fold)",
+                                    "spce_triclinic": "the triclinic pair sweep of this build (see DESIGN 4.1: image search of ComputeDistance, geometry_utils.f90:397-411)",
+                                    "adsorbate24": "pair_sweep_kernel<0,false,false> (24 sites staged through LDS in chunks: the generic site count)"}[wl],
                     "achieved": job_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": job_tflops / FP64_VECTOR_PEAK_TFLOPS,
                     "achieved_basis": f"ALGORITHMIC flops: {FLOP_PER_PAIR:g} per site-atom pair term x {n1} sites x (N - {n1}) atoms = "
@@ -937,7 +958,9 @@ def main():
             "config": {"workload": {"spce": f"spce_{system.n_mol[0]}mol_{N0}atoms_lj_cut_coul_long_ewald_Nk{Nk}",
                                     "co2_gcmc": f"co2_gcmc_50A_box_Nk{Nk}_fV{fug_one * volume:g}" if fug_one else None,
                                     "framework_water": f"framework2208_water4site_gcmc_Nk{Nk}_fV{fug_one * volume:g}" if fug_one else None,
-                                    "co2_isotherm": f"co2_isotherm_{ISOTHERM_POINTS}fugacities_50A_box_Nk{Nk}"}[wl],
+                                    "co2_isotherm": f"co2_isotherm_{ISOTHERM_POINTS}fugacities_50A_box_Nk{Nk}",
+                                    "spce_triclinic": f"spce_{system.n_mol[0]}mol_{N0}atoms_triclinic_tilt_3.0_-2.0_1.5_Nk{Nk}",
+                                    "adsorbate24": f"rigid_adsorbate_24site_{system.n_mol[0]}mol_{N0}atoms_60A_box_Nk{Nk}"}[wl],
                        "baseline_config": WORKLOADS[wl]["config"],
                        "replicas_per_gpu": R, "host_driver": args.host, "host_threads": args.host_threads if args.host == "fortran" else 1,
                        "lanes": n_lanes, "host_drivers": args.drivers, "trial_geometry": "device-built" if args.device_build else "host-built",
@@ -1000,7 +1023,7 @@ def main():
             except Exception as exc:
                 out["configs"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:
-            if wl == "spce":
+            if wl in NVT_WORKLOADS:
                 out["cpu_baseline"] = cpu_baseline(system, t_step, r_step, budget_s=args.cpu_budget,
                                                     all_cores_budget_s=args.cpu_all_cores_budget)
             else:

@@ -423,6 +423,9 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
     std::memcpy(bx.rcp, e->reciprocal, sizeof(double) * 9);
     std::memcpy(bx.m, box_matrix, sizeof(double) * 9);
     bx.triclinic = e->box_type == 3 ? 1 : 0;
+    // lower-triangular box%matrix (the reader's triclinic cells): the exact eight-evaluation image search applies
+    bx.tri_lower = (bx.triclinic && box_matrix[1] == 0.0 && box_matrix[2] == 0.0 && box_matrix[5] == 0.0 &&
+                    box_matrix[0] > 0.0 && box_matrix[4] > 0.0 && box_matrix[8] > 0.0 && std::getenv("MGPU_TRI_FULL_SEARCH") == nullptr) ? 1 : 0;
     bx.rc2 = e->rc * e->rc;
     bx.alpha = e->alpha;
     bx.volume = e->volume;

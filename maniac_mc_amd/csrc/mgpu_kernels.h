@@ -88,6 +88,9 @@ struct BoxDev {
     double rcp[9];                // box%reciprocal, row-major
     double m[9];                  // box%matrix, row-major (cell vectors are its columns)
     int triclinic;                // box%type == 3: 27-image search instead of the per-axis fold
+    int tri_lower;                // ... and box%matrix is lower triangular (m[1] = m[2] = m[5] = 0: every triclinic box the
+                                  // reference's reader builds, readers_utils.f90:242-245): the search is done exactly in 4 + 4
+                                  // evaluations instead of 27 (image_r2_tri_lower)
     double rc2;                   // real_space_cutoff^2
     double alpha;
     int coul_idx_base;            // Coulomb table: row = (hi32(r^2) >> 14) - coul_idx_base
@@ -146,8 +149,72 @@ __device__ __forceinline__ double min_image(double d, double L, double invL) {
 // Squared minimum-image distance for a raw separation (dx, dy, dz): ComputeDistance
 // (geometry_utils.f90:359-415).  Cubic / orthorhombic: per-axis fold.  Triclinic: the minimum over
 // the 27 neighbouring images delta + sx a + sy b + sz c, exactly the reference's search.
+// The 27-image search of ComputeDistance (geometry_utils.f90:397-411) for a LOWER-TRIANGULAR box%matrix -- rows
+// (lx, 0, 0), (xy, ly, 0), (xz, yz, lz): what the reference's reader stores for every triclinic cell -- where the image
+// (sx, sy, sz) of a raw separation is
+//     tx = dx + sx lx,   ty = (dy + sx xy) + sy ly,   tz = ((dz + sx xz) + sy yz) + sz lz
+// (the reference's sums, term by term: the products with 0 and +-1 are exact).  The minimum of r2 = tz^2 + (ty^2 + tx^2)
+// over the 27 is found EXACTLY in eight evaluations:
+//   * sz: for fixed (sx, sy) r2 grows with |tz| (fma is monotone), so the best sz is the one of zb - lz, zb, zb + lz of
+//     smallest magnitude: a fold, no evaluation;
+//   * sy: zb is never the worst of the three, so the two best are sy = 0 and the nearer of sy = -1 / +1; the remaining
+//     one cannot give less than tx^2 + ty_far^2;
+//   * sx: likewise sx = 0 and the nearer of -1 / +1; the remaining one cannot give less than tx_far^2.
+// If the best of the eight does not exceed the smallest of those lower bounds it IS the minimum over the 27 (the same
+// double: the same expressions, and a minimum does not care how many larger values it is taken over); otherwise --
+// cells much longer than wide, where a minimum-image distance can exceed a cell width -- the full search runs.
+__device__ __forceinline__ bool image_r2_tri_lower(double dx, double dy, double dz, const BoxDev &bx, double &out) {
+    const double lx = bx.m[0], xy = bx.m[3], ly = bx.m[4], xz = bx.m[6], yz = bx.m[7], lz = bx.m[8];
+    double best = 1.7976931348623157e308;
+    const double xm = dx - lx, xp = dx + lx;
+    const bool xneg = fabs(xm) <= fabs(xp);
+    const double x_out = xneg ? xm : xp, x_far = xneg ? xp : xm;
+    double bound = x_far * x_far;
+    auto with_sx = [&](double tx, double yb, double zb1) {
+        const double x2 = tx * tx;
+        const double ym = yb - ly, yp = yb + ly;
+        const bool yneg = fabs(ym) <= fabs(yp);
+        const double y_out = yneg ? ym : yp, y_far = yneg ? yp : ym;
+        bound = fmin(bound, fma(y_far, y_far, x2));
+        auto with_sy = [&](double ty, double zb) {
+            const double zm = zb - lz, zp = zb + lz;
+            const double z_out = fabs(zm) <= fabs(zp) ? zm : zp;
+            const double tz = fabs(z_out) < fabs(zb) ? z_out : zb;
+            best = fmin(best, fma(tz, tz, fma(ty, ty, x2)));
+        };
+        with_sy(yb, zb1);                                             // sy = 0: + 0 * yz is exact
+        with_sy(y_out, yneg ? zb1 - yz : zb1 + yz);                   // sy = -1 / +1
+    };
+    with_sx(dx, dy, dz);                                              // sx = 0
+    with_sx(x_out, xneg ? dy - xy : dy + xy, xneg ? dz - xz : dz + xz);
+    out = best;
+    return best <= bound;
+}
+
+// the full search
+__device__ __forceinline__ double image_r2_search27(double dx, double dy, double dz, const double *__restrict__ m) {
+    double best = 1.7976931348623157e308;     // huge(1.0_real64), geometry_utils.f90:399
+    for (int sx = -1; sx <= 1; ++sx)
+        for (int sy = -1; sy <= 1; ++sy)
+            for (int sz = -1; sz <= 1; ++sz) {
+                const double tx = dx + sx * m[0] + sy * m[1] + sz * m[2];
+                const double ty = dy + sx * m[3] + sy * m[4] + sz * m[5];
+                const double tz = dz + sx * m[6] + sy * m[7] + sz * m[8];
+                const double t2 = fma(tz, tz, fma(ty, ty, tx * tx));
+                best = t2 < best ? t2 : best;
+            }
+    return best;
+}
+
 template <bool TRI>
 __device__ __forceinline__ double image_r2(double dx, double dy, double dz, const BoxDev &bx) {
+    if constexpr (TRI) {
+        if (bx.tri_lower) {                                           // uniform
+            double r2;
+            if (!image_r2_tri_lower(dx, dy, dz, bx, r2)) r2 = image_r2_search27(dx, dy, dz, bx.m);
+            return r2;
+        }
+    }
     if constexpr (!TRI) {
         dx = min_image(dx, bx.L[0], bx.invL[0]);
         dy = min_image(dy, bx.L[1], bx.invL[1]);
@@ -425,10 +492,26 @@ __device__ __forceinline__ void pair_sweep_item(
                             const double rc2l = valid ? bx.rc2 : -1.0;
                             double r2[NREG], g[NREG];
                             unsigned sh_min = ~0u;
+                            if constexpr (TRI) {
+                                // the exact eight-evaluation search where the cell allows it (image_r2_tri_lower); a lane whose
+                                // certificate fails sends the WHOLE unit to the full search (a scalar branch, rarely taken: the
+                                // hot path keeps its registers)
+                                bool ok = bx.tri_lower != 0;
+                                if (ok) {
 #pragma unroll
-                            for (int s = 0; s < NREG; ++s) {
-                                r2[s] = FASTW ? image_r2_fast(xj - rx[s], yj - ry[s], zj - rz[s], bx)
-                                              : image_r2<TRI>(xj - rx[s], yj - ry[s], zj - rz[s], bx);
+                                    for (int s = 0; s < NREG; ++s) ok = image_r2_tri_lower(xj - rx[s], yj - ry[s], zj - rz[s], bx, r2[s]) && ok;
+                                }
+                                if (!__all(ok)) {
+                                    asm volatile("" ::: "memory");
+#pragma unroll
+                                    for (int s = 0; s < NREG; ++s) r2[s] = image_r2_search27(xj - rx[s], yj - ry[s], zj - rz[s], bx.m);
+                                }
+                            } else {
+#pragma unroll
+                                for (int s = 0; s < NREG; ++s) {
+                                    r2[s] = FASTW ? image_r2_fast(xj - rx[s], yj - ry[s], zj - rz[s], bx)
+                                                  : image_r2<false>(xj - rx[s], yj - ry[s], zj - rz[s], bx);
+                                }
                             }
 #pragma unroll
                             for (int s = 0; s < NREG; ++s) {

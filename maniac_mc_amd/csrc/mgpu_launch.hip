@@ -84,8 +84,17 @@ int launch_pair(mgpu_engine *e, Lane &ln, const PairItem *d_items, int n_items, 
             default: MGPU_PAIR_FF(3, true); break;
         }
     } else if (e->bx.triclinic) {
+        // triclinic boxes, round 5: the register-site sweeps with ComputeDistance's image search (image_r2_tri_lower / the full
+        // 27); a move is two single-state items (trial_submit_impl)
         if (ordered) MGPU_LAUNCH_PAIR(0, true, true);
-        else MGPU_LAUNCH_PAIR(0, false, true);
+        else switch (common_n1) {
+            case 1: MGPU_LAUNCH_PAIR(1, false, true); break;
+            case 2: MGPU_LAUNCH_PAIR(2, false, true); break;
+            case 3: MGPU_LAUNCH_PAIR(3, false, true); break;
+            case 4: MGPU_LAUNCH_PAIR(4, false, true); break;
+            case 5: MGPU_LAUNCH_PAIR(5, false, true); break;
+            default: MGPU_LAUNCH_PAIR(0, false, true); break;
+        }
     } else if (ordered) {
         MGPU_LAUNCH_PAIR(0, true, false);
     } else {
