@@ -991,3 +991,43 @@ def test_a_committed_framework_move_switches_the_batch_kernel_off():
         close(after[0][1][untouched], before[0][1][untouched], "replica 2 does not feel another replica's framework")
     for e in engines:
         e.close()
+
+
+@pytest.mark.parametrize("box,tilt", [((18.0, 21.0, 24.0), (1.5, -0.8, 0.6)), ((18.0, 21.0, 24.0), (8.9, -11.9, 10.4)),
+                                      ((11.0, 13.0, 44.0), (2.5, -3.0, 4.0))])
+def test_triclinic_image_search_is_the_27_image_minimum(box, tilt):
+    """ComputeDistance searches 27 images of a triclinic cell (src/geometry_utils.f90:397-411).  For the reader's
+    lower-triangular box%matrix the engine finds the same minimum in eight evaluations plus a certificate, and runs the
+    full search where the certificate fails (image_r2_tri_lower): two engines on the same configuration, one created
+    with MGPU_TRI_FULL_SEARCH=1, must agree BIT FOR BIT -- static energies, trial moves of every molecule, insertions --
+    for a mild tilt, the largest tilt LAMMPS allows, and a cell four times longer than wide (where minimum-image distances
+    exceed the cell's width and the certificate does fail)."""
+    import os
+    s = synth.mixture_box(box=box, seed=5, tilt=tilt, n_a=10, n_b=8)
+    engines = []
+    for full in (False, True):
+        if full:
+            os.environ["MGPU_TRI_FULL_SEARCH"] = "1"
+        try:
+            e = Engine.from_system(s, n_replicas=1, mol_capacity=[14, 12])
+        finally:
+            os.environ.pop("MGPU_TRI_FULL_SEARCH", None)
+        e.init_structure_factor(0, True)
+        engines.append(e)
+    a, b = engines
+    ea, eb = a.system_energy(0), b.system_energy(0)
+    assert all(ea[k] == eb[k] for k in E_KEYS), (ea, eb)
+    rng = np.random.default_rng(4)
+    for t in (0, 1):
+        n = int(s.n_mol[t])
+        # candidates anywhere, also well outside the cell (raw separations beyond one cell vector)
+        sites = s.all_sites(t) + rng.uniform(-6.0, 6.0, (n, 1, 3))
+        rep = np.zeros(n, np.int32)
+        tt = np.full(n, t, np.int32)
+        ra = a.gcmc_trial(rep, tt, np.arange(n, dtype=np.int32), np.full(n, MGPU_MOVE, np.int32), sites)
+        rb = b.gcmc_trial(rep, tt, np.arange(n, dtype=np.int32), np.full(n, MGPU_MOVE, np.int32), sites)
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]), (t, np.max(np.abs(ra[1] - rb[1])))
+        ca = a.gcmc_trial(rep[:3], tt[:3], [-1] * 3, [MGPU_CREATION] * 3, sites[:3])
+        cb = b.gcmc_trial(rep[:3], tt[:3], [-1] * 3, [MGPU_CREATION] * 3, sites[:3])
+        assert np.array_equal(ca[1], cb[1])
+    a.close(); b.close()
