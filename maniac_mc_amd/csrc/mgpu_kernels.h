@@ -1608,16 +1608,17 @@ __device__ __forceinline__ RecipLds recip_lds_view(const Topo &tp, const BoxDev 
     return v;
 }
 
-// phases 1 and 2 (two workgroup barriers inside).  cand_row = the item's candidate row (new sites), unused without one.
+// phases 1 and 2 in pieces WITHOUT barriers (recip_rows_tables puts them together; recip_rows2_kernel runs two items through
+// each phase between one pair of barriers).  cand_row = the item's candidate row (new sites), unused without one.
 // `after_loads()` runs once per active thread after the loads phases 1 and 2 wait for (the thread's first table entry's
 // coordinates, the charge, its first row) have been requested and before the first wait: the place where the kernels
 // request their first chunks of A(k) (recip_rows_prefetch), so that the wait for the small loads leaves the large ones
 // in flight (the memory counter retires in order) and phases 1 and 2 run under them.
 template <class Hook>
-__device__ __forceinline__ void recip_rows_tables(const Topo &tp, const BoxDev &bx, const double *__restrict__ pos,
-                                                  const double *__restrict__ res_q, const RecipRow *__restrict__ rows, int n_rows,
-                                                  const RecipItem &it, const double *__restrict__ cand_row, const RecipLds &v,
-                                                  int tid, bool active, Hook &&after_loads) {
+__device__ __forceinline__ RecipRow recip_rows_phase1(const Topo &tp, const BoxDev &bx, const double *__restrict__ pos,
+                                                      const double *__restrict__ res_q, const RecipRow *__restrict__ rows, int n_rows,
+                                                      const RecipItem &it, const double *__restrict__ cand_row, const RecipLds &v,
+                                                      int tid, bool active, Hook &&after_loads) {
     const double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
     const double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
     const int n1 = v.n1, nss = v.nss, ktot = v.ktot;
@@ -1661,10 +1662,15 @@ __device__ __forceinline__ void recip_rows_tables(const Topo &tp, const BoxDev &
         if (tid < n1) v.q[tid] = q;
         for (int a = tid + kBlock; a < n1; a += kBlock) v.q[a] = res_q[it.t * tp.max_atom + a];
     }
-    __syncthreads();
-    // phase 2: XY[row][s] = (+q for the new sites, -q for the old ones) * X[kx] * Y[ky]   (ewald_energy.f90:241-256)
-    // (one thread per row, the site-states in its inner loop: the row's indices are read once -- straight from the
-    //  launch's row list -- and nothing is divided)
+    return r_first;
+}
+// phase 2: XY[row][s] = (+q for the new sites, -q for the old ones) * X[kx] * Y[ky]   (ewald_energy.f90:241-256)
+// (one thread per row, the site-states in its inner loop: the row's indices are read once -- straight from the
+//  launch's row list -- and nothing is divided); r_first = the thread's first row as phase 1 loaded it
+__device__ __forceinline__ void recip_rows_phase2(const RecipRow *__restrict__ rows, int n_rows, const RecipLds &v, int tid, bool active,
+                                                  const RecipRow r_first) {
+    const int n1 = v.n1, nss = v.nss, ktot = v.ktot;
+    const bool used = v.use_new || v.use_old;
     if (active) {
         for (int row = tid; row < n_rows; row += kBlock) {
             const RecipRow r = row == tid ? r_first : rows[row];
@@ -1685,6 +1691,16 @@ __device__ __forceinline__ void recip_rows_tables(const Topo &tp, const BoxDev &
             }
         }
     }
+}
+// phases 1 and 2 of ONE item (two workgroup barriers inside)
+template <class Hook>
+__device__ __forceinline__ void recip_rows_tables(const Topo &tp, const BoxDev &bx, const double *__restrict__ pos,
+                                                  const double *__restrict__ res_q, const RecipRow *__restrict__ rows, int n_rows,
+                                                  const RecipItem &it, const double *__restrict__ cand_row, const RecipLds &v,
+                                                  int tid, bool active, Hook &&after_loads) {
+    const RecipRow r_first = recip_rows_phase1(tp, bx, pos, res_q, rows, n_rows, it, cand_row, v, tid, active, after_loads);
+    __syncthreads();
+    recip_rows_phase2(rows, n_rows, v, tid, active, r_first);
     __syncthreads();
 }
 
@@ -1926,6 +1942,10 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
     }
     if (COMMIT || DECIDE) recip_commit_tail(tp, pos, nmol, it, cand_row, tid);
 }
+
+// (Two items per workgroup for short k lists -- each phase's barriers shared, half the workgroups: built and measured in
+//  round 5 at the framework box, Nk = 1152: 18.5 -> 19.2 us per 2048 candidates, 28.5 -> 33.3 per 4096; its 117 registers
+//  leave four workgroups per CU and a workgroup's life simply doubles.  Not kept; LABNOTES.md.)
 
 // ------------------------------------------------------------------------------------------
 // Trial geometry built on the device (the farm's moves: Translation / Rotation / CreateMolecule of the reference,
