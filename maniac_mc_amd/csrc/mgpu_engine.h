@@ -250,6 +250,7 @@ struct mgpu_engine {
         bool topo_stale = true;
         ChainResult *d_res = nullptr;
         double2 *d_part = nullptr;
+        double2 *d_alt = nullptr;                    // [kChainMaxCand][n_slots]: A + delta of every candidate of the window
         int *d_ticket = nullptr;
         unsigned long long seq = 0;
         double margin = 16.0 * 2.220446049250313e-16;   // relative band around the acceptance probability left to the host's exp

@@ -603,7 +603,7 @@ int mgpu_engine_destroy(mgpu_engine *e) {
     e->h_stage.release();
     for (void *p : {(void *)e->chain.h_out, (void *)e->chain.h_tag})
         if (p) (void)hipHostFree(p);
-    for (void *p : {(void *)e->chain.d_res, (void *)e->chain.d_part, (void *)e->chain.d_ticket, (void *)e->chain.d_topo,
+    for (void *p : {(void *)e->chain.d_res, (void *)e->chain.d_part, (void *)e->chain.d_ticket, (void *)e->chain.d_topo, (void *)e->chain.d_alt,
                     (void *)e->farm.d_A_alt, (void *)e->farm.d_acur, (void *)e->farm.d_stalled})
         if (p) (void)hipFree(p);
     for (auto &ln : e->lanes) {

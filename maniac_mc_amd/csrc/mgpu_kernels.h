@@ -1751,7 +1751,9 @@ __device__ __forceinline__ void recip_rows_prefetch(RecipInFlight<CH> &f, const 
 // ALT (energy sweeps only): A + delta is ALSO stored, into `A_alt` -- another buffer of the replica's layout -- with the
 // commit's arithmetic, so that a later acceptance only has to make that buffer the replica's current one
 // (farm_window_kernel: its k role cannot know the verdict, and the workgroup that learns it has no phase tables).
-template <bool STORE, bool BOTH, int CH, bool ALT = false>
+// ALT = 2: the same with agent-scope write-through (`sc1`) stores, for a reader in ANOTHER workgroup of the same launch
+// that loads with `sc1` (chain_window_kernel's resolving workgroup copies the accepted step's buffer into A).
+template <bool STORE, bool BOTH, int CH, int ALT = 0>
 __device__ __forceinline__ void recip_rows_pass(const RecipLds &v, const int *__restrict__ trj, const double2 *__restrict__ tw, int n_tasks,
                                                 double2 *__restrict__ A, int tid, RecipInFlight<CH> &f, double &acc, double &acc0,
                                                 double2 *__restrict__ A_alt = nullptr) {
@@ -1797,11 +1799,21 @@ __device__ __forceinline__ void recip_rows_pass(const RecipLds &v, const int *__
                 }
             } else {
                 acc += fma(wp, fma(npx, npx, npy * npy), wm * fma(nmx, nmx, nmy * nmy));   // ewald_energy.f90:259-266
-                if constexpr (ALT) {
+                if constexpr (ALT != 0) {
                     const int t = t0 + c * kBlock;
                     if (t < n_tasks) {    // the commit's stores (STORE above), to the other buffer
-                        A_alt[2 * t] = (ch.rj[c] & kTaskHasP) ? make_double2(npx, npy) : make_double2(0.0, 0.0);
-                        A_alt[2 * t + 1] = (ch.rj[c] & kTaskHasM) ? make_double2(nmx, nmy) : make_double2(0.0, 0.0);
+                        const double2 vp = (ch.rj[c] & kTaskHasP) ? make_double2(npx, npy) : make_double2(0.0, 0.0);
+                        const double2 vm = (ch.rj[c] & kTaskHasM) ? make_double2(nmx, nmy) : make_double2(0.0, 0.0);
+                        if constexpr (ALT == 2) {
+                            double *d = reinterpret_cast<double *>(A_alt + 2 * t);
+                            __hip_atomic_store(d + 0, vp.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(d + 1, vp.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(d + 2, vm.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(d + 3, vm.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else {
+                            A_alt[2 * t] = vp;
+                            A_alt[2 * t + 1] = vm;
+                        }
                     }
                 }
             }
@@ -2245,6 +2257,7 @@ struct ChainArgs {
     ChainResult *res;                            // [n] device scratch
     double2 *partials;                           // [n_ent * nsplit] device scratch
     int *ticket;                                 // device counter, 0 between launches
+    double2 *alt;                                // [n][n_slots] device scratch: candidate c's k role leaves A + delta_c here
     double *host_out;                            // pinned host: [n][10] energies | first | undecided (ints) | stage stamps
     unsigned long long *host_tag;                // pinned host: window sequence number, written last
     unsigned long long seq;
@@ -2307,7 +2320,10 @@ __global__ __launch_bounds__(kChainBlock, 1) void chain_window_kernel(
                           [&] { recip_rows_prefetch<false>(inflight, trj, tw, n_tasks, A, tid); });
         mark(my_role, 1);
         double acc = 0.0, acc0 = 0.0;
-        if (active) recip_rows_pass<false, true>(v, trj, tw, n_tasks, A, tid, inflight, acc, acc0);
+        // (A + delta of this candidate goes to its own buffer with write-through stores: the resolving workgroup commits an
+        //  accepted step by COPYING that buffer -- round 5; until then it rebuilt the phase tables and made a second pass:
+        //  6.4 us of GPU time per window, hidden behind the host's turn-round for one chain, not for several sharing a GPU)
+        if (active) recip_rows_pass<false, true, kRecipTaskChunk, 2>(v, trj, tw, n_tasks, A, tid, inflight, acc, acc0, g.alt + (size_t)c * bx.n_slots);
         if (tid == kBlock && link != -2 && (kind == 1 || kind == 2)) {
             // ComputeIntraResidueRealCoulombEnergySingleMol of the inserted (candidate row) / deleted (resident) molecule
             const PairItem pit{g.replica, it.t, it.m, kind == 1 ? c : -1, 0};
@@ -2453,23 +2469,19 @@ __global__ __launch_bounds__(kChainBlock, 1) void chain_window_kernel(
     __syncthreads();
     const int first = s_flag;
     if (first < 0) return;
-    // ---------------- commit of the accepted step by this workgroup (the stand-alone commit's arithmetic)
+    // ---------------- commit of the accepted step by this workgroup: A <- the buffer the step's k role filled with A + delta
+    // (the stand-alone commit's arithmetic, done once, by the sweep), then coordinates / count.  An as-written deletion
+    // takes the buffer of its companion row: A + the terms of the molecule RemoveMolecule moves into the slot.
     {
         const bool as_written = g.kind[first] == 2 && g.link[first] >= 0;
         const int src = as_written ? g.link[first] : first;
         RecipItem it{g.replica, g.t[first], g.m[first], as_written ? 5 : g.kind[first], src, 0, 0};
         recip_commit_target(tp, nmol, it);
-        const RecipLds v = recip_lds_view(tp, bx, it, n_rows, reinterpret_cast<double2 *>(s_dyn));
-        const bool active = tid < kBlock;
-        RecipInFlight<kRecipCommitChunk> inflight;
-        recip_rows_tables(tp, bx, pos, res_q, rows, n_rows, it, &g.sites[src][0][0], v, tid, active,
-                          [&] { recip_rows_prefetch<true>(inflight, trj, tw, n_tasks, A, tid); });
+        const double *from = reinterpret_cast<const double *>(g.alt + (size_t)src * bx.n_slots);
+        double *to = reinterpret_cast<double *>(A);
+        for (int i = tid; i < 2 * bx.n_slots; i += kChainBlock) to[i] = load_sc1(from + i);
         mark(rs, 5);
-        double acc = 0.0, acc0 = 0.0;
-        if (active) {
-            recip_rows_pass<true, false>(v, trj, tw, n_tasks, A, tid, inflight, acc, acc0);
-            recip_commit_tail(tp, pos, nmol, it, &g.sites[src][0][0], tid);
-        }
+        if (tid < kBlock) recip_commit_tail(tp, pos, nmol, it, &g.sites[src][0][0], tid);
         mark(rs, 6);
     }
 }
@@ -2709,7 +2721,7 @@ __global__ __launch_bounds__(kChainBlock, 1) void farm_window_kernel(
             recip_rows_tables(tp, bx, pos, res_q, rows, n_rows, it, &s_cand[0][0], v, tid, active,
                               [&] { recip_rows_prefetch<false>(inflight, trj, tw, n_tasks, A, tid); });
             double acc = 0.0, acc0 = 0.0;
-            if (active) recip_rows_pass<false, true, kRecipTaskChunk, true>(v, trj, tw, n_tasks, A, tid, inflight, acc, acc0, A_other);
+            if (active) recip_rows_pass<false, true, kRecipTaskChunk, 1>(v, trj, tw, n_tasks, A, tid, inflight, acc, acc0, A_other);
             if (tid == kBlock && kind != 0) {
                 // ComputeIntraResidueRealCoulombEnergySingleMol of the inserted (candidate row) / deleted (resident) molecule
                 const PairItem pit{rec.replica, rec.t, rec.m, kind == 1 ? 0 : -1, 0};

@@ -128,6 +128,7 @@ int mgpu_chain_window(mgpu_engine *e, int replica, int n, const int *t, const in
         *ch.h_tag = 0;
         HIP_TRY(hipMalloc((void **)&ch.d_res, sizeof(ChainResult) * kChainMaxCand));
         HIP_TRY(hipMalloc((void **)&ch.d_part, sizeof(double2) * 2 * kChainMaxCand * (size_t)e->pair_nsplit));
+        HIP_TRY(hipMalloc((void **)&ch.d_alt, sizeof(double2) * kChainMaxCand * (size_t)e->n_slots));
         HIP_TRY(hipMalloc((void **)&ch.d_ticket, sizeof(int)));
         HIP_TRY(hipMemset(ch.d_ticket, 0, sizeof(int)));
         HIP_TRY(hipDeviceSynchronize());
@@ -182,7 +183,7 @@ int mgpu_chain_window(mgpu_engine *e, int replica, int n, const int *t, const in
     ch.seq += 1;
     for (int tt = 0; tt < e->tp.n_res; ++tt) g.self_of_type[tt] = e->self_of_type[tt];
     g.stamps = ch.timing ? 1 : 0;
-    g.res = ch.d_res; g.partials = ch.d_part; g.ticket = ch.d_ticket;
+    g.res = ch.d_res; g.partials = ch.d_part; g.ticket = ch.d_ticket; g.alt = ch.d_alt;
     g.host_out = ch.h_out; g.host_tag = ch.h_tag; g.seq = ch.seq;
     g.n = n; g.n_ent = n_ent; g.nsplit = nsplit; g.replica = replica;
     g.temperature = temperature; g.e_recip = recip_energy; g.margin = ch.margin;
