@@ -102,10 +102,12 @@ def test_default_line_carries_the_other_configs_the_chain_count_curve_and_both_b
     assert d["value"] > 1e5 and d["config"]["workload"].startswith("spce_3375mol_10125atoms")
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and 0 < d["roofline"]["frac"] < 1
     assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
-    assert set(d["configs"]) == {"co2_gcmc", "framework_water", "co2_isotherm"}
+    assert set(d["configs"]) == {"co2_gcmc", "framework_water", "co2_isotherm", "spce_triclinic", "adsorbate24"}
     for name, leg in d["configs"].items():
         assert "error" not in leg, (name, leg)
         assert leg["value"] > 1e5 and leg["steps"] == 40 and leg["roofline"]["frac"] is not None and leg["roofline"]["basis"]
         assert leg["cpu_baseline"]["value"] > 0
     assert [r["replicas"] for r in d["replicas_sweep"]] == [1, 64] and all(r["value"] > 0 for r in d["replicas_sweep"])
+    assert all(r["path"].startswith("window") for r in d["replicas_sweep"])                 # round 5: one launch per lane step
+    assert d["exchange"]["ranks_seen"] == 1 and d["exchange"]["per_rank_device"] == [0]
     assert d["single_chain"]["value"] > 0 and d["single_chain"]["windows"] > 0
