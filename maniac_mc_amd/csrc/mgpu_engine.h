@@ -193,6 +193,7 @@ struct mgpu_engine {
     std::vector<int> kslot;
     int n_slots = 0;                 // complex entries of A(k) per replica
     RecipRow *d_rrows = nullptr;
+    int *d_row_first = nullptr;      // [n_rrows + 1] first task of every row (a row's tasks are contiguous): recip_rows_wide_kernel
     int n_rtasks = 0, n_rrows = 0;
     double2 *d_pair_tab = nullptr;
     char *d_coul_tab = nullptr;      // Coulomb table rows (build_coulomb_table), staged into LDS by the pair sweep
@@ -304,6 +305,7 @@ size_t recip_lds_bytes(const mgpu_engine *e, int n1_max);
 int recip_tile_sites(const mgpu_engine *e, int n1_max);
 size_t recip_rows_lds_bytes(const mgpu_engine *e, int n1_max);
 bool recip_by_rows(const mgpu_engine *e, int n1_max);
+int recip_wide_rows_per_tile(const mgpu_engine *e, int n1_max);   // 0: the wide row form does not apply
 int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items, int n1_max, int site_stride,
                  bool commit, double2 *A_base, double *d_u, double *d_u_old = nullptr, const AcceptBits *accept = nullptr,
                  const double *sites_override = nullptr, const DecideArgs *decide = nullptr);

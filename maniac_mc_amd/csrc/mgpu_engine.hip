@@ -566,6 +566,10 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
         HIP_TRY_E(hipMemcpy(e->d_trj, trj.data(), trj.size() * sizeof(int), hipMemcpyHostToDevice));
         HIP_TRY_E(hipMemcpy(e->d_tw, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice));
         HIP_TRY_E(hipMemcpy(e->d_rrows, rrows.data(), rrows.size() * sizeof(RecipRow), hipMemcpyHostToDevice));
+        std::vector<int> row_first(rrows.size() + 1, (int)rtasks.size());
+        for (int ti = (int)rtasks.size() - 1; ti >= 0; --ti) row_first[rtasks[ti].row] = ti;
+        HIP_TRY_E(hipMalloc(&e->d_row_first, row_first.size() * sizeof(int)));
+        HIP_TRY_E(hipMemcpy(e->d_row_first, row_first.data(), row_first.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     HIP_TRY_E(hipMemcpy(e->d_kw, kw.data(), e->nk * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY_E(hipMemcpy(e->d_pair_tab, ptab.data(), ptab.size() * sizeof(double2), hipMemcpyHostToDevice));
@@ -598,7 +602,7 @@ int mgpu_engine_destroy(mgpu_engine *e) {
     for (void *p : {(void *)e->d_pos, (void *)e->d_nmol, (void *)e->d_A, (void *)e->d_kpack, (void *)e->d_kw,
                     (void *)e->d_pair_tab, (void *)e->d_coul_tab, (void *)e->d_res_q, (void *)e->d_res_atype, (void *)e->d_atom_res,
                     (void *)e->d_atom_mol, (void *)e->d_atom_q, (void *)e->d_atom_q_on, (void *)e->d_phase_tab, (void *)e->d_S, (void *)e->d_trj,
-                    (void *)e->d_tw, (void *)e->d_kslot, (void *)e->d_rrows, (void *)e->d_atom_ty, (void *)e->d_com, (void *)e->d_off})
+                    (void *)e->d_tw, (void *)e->d_kslot, (void *)e->d_rrows, (void *)e->d_row_first, (void *)e->d_atom_ty, (void *)e->d_com, (void *)e->d_off})
         if (p) (void)hipFree(p);
     e->h_stage.release();
     for (void *p : {(void *)e->chain.h_out, (void *)e->chain.h_tag})

@@ -1955,6 +1955,164 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
     if (COMMIT || DECIDE) recip_commit_tail(tp, pos, nmol, it, cand_row, tid);
 }
 
+// ------------------------------------------------------------------------------------------
+// Row form for molecules of MANY sites ("wide": a few dozen sites -- the 24-site adsorbate of the tests, a typical rigid
+// organic adsorbate), whose XY table [rows][site-states] does not fit LDS at once.  The 1-D phase tables of ALL the item's
+// site-states stay in LDS; the rows pass through the XY table a TILE of rows at a time, and with them the tasks of those
+// rows (a row's tasks are contiguous in the task list: row_first[r] .. row_first[r + 1]).  Per task and site-state this is
+// the row form's arithmetic, expression for expression -- 2 LDS reads and 4 FMAs for TWO k-vectors, against two complex
+// products and three reads for ONE in the per-k form (recip_kernel) that such molecules took before: measured round 5,
+// 1024 items of the 24-site adsorbate at Nk = 8936, 635 us per launch there (profiles/r05/recip_many_sites.txt).
+// Molecules whose phase tables alone exceed the budget (hundreds of sites) keep the per-k form with its site tiles.
+// Dynamic LDS: tab [nss][ktot] | xy [rows_per_tile][nss] | signed charges [nss].
+// ------------------------------------------------------------------------------------------
+template <bool COMMIT, bool BOTH>
+__global__ __launch_bounds__(kBlock, 2) void recip_rows_wide_kernel(
+    Topo tp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
+    const int *__restrict__ trj, const double2 *__restrict__ tw, const RecipRow *__restrict__ rows, const int *__restrict__ row_first,
+    int n_rows, int rows_per_tile, int nss_max, double2 *__restrict__ A_base, const RecipItem *__restrict__ items,
+    const double *__restrict__ cand_sites, int site_stride, double *__restrict__ u_new, double *__restrict__ u_old) {
+    extern __shared__ double2 s_tab[];
+    __shared__ double s_red[2 * kWavesPerBlock];
+    const RecipItem it = items[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int n1 = tp.n1[it.t];
+    const bool use_new = (it.kind == 0 /*MOVE*/ || it.kind == 1 /*CREATION*/ || it.kind == 4 /*FOURIER_ADD*/);
+    const bool use_old = (it.kind == 0 /*MOVE*/ || it.kind == 2 /*DELETION*/);
+    const bool two_sets = use_new && use_old, used = use_new || use_old;
+    const int nss = two_sets ? 2 * n1 : n1;
+    const int kofs1 = bx.kmax[0] + 1, kofs2 = bx.kmax[0] + bx.kmax[1] + 2, ktot = bx.kmax[0] + bx.kmax[1] + bx.kmax[2] + 3;
+    double2 *tab = s_tab, *xyt = s_tab + (size_t)nss_max * ktot;
+    double *sq = reinterpret_cast<double *>(xyt + (size_t)rows_per_tile * nss_max);
+    double *px = pos + (size_t)it.replica * 3 * tp.n_cap_atoms;
+    double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
+    const double *cand_row = cand_sites + (size_t)(it.src < 0 ? 0 : it.src) * site_stride * 3;
+    // ---- phase 1, once: entry (s, axis, k >= 0) at tab[s * ktot + kofs[axis] + k]; s = set * n1 + a with both sets (set 0 =
+    //      the new sites, 1 = the old ones), s = a with one
+    for (int e = tid; e < nss * ktot; e += kBlock) {
+        const int s = e / ktot, kk = e - s * ktot;
+        const int set = two_sets ? (s >= n1 ? 1 : 0) : (use_old ? 1 : 0), a = s - (s >= n1 ? n1 : 0);
+        double x = 0.0, y = 0.0, z = 0.0;
+        if (used) {
+            if (set == 0) { const double *c = cand_row + (size_t)a * 3; x = c[0]; y = c[1]; z = c[2]; }
+            else { const int j = atom_slot(tp, it.t, it.m, a); x = px[j]; y = py[j]; z = pz[j]; }
+        }
+        const int axis = (kk >= kofs2) ? 2 : (kk >= kofs1 ? 1 : 0);
+        const int k0 = axis == 2 ? kofs2 : (axis == 1 ? kofs1 : 0);
+        tab[e] = used ? phase_entry(atom_phase(bx, axis, x, y, z), kk - k0) : make_double2(0.0, 0.0);
+    }
+    for (int s = tid; s < nss; s += kBlock) {
+        const int set = two_sets ? (s >= n1 ? 1 : 0) : (use_old ? 1 : 0), a = s - (s >= n1 ? n1 : 0);
+        const double q = res_q[it.t * tp.max_atom + a];
+        sq[s] = set == 0 ? q : -q;                      // + for the new sites, - for the old ones (ewald_energy.f90:241-256)
+    }
+    __syncthreads();
+    double2 *A = A_base + (size_t)it.replica * bx.n_slots;
+    const double2 *zt = tab + kofs2;
+    double acc = 0.0, acc0 = 0.0;
+    for (int r0 = 0; r0 < n_rows; r0 += rows_per_tile) {
+        const int r1 = min(n_rows, r0 + rows_per_tile);
+        // ---- phase 2 for the rows of this tile: XY[row][s] = +-q X[kx] Y[ky]  (recip_rows_phase2's expression)
+        for (int idx = tid; idx < (r1 - r0) * nss; idx += kBlock) {
+            const int rr = idx / nss, s = idx - rr * nss;
+            const RecipRow r = rows[r0 + rr];
+            const int aky = r.ky < 0 ? -r.ky : r.ky;
+            double2 xy = make_double2(0.0, 0.0);
+            if (used) {
+                double2 Y = tab[s * ktot + kofs1 + aky];
+                if (r.ky < 0) Y.y = -Y.y;
+                xy = cmul(tab[s * ktot + r.kx], Y);
+                const double q = sq[s];
+                xy.x *= q; xy.y *= q;
+            }
+            xyt[rr * nss + s] = xy;
+        }
+        __syncthreads();
+        // ---- phase 3 for the tasks of those rows (recip_rows_pass's arithmetic per task)
+        for (int t = row_first[r0] + tid; t < row_first[r1]; t += kBlock) {
+            const int rj = trj[t];
+            const double2 Ap = A[2 * t], Am = A[2 * t + 1];
+            const double2 w = COMMIT ? make_double2(0.0, 0.0) : tw[t];
+            const double2 *xy = xyt + (((rj >> 8) & 0xfffff) - r0) * nss;
+            const double2 *z = zt + (rj & 0xff);
+            double sac = 0.0, sbd = 0.0, sad = 0.0, sbc = 0.0;
+            auto term = [&](const double2 p, const double2 q) {
+                sac = fma(p.x, q.x, sac);
+                sbd = fma(p.y, q.y, sbd);
+                sad = fma(p.x, q.y, sad);
+                sbc = fma(p.y, q.x, sbc);
+            };
+            int s = 0;
+            for (; s + 2 <= nss; s += 2) {
+                const double2 p0 = xy[s], p1 = xy[s + 1];
+                const double2 q0 = z[s * ktot], q1 = z[(s + 1) * ktot];
+                term(p0, q0); term(p1, q1);
+            }
+            for (; s < nss; ++s) term(xy[s], z[s * ktot]);
+            if (BOTH && !COMMIT) acc0 += fma(w.x, fma(Ap.x, Ap.x, Ap.y * Ap.y), w.y * fma(Am.x, Am.x, Am.y * Am.y));
+            const double npx = Ap.x + (sac - sbd), npy = Ap.y + (sad + sbc);
+            const double nmx = Am.x + (sac + sbd), nmy = Am.y + (sbc - sad);
+            if (COMMIT) {
+                A[2 * t] = (rj & kTaskHasP) ? make_double2(npx, npy) : make_double2(0.0, 0.0);
+                A[2 * t + 1] = (rj & kTaskHasM) ? make_double2(nmx, nmy) : make_double2(0.0, 0.0);
+            } else {
+                acc += fma(w.x, fma(npx, npx, npy * npy), w.y * fma(nmx, nmx, nmy * nmy));   // ewald_energy.f90:259-266
+            }
+        }
+        __syncthreads();                                 // the next tile overwrites XY
+    }
+    if (!COMMIT) {
+        acc = wave_sum(acc);
+        if (BOTH) acc0 = wave_sum(acc0);
+        if ((tid & 63) == 0) { s_red[2 * (tid >> 6)] = acc; s_red[2 * (tid >> 6) + 1] = acc0; }
+        __syncthreads();
+        if (tid == 0) {
+            double u = 0.0, u0 = 0.0;
+            for (int wv = 0; wv < kWavesPerBlock; ++wv) { u += s_red[2 * wv]; u0 += s_red[2 * wv + 1]; }
+            u_new[blockIdx.x] = u * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;   // ewald_energy.f90:272
+            if (BOTH) u_old[blockIdx.x] = u0 * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume;
+        }
+    } else {
+        // (every read of the old coordinates happened in phase 1, before the first barrier; a molecule may have more sites
+        //  than the workgroup has threads)
+        if (it.kind == 0 || it.kind == 1) {
+            for (int a = tid; a < n1; a += kBlock) {
+                const double *c = cand_row + (size_t)a * 3;
+                const int j = atom_slot(tp, it.t, it.m, a);
+                px[j] = c[0]; py[j] = c[1]; pz[j] = c[2];
+            }
+        } else if (it.kind == 2) {
+            const int last = it.aux;                      // swap-with-last, delete_molecule.f90:107-114
+            if (last != it.m)
+                for (int a = tid; a < n1; a += kBlock) {
+                    const int j = atom_slot(tp, it.t, it.m, a), jl = atom_slot(tp, it.t, last, a);
+                    px[j] = px[jl]; py[j] = py[jl]; pz[j] = pz[jl];
+                }
+        }
+        if (tp.com) {
+            const size_t rep3 = (size_t)it.replica * 3;
+            double *fcom = tp.com + rep3 * tp.n_mol_slots + tp.mol_off[it.t];
+            double *foff = tp.off + rep3 * tp.n_cap_atoms;
+            if ((it.kind == 0 || it.kind == 1) && it.frame > 0) {
+                const double *fr = cand_row + (size_t)it.frame * 3;
+                if (tid < 3) fcom[(size_t)tid * tp.n_mol_slots + it.m] = fr[tid];
+                for (int a = tid; a < n1; a += kBlock) {
+                    const int j = atom_slot(tp, it.t, it.m, a);
+                    for (int d = 0; d < 3; ++d) foff[(size_t)d * tp.n_cap_atoms + j] = fr[(1 + a) * 3 + d];
+                }
+            } else if (it.kind == 2 && it.aux != it.m) {
+                const int last = it.aux;
+                if (tid < 3) fcom[(size_t)tid * tp.n_mol_slots + it.m] = fcom[(size_t)tid * tp.n_mol_slots + last];
+                for (int a = tid; a < n1; a += kBlock) {
+                    const int j = atom_slot(tp, it.t, it.m, a), jl = atom_slot(tp, it.t, last, a);
+                    for (int d = 0; d < 3; ++d) foff[(size_t)d * tp.n_cap_atoms + j] = foff[(size_t)d * tp.n_cap_atoms + jl];
+                }
+            }
+        }
+        if (tid == 0 && (it.kind == 1 || it.kind == 2)) nmol[it.replica * tp.n_res + it.t] = it.aux;
+    }
+}
+
 // (Two items per workgroup for short k lists -- each phase's barriers shared, half the workgroups: built and measured in
 //  round 5 at the framework box, Nk = 1152: 18.5 -> 19.2 us per 2048 candidates, 28.5 -> 33.3 per 4096; its 117 registers
 //  leave four workgroups per CU and a workgroup's life simply doubles.  Not kept; LABNOTES.md.)

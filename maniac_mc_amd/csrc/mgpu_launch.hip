@@ -213,6 +213,20 @@ bool recip_by_rows(const mgpu_engine *e, int n1_max) {
     return !e->recip_force_per_k && e->n_rtasks > 0 && recip_rows_lds_bytes(e, n1_max) <= 40 * 1024;
 }
 
+// The wide row form (recip_rows_wide_kernel): the phase tables of every site-state of the largest molecule of the launch
+// in LDS, the XY table a tile of rows at a time.  Rows per tile (0: does not apply -- no row structure, tables beyond
+// kRecipWideTableBytes, fewer than eight rows per tile).
+constexpr size_t kRecipWideTableBytes = 40 * 1024, kRecipWideLdsBytes = 60 * 1024;   // (dynamic LDS: 64 KiB with the static part)
+int recip_wide_rows_per_tile(const mgpu_engine *e, int n1_max) {
+    if (e->recip_force_per_k || e->n_rtasks <= 0 || !e->d_row_first) return 0;
+    const int ktot = e->kmax[0] + e->kmax[1] + e->kmax[2] + 3;
+    const size_t nss = (size_t)2 * n1_max;
+    const size_t tables = nss * ktot * sizeof(double2) + nss * sizeof(double);
+    if (tables > kRecipWideTableBytes) return 0;
+    const int rpt = (int)((kRecipWideLdsBytes - tables) / (nss * sizeof(double2)));
+    return rpt >= 8 ? std::min(rpt, e->n_rrows) : 0;
+}
+
 // accept != nullptr (commit, row form only): d_items are the candidates of the lane's last trial and only
 // those whose bit is set are applied
 int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items, int n1_max, int site_stride,
@@ -249,7 +263,19 @@ int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items
                                   e->tp, e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_kpack, e->d_kslot, e->d_kw, A_base, d_items,  \
                                d_cand, site_stride, tile, d_u, d_u_old);                         \
     } while (0)
-    if (decide)
+    const int wide_rpt = (!by_rows && !accept && !decide) ? recip_wide_rows_per_tile(e, n1_max) : 0;
+    if (wide_rpt > 0) {
+        const int ktot = e->kmax[0] + e->kmax[1] + e->kmax[2] + 3, nss_max = 2 * n1_max;
+        const size_t lds_w = (size_t)nss_max * ktot * sizeof(double2) + (size_t)wide_rpt * nss_max * sizeof(double2) + (size_t)nss_max * sizeof(double);
+#define MGPU_LAUNCH_WIDE(COMMIT, BOTH)                                                                               \
+        hipExtLaunchKernelGGL((recip_rows_wide_kernel<COMMIT, BOTH>), dim3(n_items), dim3(kBlock), lds_w, ln.stream, a, b, 0, e->tp, \
+                              e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_trj, e->d_tw, e->d_rrows, e->d_row_first, e->n_rrows, wide_rpt, \
+                              nss_max, A_base, d_items, d_cand, site_stride, d_u, d_u_old)
+        if (commit) MGPU_LAUNCH_WIDE(true, false);
+        else if (d_u_old) MGPU_LAUNCH_WIDE(false, true);
+        else MGPU_LAUNCH_WIDE(false, false);
+#undef MGPU_LAUNCH_WIDE
+    } else if (decide)
         hipExtLaunchKernelGGL((recip_rows_kernel<false, true, true>), dim3(n_items), dim3(kBlock), lds, ln.stream, a, b, 0, e->tp,
                               e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_trj, e->d_tw, e->n_rtasks, e->d_rrows, e->n_rrows, A_base,
                               d_items, d_cand, site_stride, d_u, d_u_old, bits, 0, *decide);

@@ -380,7 +380,8 @@ def test_per_k_reciprocal_kernel():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MGPU_RECIP_PER_K="1")
     p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-q", "-x", "-m", "gpu", "-k",
-                        "test_engine_vs_golden and (co2_20 or mixture)"], capture_output=True, text=True, env=env,
+                        "(test_engine_vs_golden and (co2_20 or mixture)) or test_wide_row_form_for_a_24_site_adsorbate"],
+                       capture_output=True, text=True, env=env,
                        cwd=root, timeout=900)
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
 
@@ -467,19 +468,21 @@ def test_maximum_molecule_count(refcpu_mod):
     eng.close()
 
 
-def test_per_k_kernel_is_the_only_path_for_a_24_site_adsorbate(refcpu_mod):
-    """A 24-site rigid adsorbate: the row-form k sweep's LDS tables exceed its 40 KiB budget, so the per-k kernel is
-    what runs -- no environment switch.  Trial energies, a committed move (A(k) and coordinates), an insertion
-    and a deletion against the oracle."""
+def test_wide_row_form_for_a_24_site_adsorbate(refcpu_mod):
+    """A 24-site rigid adsorbate: the row-form k sweep's XY table exceeds its 40 KiB budget, so the WIDE row form runs (the
+    phase tables of all 48 site-states in LDS, the rows a tile at a time: recip_rows_wide_kernel; until round 5 such a
+    molecule took the per-k kernel) -- no environment switch.  Trial energies, a committed move (A(k) and coordinates), an
+    insertion and a deletion against the oracle; tests/test_gpu_parity.py::test_per_k_reciprocal_kernel re-runs the file
+    with MGPU_RECIP_PER_K=1, which sends the same molecule through the per-k kernel."""
     s = synth.rigid_adsorbate_box()
     n1 = int(s.topo.atoms_in_res[0])
     eng = Engine.from_system(s, n_replicas=2, mol_capacity=[10])
     kv = eng.kvectors()
     ktot = int(eng.kmax.sum()) + 3
     n_rows = len(set(zip(kv["kx"].tolist(), kv["ky"].tolist())))
-    rows_lds = 2 * n1 * ktot * 16 + n1 * 8 + n_rows * (2 * n1 * 16 + 8)      # recip_rows_lds_bytes (mgpu_engine.hip)
+    rows_lds = 2 * n1 * ktot * 16 + n1 * 8 + n_rows * (2 * n1 * 16 + 8)      # recip_rows_lds_bytes (mgpu_launch.hip)
     assert rows_lds > 40 * 1024, "this molecule is meant to overflow the row form's LDS budget"
-    assert 2 * n1 * ktot * 16 + n1 * 8 <= 64 * 1024
+    assert 2 * n1 * ktot * 16 + 2 * n1 * 8 <= 40 * 1024, "... and to fit the wide row form's table budget"
     for r in range(2):
         eng.init_structure_factor(r, True)
     P = refcpu_mod.RefCPU(s, mol_capacity=10)
