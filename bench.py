@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 fp64 lanes x 2 flop x 2.4 GHz (spec)
 FP64_SUSTAINED_TFLOPS = 61.0    # tools/probe_fma.hip on MI355X: what back-to-back v_fma_f64 sustains (clock under load)
 FLOP_PER_PAIR = 64.0            # ~64 fp64 flops per site-atom pair term incl. erfc (the ALGORITHMIC flop count)
-PMC_DIR = os.path.join("profiles", "r04")
+PMC_DIR = os.path.join("profiles", "r05")
 
 
 def lib_sha256():

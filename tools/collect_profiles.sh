@@ -1,20 +1,24 @@
 #!/bin/bash
-# Copy what tools/measure_round.sh left under gpurun_out/r4final into profiles/r04 under the names profiles/r04/README.md uses.
+# Copy what tools/measure_round.sh left under gpurun_out/r5final into profiles/r05 under the names profiles/r05/README.md uses.
 set -e
 cd "$(dirname "$0")/.."
-src=${1:-gpurun_out/r4final}
-dst=${2:-profiles/r04}
+src=${1:-gpurun_out/r5final}
+dst=${2:-profiles/r05}
 mkdir -p $dst
 cp $src/lib_sha256.txt $dst/lib_sha256.txt
 for wl in spce co2_gcmc framework_water; do
-  cp $src/pmc/pmc_${wl}_r04.json $dst/pmc_${wl}.json
-  cp $src/pmc/pmc_kernels_${wl}_r04.txt $dst/pmc_kernels_${wl}.txt
+  cp $src/pmc/pmc_${wl}_r05.json $dst/pmc_${wl}.json
+  cp $src/pmc/pmc_kernels_${wl}_r05.txt $dst/pmc_kernels_${wl}.txt
   cp $src/prof_$wl/p_kernel_stats.csv $dst/bench_${wl}_kernel_stats.csv
   cp $src/bench_${wl}_under_rocprof.json $dst/bench_${wl}_under_rocprof.json
   cp $src/bench_${wl}.json $dst/bench_${wl}.json
 done
 cp $src/bench_co2_isotherm.json $dst/bench_co2_isotherm.json
-cp $src/bench_co2_isotherm_exchange_c_abi.json $dst/bench_co2_isotherm_exchange_c_abi.json
+cp $src/bench_co2_isotherm_exchange_torch.json $dst/bench_co2_isotherm_exchange_torch.json
+for wl in spce_triclinic adsorbate24; do cp $src/bench_$wl.json $dst/bench_$wl.json; done
+cp $src/farm_window_speed.txt $dst/farm_window_speed.txt
+cp $src/recip_many_sites.txt $dst/recip_many_sites.txt
+cp $src/host_team_matrix.txt $dst/host_team_matrix.txt 2>/dev/null || true
 cp $src/bench_driver_format.json $dst/bench_driver_format_steps20_warmup5.json
 cp $src/bench_driver_format_with_pmc.json $dst/bench_driver_format_steps20_warmup5_with_pmc.json 2>/dev/null || true
 cp $src/chain_speed.txt $dst/chain_speed.txt

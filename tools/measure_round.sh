@@ -1,11 +1,11 @@
 #!/bin/bash
 # One measurement session on an MI355X box (run as: gpurun --timeout 1200 -- bash tools/measure_round.sh [part]): what
-# profiles/r04/ keeps.  Output under gpurun_out/r4final; tools/collect_profiles.sh copies it into profiles/r04.
+# profiles/r05/ keeps.  Output under gpurun_out/r5final; tools/collect_profiles.sh copies it into profiles/r05.
 # part 1: GPU tests, single-chain speed / stage stamps / rocprofv3 trace, kernel-only timings, the bench lines
 # part 2: PMC passes (tied to the library hash) and rocprofv3 kernel stats of the three workloads
 set -e -o pipefail
 part=${1:-1}
-out=gpurun_out/r4final
+out=gpurun_out/r5final
 mkdir -p $out
 export TMPDIR=/tmp
 sha256sum maniac_mc_amd/libmaniac_hip.so > $out/lib_sha256.txt
@@ -29,18 +29,24 @@ if [ "$part" = 1 ]; then
   python bench.py --workload co2_gcmc > $out/bench_co2_gcmc.json 2> $out/bench_co2_gcmc.err
   python bench.py --workload framework_water > $out/bench_framework_water.json 2> $out/bench_framework_water.err
   python bench.py --workload co2_isotherm > $out/bench_co2_isotherm.json 2> $out/bench_co2_isotherm.err
-  python bench.py --workload co2_isotherm --exchange c-abi --no-cpu-baseline > $out/bench_co2_isotherm_exchange_c_abi.json 2> $out/bench_co2_isotherm_exchange_c_abi.err
+  python bench.py --workload co2_isotherm --exchange torch --no-cpu-baseline > $out/bench_co2_isotherm_exchange_torch.json 2> $out/bench_co2_isotherm_exchange_torch.err
+  python bench.py --workload spce_triclinic > $out/bench_spce_triclinic.json 2> $out/bench_spce_triclinic.err
+  python bench.py --workload adsorbate24 > $out/bench_adsorbate24.json 2> $out/bench_adsorbate24.err
+  # round 5: the few-chain regime (one launch per lane step) against the batched path, and the many-site reciprocal kernels
+  python tools/farm_window_speed.py --replicas 1,8,64,512,1024 --modes batched,w1,w2,w3 --lanes 1,2 --seconds 0.5 --json $out/farm_window_speed.json > $out/farm_window_speed.txt 2>&1
+  python tools/recip_many_sites.py > $out/recip_many_sites.txt 2>&1
+  python tools/host_team_matrix.py > $out/host_team_matrix.txt 2>&1 || true
 else
-  bash tools/pmc_passes.sh $out/pmc r04 4096 1 spce > $out/pmc_spce.log 2>&1   # the default bench: 16384 chains on 4 lanes, engine nsplit 1
-  bash tools/pmc_passes.sh $out/pmc r04 4096 2 co2_gcmc > $out/pmc_co2.log 2>&1
-  bash tools/pmc_passes.sh $out/pmc r04 2048 4 framework_water > $out/pmc_fw.log 2>&1
-  mkdir -p profiles/r04
-  for wl in spce co2_gcmc framework_water; do cp $out/pmc/pmc_${wl}_r04.json profiles/r04/pmc_${wl}.json; done
+  bash tools/pmc_passes.sh $out/pmc r05 4096 1 spce > $out/pmc_spce.log 2>&1   # the default bench: 16384 chains on 4 lanes, engine nsplit 1
+  bash tools/pmc_passes.sh $out/pmc r05 4096 2 co2_gcmc > $out/pmc_co2.log 2>&1
+  bash tools/pmc_passes.sh $out/pmc r05 2048 4 framework_water > $out/pmc_fw.log 2>&1
+  mkdir -p profiles/r05
+  for wl in spce co2_gcmc framework_water; do cp $out/pmc/pmc_${wl}_r05.json profiles/r05/pmc_${wl}.json; done
   for wl in spce co2_gcmc framework_water; do
     (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$out/prof_$wl -o p -- python3 /root/repo/bench.py --workload $wl --no-cpu-baseline --steps 200 --settle-s 0 --sustained-steps 0 --configs 0 --replicas-sweep "" > /root/repo/$out/bench_${wl}_under_rocprof.json 2> /root/repo/$out/bench_${wl}_under_rocprof.err)
     rm -f $out/prof_$wl/*kernel_trace.csv
   done
-  # the headline line again, now that profiles/r04/pmc_*.json are of this build (roofline.traffic / valu_issue filled in)
+  # the headline line again, now that profiles/r05/pmc_*.json are of this build (roofline.traffic / valu_issue filled in)
   python bench.py --steps 20 --warmup 5 > $out/bench_driver_format_with_pmc.json 2> $out/bench_driver_format_with_pmc.err
 fi
 find $out -name '*kernel_trace.csv' -path '*pmc*' -delete
