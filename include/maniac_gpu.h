@@ -37,13 +37,11 @@ extern "C" {
 #define MGPU_ERR_NO_DEVICE 4
 #define MGPU_ERR_STATE 5
 
-/* Environment switches, all read ONCE in mgpu_engine_create and all for tuning / tests only (defaults are the
- * measured best; none changes results beyond the last bits of a sum order):
+/* Environment switches, all read ONCE in mgpu_engine_create, all for tests / A-B runs only, each one exercised by a test
+ * (defaults are the measured best; none changes results beyond the last bits of a sum order):
  *   MGPU_PAIR_NSPLIT=<n>        waves per pair-sweep item (default: engine constant from the topology's capacity
  *                               and the replica count, see engine_nsplit in mgpu_engine.hip)
- *   MGPU_PAIR_BLOCKS_PER_CU=<n> resident pair-sweep workgroups per CU (default 2)
- *   MGPU_PAIR_NO_FUSE=1         trial moves as two single-state sweeps instead of one fused old + new sweep
- *   MGPU_RECIP_PER_K=1          per-k reciprocal kernel even where the row form's LDS tables fit
+ *   MGPU_RECIP_PER_K=1          per-k reciprocal kernel even where a row form applies
  *   MGPU_PAIR_EXACT_FOLD=1      always the multiply / round / fma minimum-image fold in the pair sweep (default: the
  *                               two-instruction fold min(|d|, L - |d|) whenever every resident atom of the replicas in
  *                               a launch and every candidate site of it lies within 0.745 box lengths of the cell
@@ -52,16 +50,12 @@ extern "C" {
  *   MGPU_PAIR_FLAT=0 / 1        plane-by-plane (pair_sweep_kernel) / flat (pair_flat_kernel) register-site pair sweep
  *                               (default: flat for topologies with short planes -- every plane-major residue type has
  *                               at most 1024 molecule slots -- or a frozen framework, orthorhombic boxes)
- *   MGPU_NO_FROZEN=1            inactive residues of >= 64 atoms stay site-major in the caller's site order (default:
- *                               "frozen" layout, sites sorted by atom type, swept by pair_flat_kernel)
  *   MGPU_NO_FROZEN_BATCH=1      framework boxes keep one wave per candidate (pair_flat_kernel) instead of 64 candidates
  *                               per wave against chunks of the framework (pair_frozen_kernel; default where exactly one
  *                               frozen residue type exists and it is identical in every replica)
- *   MGPU_FROZEN_CHUNK=<n>       framework atoms per pair_frozen_kernel chunk, 1..64 (default: from the framework's size
- *                               alone -- the fewest multiple-of-eight chunks of <= 30 atoms; never from the batch: the
- *                               chunk partials are summed in a fixed order, so results are reproducible per value)
- *   MGPU_PAIR_FUSE_MAX=<n>      largest molecule whose trial moves sweep old + new state in one pass (default 3; 4 and
- *                               5 select kernels of up to 256 VGPRs at half the occupancy: measured slower)
+ *   MGPU_TRI_FULL_SEARCH=1      triclinic boxes: always ComputeDistance's full 27-image search (default: for the reader's
+ *                               lower-triangular cells the same minimum in eight evaluations, the full search only
+ *                               where its certificate fails; bit-identical results)
  * Threading rule: the per-lane asynchronous entry points (mgpu_*_submit, mgpu_*_wait, mgpu_commit_submit,
  * mgpu_lane_site_buffer) may be called concurrently from different host threads on DIFFERENT lanes -- one thread per
  * lane at a time (the farm runs up to three driver threads that way); lanes must hold disjoint replicas while their

@@ -544,7 +544,6 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
         hipDeviceProp_t prop;
         HIP_TRY_E(hipGetDeviceProperties(&prop, device));
         e->n_cu = std::max(1, prop.multiProcessorCount);
-        if (const char *ov = std::getenv("MGPU_PAIR_BLOCKS_PER_CU")) e->pair_blocks_per_cu = std::max(1, std::atoi(ov));   // tuning only
         e->pair_nsplit = engine_nsplit(e);
     }
     HIP_TRY_E(hipMalloc(&e->d_res_q, e->charges.size() * sizeof(double)));

@@ -10,7 +10,7 @@ One launch group per repetition, shaped like one lane step of bench.py's farm fo
   framework_water  R trials of the full move set (25 % translation, 25 % rotation, 25 % insertion, 25 % deletion) of
                    4-site water in the 2208-atom framework (configs[3])
 This is also the command the rocprofv3 --pmc passes profile (tools/pmc_passes.sh).
-Environment knobs read by the library: MGPU_PAIR_NSPLIT, MGPU_PAIR_BLOCKS_PER_CU.
+Environment knob read by the library: MGPU_PAIR_NSPLIT.
 MANIAC_HIP_LIB selects an alternative build of libmaniac_hip.so (tuning variants).
 """
 import argparse
@@ -158,7 +158,7 @@ def main():
             "pair_ns_per_eval": tot.get("pair_sweep", 0.0) / args.reps * 1e3 / ev,
             "recip_ns_per_eval": out.get("recip", 0.0) * 1e3 / ev,
             "acceptance": "device" if args.decide else "host + commit launch", "lib": os.path.basename(_lib.LIB_PATH), "nsplit": os.environ.get("MGPU_PAIR_NSPLIT", "auto"),
-            "blocks_per_cu": os.environ.get("MGPU_PAIR_BLOCKS_PER_CU", "auto")}
+            "blocks_per_cu": "auto"}
     print(json.dumps(line))
     if args.json:
         with open(args.json, "w") as f:
