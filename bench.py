@@ -340,10 +340,12 @@ def replicas_sweep(system, counts, device, host_threads, seconds, t_step, r_step
         # batched path, lanes: measured round 4 at the 10 125-atom box, accepted moves/s with 1 / 2 / 4 lanes: 8 chains 0.115 / 0.098 /
         # 0.10 M, 64: 0.72 / 0.75 / 0.69, 512: 2.6 / 2.8 / 1.3, 1024: - / 4.9 / 3.4, 2048: - / 6.3 / 5.7, 4096: - / 7.2 / 6.2,
         # 8192: - / 6.9 / 7.4, 16384: - / 7.2 / 7.7 (a lane's launch should fill the GPU: at nsplit 4 that takes ~1000 chains).
-        # window mode, round 5 (profiles/r05/farm_window_nsplit.txt): one lane up to 256 chains, two from 512
+        # window mode, round 5 (profiles/r05/farm_window_speed.txt): ONE lane -- a second lane doubles the driver's launches per
+        # lock step, and two lanes' launches sharing the chip scatter from box to box (512 chains: 3.9-6.3 M on two lanes,
+        # 5.1-5.5 M on one)
         window = R <= 1024
         if window:
-            lanes = 1 if R < 512 else 2
+            lanes = 1
         else:
             lanes = 2 if R < 8192 else 4
         farm = FortranFarm(system, R, device=device, seed=77, translation_step=t_step, rotation_step=r_step, p_translation=0.5,

@@ -2804,8 +2804,11 @@ __device__ __forceinline__ void farm_resolve(const Topo &tp, const BoxDev &bx, d
     if (lane == 0) g.acur[rec.replica] ^= 1;
 }
 
+// (launch bounds: four waves per SIMD = two of these 8-wave workgroups per CU, i.e. at most 128 VGPRs.  Left to itself
+//  the compiler took 130-132 -- ONE workgroup per CU -- and every farm of more than ~28 chains paid a second round of
+//  workgroups: 64 chains 22 -> 32 us per step, 512 chains 57 -> 82 us.)
 template <bool FLAT, bool FASTW>
-__global__ __launch_bounds__(kChainBlock, 1) void farm_window_kernel(
+__global__ __launch_bounds__(kChainBlock, 4) void farm_window_kernel(
     const Topo *__restrict__ tpp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
     const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab, const char *__restrict__ coul_tab_g,
     const int *__restrict__ trj, const double2 *__restrict__ tw, int n_tasks, const RecipRow *__restrict__ rows, int n_rows,

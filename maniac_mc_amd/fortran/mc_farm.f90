@@ -990,7 +990,7 @@ contains
         integer(c_int) :: rc
         integer :: i, b, r, ia, mv, slot, k, o, v
         integer(int64) :: c0, c1, c2
-        integer(int64) :: k_tt, k_t, k_rt, k_r, k_ct, k_c, k_dt, k_d, n_skip, n_done, n_und
+        integer(int64) :: k_tt, k_t, k_rt, k_r, k_ct, k_c, k_dt, k_d, n_skip, n_done, n_und, n_back
         real(real64) :: e_old, e_new, delta_e, probability
         logical :: yes, bad
         type(lane_buffers), pointer :: L
@@ -1002,10 +1002,15 @@ contains
         if (rc /= MGPU_OK) return
         call system_clock(c1)
         k_tt = 0; k_t = 0; k_rt = 0; k_r = 0; k_ct = 0; k_c = 0; k_dt = 0; k_d = 0; n_skip = 0; n_done = 0; n_und = 0
+        n_back = 0
         bad = .false.
+        ! (the chains are independent: with a few hundred of them the loop -- an exp per chain -- runs on the driver's team)
+        !$omp parallel do num_threads(F%team) schedule(static) if (F%team > 1 .and. L%n >= 256) &
+        !$omp& private(i, r, ia, mv, slot, k, o, v, e_old, e_new, delta_e, probability, yes) &
+        !$omp& reduction(+:k_tt, k_t, k_rt, k_r, k_ct, k_c, k_dt, k_d, n_skip, n_done, n_und, n_back) reduction(.or.:bad)
         do i = 1, L%n
             if (L%w_live(i, b) == 0) cycle
-            L%in_flight = L%in_flight - 1
+            n_back = n_back + 1
             r = L%first + i
             ia = L%w_ia(i, b); mv = L%w_mv(i, b); slot = L%w_slot(i, b)
             v = L%verdict(i)
@@ -1080,6 +1085,8 @@ contains
             n_done = n_done + 1
             L%resolved(i) = L%resolved(i) + 1
         end do
+        !$omp end parallel do
+        L%in_flight = L%in_flight - n_back
         L%counters = L%counters + [k_tt, k_t, k_rt, k_r, k_ct, k_c, k_dt, k_d]
         L%accepted = L%accepted + k_t + k_r + k_c + k_d
         L%trials = L%trials + k_tt + k_rt + k_ct + k_dt
