@@ -62,7 +62,11 @@ def pmc_summary(workload, kernel_substr):
     except Exception:
         return None
     out = {"path": path, "build": d.get("build"), "lib_sha256": d.get("lib_sha256"), "candidates": float(d.get("candidates_per_launch") or 0.0),
-           "evals": float(d.get("evaluations_per_launch_group") or 0.0), "stale": d.get("lib_sha256") != lib_sha256(), "kernels": []}
+           "evals": float(d.get("evaluations_per_launch_group") or 0.0), "kernels": []}
+    # the counters belong to this build if the BINARY is the one profiled, or -- a rebuild changes the binary's hash through
+    # its build id and output path, not its code -- if the library's SOURCES are the ones it was built from
+    from maniac_mc_amd import _lib
+    out["stale"] = d.get("lib_sha256") != lib_sha256() and d.get("source_digest") != _lib.source_digest()
     if out["stale"] or not out["evals"]:
         return out
     hbm = valu = 0.0

@@ -78,6 +78,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def source_digest() -> str:
+    """sha256 over the library's sources (csrc/*, include/maniac_gpu.h) in a fixed order: what a profile of the library
+    belongs to, whatever the linker's build id or the output path did to the binary's own hash."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")))
+    files.append(os.path.join(_HERE, "..", "include", "maniac_gpu.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 _lib = None
 
 

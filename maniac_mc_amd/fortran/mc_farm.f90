@@ -936,7 +936,8 @@ contains
                 k = mgpu_rng_fill(F%cxs(:, L%first + i), int(min(RNG_BLOCK, L%n - i + 1), c_int), int(NRAND, c_int), L%w_u(:, i, b))
             end do
         end if
-        !$omp parallel do num_threads(F%team) schedule(static) private(i, r, ia, mv, slot, k, d) if (F%team > 1 .and. L%n >= 256)
+        ! (one thread: a chain's record costs ~25 ns and a lane holds at most 1024 chains -- measured round 5, a team of two made
+        !  this loop 31 us at 512 chains against 12: the fork / join of a region outweighs a loop this short)
         do i = 1, L%n
             r = L%first + i
             L%rep(i) = int(r - 1, c_int)
@@ -971,7 +972,6 @@ contains
             L%acc_u(i) = L%w_u(9, i, b)
             L%acc_pref(i) = acceptance_prefactor(mv, ia, r)
         end do
-        !$omp end parallel do
         call system_clock(c1)
         rc = mgpu_farm_window_submit(F%engine, int(g, c_int), int(L%n, c_int), L%rep, L%t, L%m, L%mvc, L%forced, L%u5, &
                                      L%acc_u, L%acc_pref, F%translation_step, F%rotation_step, F%temperature)
@@ -1004,10 +1004,7 @@ contains
         k_tt = 0; k_t = 0; k_rt = 0; k_r = 0; k_ct = 0; k_c = 0; k_dt = 0; k_d = 0; n_skip = 0; n_done = 0; n_und = 0
         n_back = 0
         bad = .false.
-        ! (the chains are independent: with a few hundred of them the loop -- an exp per chain -- runs on the driver's team)
-        !$omp parallel do num_threads(F%team) schedule(static) if (F%team > 1 .and. L%n >= 256) &
-        !$omp& private(i, r, ia, mv, slot, k, o, v, e_old, e_new, delta_e, probability, yes) &
-        !$omp& reduction(+:k_tt, k_t, k_rt, k_r, k_ct, k_c, k_dt, k_d, n_skip, n_done, n_und, n_back) reduction(.or.:bad)
+        ! (one thread, as in issue_window: a chain costs an exp and a few adds)
         do i = 1, L%n
             if (L%w_live(i, b) == 0) cycle
             n_back = n_back + 1
@@ -1085,7 +1082,6 @@ contains
             n_done = n_done + 1
             L%resolved(i) = L%resolved(i) + 1
         end do
-        !$omp end parallel do
         L%in_flight = L%in_flight - n_back
         L%counters = L%counters + [k_tt, k_t, k_rt, k_r, k_ct, k_c, k_dt, k_d]
         L%accepted = L%accepted + k_t + k_r + k_c + k_d

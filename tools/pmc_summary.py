@@ -49,7 +49,9 @@ def main():
     extra = (" " + os.environ.get("PMC_EXTRA", "")).rstrip()
     lines = [f"# rocprofv3 --pmc passes (separate runs, --kernel-trace only) of `python3 tools/bench_kernels.py --workload {wl} --reps 3 --replicas {repl}{extra}`, build {tag}, libmaniac_hip.so sha256 {sha[:16]}",
              "# per-dispatch means over the dispatches after each kernel's first; whole GPU", ""]
-    out = {"build": tag, "workload": wl, "lib_sha256": sha, "candidates_per_launch": repl,
+    sys.path.insert(0, root)
+    from maniac_mc_amd import _lib
+    out = {"build": tag, "workload": wl, "lib_sha256": sha, "source_digest": _lib.source_digest(), "candidates_per_launch": repl,
            "evaluations_per_launch_group": meta.get("evaluations_per_launch_group", 2 * repl),
            "evaluations_per_pair_launch": 2 * repl if wl == "spce" else None, "bench_kernels": meta, "source": "tools/pmc_passes.sh (rocprofv3 --pmc, separate passes; FETCH_SIZE doubled per the gfx950 calibration)",
            "kernels": {}}
