@@ -424,6 +424,14 @@ int mgpu_chain_get_timing(mgpu_engine *e, double us[15]);
  *               reject) and the device obeys
  *   u5          [n][5] the construction's uniform numbers (mgpu_move_trial_submit's)
  *   accept_u / accept_pref   the test's uniform number and prefactor (mgpu_chain_window's)
+ *   slot_u      NULL: m[c] is the molecule the driver picked (against counts that must then be current: a window with an
+ *               insertion / deletion is collected before the lane's next submit).  Otherwise BY COUNT: m is ignored,
+ *               slot_u[c] is the uniform number of PickRandomMoleculeIndex and accept_pref[c] = phi V for insertions and
+ *               deletions (1 for moves); the launch completes every record from the replica's molecule count as it is when
+ *               it runs -- slot int(u N) of N (nothing to do for a move or deletion of an empty type or an insertion into a
+ *               full one: verdict 5), prefactor phi V / (N + 1) or N / (phi V) -- so that insertion / deletion farms, too,
+ *               queue a window before they have seen the last (the type and the kind of move do not depend on N); the
+ *               driver replays the same arithmetic with its own counts when it collects the window
  * mgpu_farm_window_wait collects the lane's OLDEST window: old_energy / new_energy [n][5] as mgpu_gcmc_trial_wait fills
  * them, verdict[c] = 0 rejected, 1 accepted and committed, 2 UNDECIDED, 4 nothing done (the replica waits for the driver's
  * decision of an earlier step), 5 idle record.  Undecided: the draw lies within the engine's relative margin (16 ulp;
@@ -439,7 +447,7 @@ int mgpu_chain_get_timing(mgpu_engine *e, double us[15]);
 int mgpu_farm_window_capacity(const mgpu_engine *e, int *max_chains, int *max_in_flight);
 int mgpu_farm_window_submit(mgpu_engine *e, int lane, int n, const int *replica, const int *t, const int *m, const int *move,
                             const int *forced, const double *u5, const double *accept_u, const double *accept_pref,
-                            double t_step, double r_step, double temperature);
+                            const double *slot_u, double t_step, double r_step, double temperature);
 int mgpu_farm_window_wait(mgpu_engine *e, int lane, double *old_energy, double *new_energy, int *verdict);
 int mgpu_farm_window_flush(mgpu_engine *e);
 int mgpu_farm_window_get_stats(const mgpu_engine *e, long long *windows, long long *undecided);

@@ -2669,16 +2669,27 @@ __global__ __launch_bounds__(kChainBlock, 1) void chain_window_kernel(
 // replica is marked `stalled`, and every later window already queued for it does nothing (verdict 4) until the host,
 // which decides with its own exp, sends the step again with `forced` set.  The host checks every other verdict against
 // its own rule, so every decision taken is the host's.
+// Records `by_count` (insertion / deletion farms): which molecule a step picks and its prefactor depend on the molecule count
+// N, i.e. on the outcome of the chain's previous step -- the one thing that would keep such a farm from queueing a window
+// before it has seen the last.  The driver therefore hands over what does NOT depend on N (the residue type and the kind of
+// move it drew, the draw of PickRandomMoleculeIndex, phi V) and every workgroup completes its records from the replica's
+// count as it is when the launch runs: slot = int(u N) of N (a move or deletion of an empty type, an insertion into a full
+// one: nothing to do, as in the reference's drivers), prefactor phi V / (N + 1) or N / (phi V)
+// (src/monte_carlo.f90:50-75, src/monte_carlo_utils.f90:184-226).  The driver replays the same integer arithmetic with
+// its own counts when it collects the window.
 // Orthorhombic boxes, row-form k sweep, molecules of <= kMaxFusedSitesWide sites, frames resident.
 // ------------------------------------------------------------------------------------------
 struct FarmRec {
     int replica, t, m, move;      // move 0: the chain does nothing this step; 1 translation, 2 rotation, 3 creation, 4 deletion
-    int forced, pad;              // 0: apply the rule; 1 / 2: the host has decided this step -- accept / reject
+    int forced;                   // 0: apply the rule; 1 / 2: the host has decided this step -- accept / reject
+    int by_count;                 // 1: the molecule slot and the prefactor follow from the replica's molecule COUNT on the device
     double u[5];                  // the construction's uniform numbers (trial_build_kernel)
-    double acc_u, pref;           // the test's uniform number and prefactor (1; phi V / (N + 1); N / (phi V))
+    double acc_u, pref;           // the test's uniform number and prefactor (1; phi V / (N + 1); N / (phi V)); by_count: phi V
+    double sel_u;                 // by_count: the uniform number of PickRandomMoleculeIndex
 };
-static_assert(sizeof(FarmRec) == 80, "FarmRec is read as ten 8-byte words");
-constexpr int kFarmInline = 36;                  // records that travel in the kernel arguments (more: read from pinned host memory)
+constexpr int kFarmRecWords = 11;
+static_assert(sizeof(FarmRec) == 8 * kFarmRecWords, "FarmRec is read as 8-byte words");
+constexpr int kFarmInline = 32;                  // records that travel in the kernel arguments (more: read from pinned host memory)
 constexpr int kFarmOut = 11;                     // doubles per chain in the host block: old[5] | new[5] | verdict
 constexpr int kFarmVerdictRejected = 0, kFarmVerdictAccepted = 1, kFarmVerdictUndecided = 2, kFarmVerdictStalled = 4, kFarmVerdictIdle = 5;
 struct FarmArgs {
@@ -2706,11 +2717,14 @@ __device__ __forceinline__ void farm_resolve(const Topo &tp, const BoxDev &bx, d
     int verdict;
     // the roles sweep whatever the replica's stall flag says (they only read, and the k role's A + delta goes to the buffer
     // that is NOT current): the flag is looked at here, once, beside the partials -- not on every role's critical path
-    const int skip = rec.move == 0 || (rec.forced == 0 && g.stalled[rec.replica] != 0);
+    const int waits = rec.forced == 0 && g.stalled[rec.replica] != 0;
+    const int skip = rec.move == 0 || waits;
     double o[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, w[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     const int kind = rec.move <= 2 ? 0 : (rec.move == 3 ? 1 : 2);
     if (skip) {
-        verdict = rec.move == 0 ? kFarmVerdictIdle : kFarmVerdictStalled;
+        // (a by-count record behind an undecided step waits even when THIS count makes it a no-op: the step it waits for
+        //  may change the count, and the chain's steps are followed in order)
+        verdict = waits && (rec.by_count || rec.move != 0) ? kFarmVerdictStalled : kFarmVerdictIdle;
     } else {
         // every split partial of the chain's two entries in one round trip, then one lane per (entry, component) adds them
         // in split order -- the order trial_wait uses on the host
@@ -2844,7 +2858,7 @@ __global__ __launch_bounds__(kChainBlock, 4) void farm_window_kernel(
     // ---- records: ten 8-byte words per chain from the kernel arguments (few chains) or from pinned host memory
     {
         const double *src = reinterpret_cast<const double *>((n <= kFarmInline ? g.inline_recs : g.recs) + c_lo);
-        if (tid < 10 * n_c) reinterpret_cast<double *>(s_rec)[tid] = src[tid];
+        if (tid < kFarmRecWords * n_c) reinterpret_cast<double *>(s_rec)[tid] = src[tid];
     }
     if (!k_role) {
         // (the table staging runs under the records' load)
@@ -2855,6 +2869,20 @@ __global__ __launch_bounds__(kChainBlock, 4) void farm_window_kernel(
         if (FLAT && tid < kMaxGrp) s_grp[tid] = make_int4(tp.grp_start[tid], tp.grp_cnt[tid], tp.grp_ty[tid], 0);
     }
     __syncthreads();
+    if (tid < n_c && s_rec[tid].by_count && s_rec[tid].move != 0) {
+        // complete the record from the replica's molecule count (see above); every workgroup of the chain does the same
+        FarmRec &r = s_rec[tid];
+        const int nm = nmol[r.replica * tp.n_res + r.t];
+        if (r.move == 3) {
+            if (nm >= tp.cap[r.t]) r.move = 0;                          // full: nothing to do (monte_carlo.f90:63)
+            else { r.m = 0; r.pref = r.pref / (double)(nm + 1); }       // phi V / (N + 1), N + 1 = the count after it
+        } else if (nm <= 0) {
+            r.move = 0;                                                 // PickRandomMoleculeIndex of an empty type: the drivers return
+        } else {
+            r.m = min((int)(r.sel_u * nm), nm - 1);
+            if (r.move == 4) r.pref = ((double)(nm - 1) + 1.0) / r.pref;   // (N' + 1) / (phi V), N' = the count after it
+        }
+    }
     if (tid < n_c) s_skip[tid] = s_rec[tid].move == 0 ? 1 : 0;          // (a stalled replica is the resolver's business)
     if (k_role && tid == 0) s_acur = s_rec[0].move != 0 ? g.acur[s_rec[0].replica] : 0;
     __syncthreads();

@@ -318,7 +318,7 @@ static int farm_reserve(mgpu_engine *e, Lane &ln, int cap) {
 
 int mgpu_farm_window_submit(mgpu_engine *e, int lane, int n, const int *replica, const int *t, const int *m, const int *move,
                             const int *forced, const double *u5, const double *accept_u, const double *accept_pref,
-                            double t_step, double r_step, double temperature) {
+                            const double *slot_u, double t_step, double r_step, double temperature) {
     Lane *lp = nullptr;
     int rc = farm_lane(e, lane, &lp);
     if (rc) return rc;
@@ -368,17 +368,25 @@ int mgpu_farm_window_submit(mgpu_engine *e, int lane, int n, const int *replica,
         const size_t idx = (size_t)replica[c] * e->tp.n_res + t[c];
         if (!e->d_com || !e->frames_ok[idx]) { rc = set_error(MGPU_ERR_STATE, "farm_window_submit: no molecule frames for chain " + std::to_string(c) + " (mgpu_replica_set_frames)"); break; }
         const int k = mv <= 2 ? MGPU_MOVE : (mv == 3 ? MGPU_CREATION : MGPU_DELETION);
-        const int mc = k == MGPU_CREATION ? -1 : m[c];
-        if ((rc = check_candidate(e, c, replica[c], t[c], mc, k != MGPU_CREATION))) break;
-        if (k == MGPU_CREATION && e->h_nmol[idx] >= e->tp.cap[t[c]]) { rc = set_error(MGPU_ERR_CAPACITY, "farm_window_submit: residue type is at mol_capacity"); break; }
-        if (k == MGPU_CREATION && e->h_nmol[idx] < 1) { rc = set_error(MGPU_ERR_STATE, "farm_window_submit: an insertion copies the geometry of molecule 1 of its type"); break; }
-        if (k != MGPU_MOVE) pd.counts_change = true;
+        const int mc = k == MGPU_CREATION ? -1 : (slot_u ? 0 : m[c]);
+        if (!slot_u) {
+            // the caller picked the molecule: against the engine's counts, which must then be current
+            if ((rc = check_candidate(e, c, replica[c], t[c], mc, k != MGPU_CREATION))) break;
+            if (k == MGPU_CREATION && e->h_nmol[idx] >= e->tp.cap[t[c]]) { rc = set_error(MGPU_ERR_CAPACITY, "farm_window_submit: residue type is at mol_capacity"); break; }
+            if (k == MGPU_CREATION && e->h_nmol[idx] < 1) { rc = set_error(MGPU_ERR_STATE, "farm_window_submit: an insertion copies the geometry of molecule 1 of its type"); break; }
+            if (k != MGPU_MOVE) pd.counts_change = true;
+        } else {
+            // the device picks it from the replica's count when the launch runs (FarmRec::by_count)
+            if (!(slot_u[c] >= 0.0 && slot_u[c] < 1.0)) { rc = set_error(MGPU_ERR_INVALID_ARG, "farm_window_submit: slot_u must lie in [0, 1)"); break; }
+            r.by_count = 1;
+            r.sel_u = slot_u[c];
+        }
         n1_max = std::max(n1_max, n1);
         pd.kind[c] = k;
         // a built candidate's centre lies in the cell; with tight frames its sites are within the fast fold's range
         fast = fast && replica_in_range(e, replica[c]);
         if (k != MGPU_DELETION) { pd.ok[c] = e->frames_tight[idx]; fast = fast && pd.ok[c]; }
-        r.t = t[c]; r.m = k == MGPU_CREATION ? 0 : m[c]; r.move = mv;
+        r.t = t[c]; r.m = (k == MGPU_CREATION || slot_u) ? 0 : m[c]; r.move = mv;
         r.forced = forced ? forced[c] : 0;
         if (r.forced < 0 || r.forced > 2) { rc = set_error(MGPU_ERR_INVALID_ARG, "farm_window_submit: forced is 0, 1 (accept) or 2 (reject)"); break; }
         for (int d = 0; d < 5; ++d) r.u[d] = u5[5 * (size_t)c + d];

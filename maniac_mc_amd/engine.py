@@ -191,7 +191,7 @@ class Engine:
         return n.value, d.value
 
     def farm_window_submit(self, replica, t, m, move, u, translation_step, rotation_step, accept_u, accept_pref, temperature,
-                           forced=None, lane=0):
+                           forced=None, lane=0, slot_u=None):
         """mgpu_farm_window_submit: one launch evaluates, decides and commits one step of every chain given."""
         m = _ints(m); n = m.shape[0]
         replica = _ints(replica, n); t = _ints(t, n); move = _ints(move, n)
@@ -199,8 +199,9 @@ class Engine:
         au = np.ascontiguousarray(accept_u, dtype=np.float64).reshape(n)
         ap = np.ascontiguousarray(accept_pref, dtype=np.float64).reshape(n)
         fo = _ints(0 if forced is None else forced, n)
+        su = None if slot_u is None else np.ascontiguousarray(slot_u, dtype=np.float64).reshape(n)
         check(self.L.mgpu_farm_window_submit(self.h, C.c_int(lane), C.c_int(n), _i(replica), _i(t), _i(m), _i(move), _i(fo), _d(u),
-                                             _d(au), _d(ap), C.c_double(translation_step), C.c_double(rotation_step),
+                                             _d(au), _d(ap), _d(su), C.c_double(translation_step), C.c_double(rotation_step),
                                              C.c_double(temperature)))
         return n
 

@@ -262,7 +262,7 @@ module maniac_gpu
             integer(c_int), intent(out) :: max_chains, max_in_flight
             integer(c_int) :: rc
         end function
-        function mgpu_farm_window_submit(e, lane, n, replica, t, m, move, forced, u5, accept_u, accept_pref, &
+        function mgpu_farm_window_submit(e, lane, n, replica, t, m, move, forced, u5, accept_u, accept_pref, slot_u, &
                                          translation_step, rotation_step, temperature) &
                 bind(C, name="mgpu_farm_window_submit") result(rc)
             import :: c_ptr, c_int, c_double
@@ -270,6 +270,7 @@ module maniac_gpu
             integer(c_int), value :: lane, n
             integer(c_int), intent(in) :: replica(*), t(*), m(*), move(*), forced(*)
             real(c_double), intent(in) :: u5(*), accept_u(*), accept_pref(*)
+            type(c_ptr), value :: slot_u              ! c_null_ptr, or c_loc of n uniform numbers: the device picks the molecule
             real(c_double), value :: translation_step, rotation_step, temperature
             integer(c_int) :: rc
         end function

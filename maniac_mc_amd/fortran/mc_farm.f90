@@ -90,6 +90,7 @@ module mc_farm
         integer, allocatable :: issued(:), resolved(:), pend_n(:), pend_forced(:)
         real(real64), allocatable :: pend_u(:, :, :)                                                  ! (NRAND, depth + 1, n)
         integer(c_int), allocatable :: forced(:), verdict(:)
+        real(c_double), allocatable :: slot_u(:)                  ! insertion / deletion farms: the draw the engine picks the molecule with
         integer(int64) :: outstanding = 0, in_flight = 0          ! steps of the run not yet resolved / records in flight
         ! per-lane accumulators (lanes may run on different host threads), folded into the farm's totals by mfarm_run
         integer(int64) :: trials = 0, accepted = 0, skipped = 0, counters(8) = 0, ticks(7) = 0
@@ -277,6 +278,7 @@ contains
         F%device_build = want_device_build
         F%device_accept = want_device_build .and. want_device_accept
         F%window = .false.
+        F%undecided = 0                      ! (a slot is reused by the next farm)
         if (want_device_build .and. want_window) then
             ! where the one-launch path does not apply (triclinic box, large molecules) the farm stays on the batched path
             rc = mgpu_farm_window_capacity(engine, k, i)
@@ -429,7 +431,7 @@ contains
             allocate(L%w_live(n, 0:MGPU_FARM_DEPTH - 1), L%w_ia(n, 0:MGPU_FARM_DEPTH - 1), L%w_mv(n, 0:MGPU_FARM_DEPTH - 1), &
                      L%w_slot(n, 0:MGPU_FARM_DEPTH - 1), L%w_forced(n, 0:MGPU_FARM_DEPTH - 1), &
                      L%w_u(NRAND, n, 0:MGPU_FARM_DEPTH - 1), L%issued(n), L%resolved(n), L%pend_n(n), L%pend_forced(n), &
-                     L%pend_u(NRAND, MGPU_FARM_DEPTH + 1, n), L%forced(n), L%verdict(n))
+                     L%pend_u(NRAND, MGPU_FARM_DEPTH + 1, n), L%forced(n), L%verdict(n), L%slot_u(n))
             L%pend_n = 0; L%pend_forced = 0; L%issued = 0; L%resolved = 0
             L%w_head = 0; L%w_count = 0; L%outstanding = 0; L%in_flight = 0
         end if
@@ -464,7 +466,7 @@ contains
                 if (allocated(F%lane(g)%sites_own)) deallocate(F%lane(g)%sites_own)
                 if (allocated(F%lane(g)%w_live)) deallocate(F%lane(g)%w_live, F%lane(g)%w_ia, F%lane(g)%w_mv, F%lane(g)%w_slot, &
                     F%lane(g)%w_forced, F%lane(g)%w_u, F%lane(g)%issued, F%lane(g)%resolved, F%lane(g)%pend_n, &
-                    F%lane(g)%pend_forced, F%lane(g)%pend_u, F%lane(g)%forced, F%lane(g)%verdict)
+                    F%lane(g)%pend_forced, F%lane(g)%pend_u, F%lane(g)%forced, F%lane(g)%verdict, F%lane(g)%slot_u)
                 nullify(F%lane(g)%sites)
             end if
         end do
@@ -958,23 +960,42 @@ contains
                 L%t(i) = 0; L%m(i) = 0; L%mvc(i) = 0
                 L%acc_u(i) = 0.0_real64; L%acc_pref(i) = 1.0_real64
                 L%u5(:, i) = 0.0_real64
+                L%slot_u(i) = 0.0_real64
                 cycle
             end if
             call select_move(r, L%w_u(:, i, b), ia, mv, slot)
             L%w_live(i, b) = 1
             L%w_ia(i, b) = ia; L%w_mv(i, b) = mv; L%w_slot(i, b) = slot; L%w_forced(i, b) = L%forced(i)
             L%t(i) = int(F%res_type(ia), c_int)
-            L%m(i) = int(max(slot, 1) - 1, c_int)
-            L%mvc(i) = int(merge(mv, 0, slot > 0), c_int)               ! a no-op selection: the engine does nothing for it
             do d = 1, 5
                 L%u5(d, i) = L%w_u(3 + d, i, b)                         ! u4..u6 displacement / position, u7 angle, u8 axis
             end do
             L%acc_u(i) = L%w_u(9, i, b)
-            L%acc_pref(i) = acceptance_prefactor(mv, ia, r)
+            if (F%gcmc) then
+                ! Insertion / deletion farms: the residue type and the kind of move do not depend on the molecule count, the
+                ! slot and the prefactor do -- and the count depends on the outcome of a window that may still be in flight.
+                ! The engine completes the record from the replica's count when the launch runs (slot_u, phi V); the slot
+                ! select_move has just computed from THIS side's count is not used -- resolve_window replays the selection
+                ! once the earlier windows have been followed.  The one no-op that does not depend on the count: the
+                ! rotation of an atom (rotation.f90:45).
+                L%m(i) = 0
+                L%mvc(i) = int(merge(0, mv, mv == MV_ROTATION .and. F%n1(ia) == 1), c_int)
+                L%slot_u(i) = L%w_u(2, i, b)
+                L%acc_pref(i) = merge(F%fugacity(ia, r) * F%volume, 1.0_real64, mv >= MV_CREATION)
+            else
+                L%m(i) = int(max(slot, 1) - 1, c_int)
+                L%mvc(i) = int(merge(mv, 0, slot > 0), c_int)           ! a no-op selection: the engine does nothing for it
+                L%acc_pref(i) = acceptance_prefactor(mv, ia, r)
+            end if
         end do
         call system_clock(c1)
-        rc = mgpu_farm_window_submit(F%engine, int(g, c_int), int(L%n, c_int), L%rep, L%t, L%m, L%mvc, L%forced, L%u5, &
-                                     L%acc_u, L%acc_pref, F%translation_step, F%rotation_step, F%temperature)
+        if (F%gcmc) then
+            rc = mgpu_farm_window_submit(F%engine, int(g, c_int), int(L%n, c_int), L%rep, L%t, L%m, L%mvc, L%forced, L%u5, &
+                                         L%acc_u, L%acc_pref, c_loc(L%slot_u), F%translation_step, F%rotation_step, F%temperature)
+        else
+            rc = mgpu_farm_window_submit(F%engine, int(g, c_int), int(L%n, c_int), L%rep, L%t, L%m, L%mvc, L%forced, L%u5, &
+                                         L%acc_u, L%acc_pref, c_null_ptr, F%translation_step, F%rotation_step, F%temperature)
+        end if
         call system_clock(c2)
         L%in_flight = L%in_flight + count(L%w_live(1:L%n, b) == 1)
         L%w_count = L%w_count + 1
@@ -1011,17 +1032,23 @@ contains
             r = L%first + i
             ia = L%w_ia(i, b); mv = L%w_mv(i, b); slot = L%w_slot(i, b)
             v = L%verdict(i)
-            if (slot == 0) then
-                ! a no-op selection (empty type, full type, rotation of an atom): the step is spent
-                n_skip = n_skip + 1
-                n_done = n_done + 1
-                L%resolved(i) = L%resolved(i) + 1
-                cycle
+            if (F%gcmc .and. v /= 4) then
+                ! the selection again, now that every earlier window of the chain has been followed: this side's count is the
+                ! count the launch saw (a record that did nothing because its replica waits -- verdict 4 -- is sent again as it is)
+                call select_move(r, L%w_u(:, i, b), ia, mv, slot)
+                if ((slot == 0) .neqv. (v == 5)) bad = .true.           ! both sides must find the same steps empty
             end if
             if (v == 4) then
                 ! the window ran behind an undecided step of this chain and did nothing: send the step again, in order
                 L%pend_n(i) = L%pend_n(i) + 1
                 L%pend_u(:, L%pend_n(i), i) = L%w_u(:, i, b)
+                cycle
+            end if
+            if (slot == 0) then
+                ! a no-op selection (empty type, full type, rotation of an atom): the step is spent
+                n_skip = n_skip + 1
+                n_done = n_done + 1
+                L%resolved(i) = L%resolved(i) + 1
                 cycle
             end if
             o = 5 * (i - 1)
@@ -1107,7 +1134,6 @@ contains
         type(lane_buffers), pointer :: L
         rc = MGPU_OK
         depth = max(1, min(F%depth, int(MGPU_FARM_DEPTH)))
-        if (F%gcmc) depth = 1             ! the next selection depends on this step's outcome (counts)
         do g = 0, F%n_lanes - 1
             L => F%lane(g)
             if (L%n == 0) cycle
@@ -1292,7 +1318,7 @@ contains
     subroutine mfarm_window_mode(out) bind(C, name="mfarm_window_mode")
         real(c_double), intent(out) :: out(3)
         out(1) = merge(1.0_real64, 0.0_real64, F%window)
-        out(2) = real(merge(1, F%depth, F%gcmc), real64)
+        out(2) = real(F%depth, real64)
         out(3) = real(F%undecided, real64)
     end subroutine mfarm_window_mode
 

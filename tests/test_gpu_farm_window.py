@@ -135,6 +135,55 @@ def test_farm_window_gcmc_steps_are_the_batched_path():
     a.close(); b.close()
 
 
+def test_by_count_records_follow_the_count_the_launch_sees():
+    """Insertion / deletion windows IN FLIGHT: the driver hands over the residue type, the kind of move, the draw of
+    PickRandomMoleculeIndex and phi V; the launch completes each record from the replica's molecule count as it is when it
+    runs (`slot_u`).  Two windows are queued before either is collected -- the second one's slots and prefactors depend on
+    what the first one accepted -- and held to the batched decide path run step by step with the slot and prefactor
+    computed here from the twin's counts: energies, verdicts, counts, state.  Steps with nothing to do (a deletion from an
+    empty type, an insertion into a full one) come back idle."""
+    s = synth.co2_box(3, seed=13)
+    R = 10
+    cap = 5
+    a, b = _twin(s, R, cap=[cap])
+    rng = np.random.default_rng(21)
+    T = float(s.temperature)
+    V = float(np.linalg.det(s.box_matrix))
+    phiV = 4.0
+    tt = np.zeros(R, np.int32)
+    rep = np.arange(R, dtype=np.int32)
+    seen = set()
+    for rnd in range(12):
+        recs = []
+        for _ in range(2):
+            move = rng.integers(1, 5, R).astype(np.int32)
+            move[rng.random(R) < 0.55] = rng.choice([3, 4])                 # mostly insertions / deletions: the counts hit 0 and cap
+            u = rng.uniform(0, 1, (R, 5)); au = rng.uniform(0, 1, R); su = rng.uniform(0, 1, R)
+            pv = np.where(move >= 3, phiV, 1.0)
+            recs.append((move, u, au, su, pv))
+            b.farm_window_submit(rep, tt, np.zeros(R, np.int32), move, u, 1.0, 0.6, au, pv, T, slot_u=su)
+        for move, u, au, su, pv in recs:
+            o2, w2, v = b.farm_window_wait(R)
+            n_now = np.array([a.num_molecules(r, 0) for r in range(R)])
+            # what the launch must have made of the records, from the twin's counts (mc_farm.f90 select_move)
+            live = np.where(move == 3, n_now < cap, n_now > 0)
+            m = np.minimum((su * n_now).astype(np.int32), np.maximum(n_now - 1, 0)).astype(np.int32)
+            pref = np.ones(R)
+            pref[move == 3] = phiV / (n_now[move == 3] + 1.0)
+            pref[move == 4] = ((n_now[move == 4] - 1.0) + 1.0) / phiV
+            assert np.all(v[~live] == V_IDLE) and not np.any(o2[~live]) and not np.any(w2[~live])
+            if live.any():
+                o1, w1, acc = a.move_trial_decide(rep[live], tt[live], m[live], move[live], u[live], 1.0, 0.6, au[live], pref[live], T)
+                a.synchronize()
+                assert np.array_equal(o1, o2[live]) and np.array_equal(w1, w2[live]), rnd
+                assert np.array_equal(v[live] == V_ACC, acc != 0) and np.all((v[live] == V_ACC) | (v[live] == V_REJ))
+            seen.update((int(mv), int(vv), int(nn)) for mv, vv, nn in zip(move, v, n_now))
+        _same_state(a, b, s, R)                                # (both windows have run on the window engine)
+    assert any(mv == 3 and vv == V_ACC for mv, vv, _ in seen) and any(mv == 4 and vv == V_ACC for mv, vv, _ in seen)
+    assert any(mv == 4 and vv == V_IDLE and nn == 0 for mv, vv, nn in seen) or any(mv == 3 and vv == V_IDLE and nn == cap for mv, vv, nn in seen)
+    a.close(); b.close()
+
+
 def test_undecided_steps_stall_the_chain_until_the_host_decides():
     """With the margin wide open every step is UNDECIDED: nothing is committed, the replica is marked, a window already in
     flight for it does nothing (verdict 4), and the step sent again with the host's decision (`forced`) is obeyed --
@@ -264,18 +313,29 @@ def test_window_farm_is_the_batched_farm(case):
         f.close()
 
 
-def test_window_farm_with_every_step_left_to_the_driver():
+@pytest.mark.parametrize("gcmc", [False, True], ids=["spce_nvt", "co2_gcmc"])
+def test_window_farm_with_every_step_left_to_the_driver(gcmc):
     """The margin wide open: the device leaves EVERY step undecided, the Fortran driver decides each one with its own exp
     and sends it again, and the windows in flight behind an undecided step come back untouched and are sent again in
-    order.  The trajectory is still the batched farm's, bit for bit."""
+    order.  The trajectory is still the batched farm's, bit for bit -- also for an insertion / deletion farm, whose records
+    the launches complete from the count they see."""
     from maniac_mc_amd.fortran_host import FortranFarm
-    s, R, steps = synth.spce_box(5, seed=9), 7, 30
     kw = dict(seed=5, n_threads=2, n_lanes=2, device_build=True, translation_step=0.4, rotation_step=0.4)
+    if gcmc:
+        s, R, steps = synth.co2_box(6, seed=13), 6, 60
+        kw.update(translation_step=1.0, rotation_step=0.6, mol_capacity=[12],
+                  gcmc=dict(p_translation=0.2, p_rotation=0.2, fugacity=8.0 / 50.0 ** 3))
+    else:
+        s, R, steps = synth.spce_box(5, seed=9), 7, 30
     a = FortranFarm(s, R, **kw)
     b = FortranFarm(s, R, window=True, window_depth=3, **kw)
     b.eng.chain_set_margin(1e9)
     a.run(steps); b.run(steps)
-    assert b.window_mode() == (True, 3, R * steps)
+    on, depth, undecided = b.window_mode()
+    # (an insertion onto an atom: exp(-dE/T) underflows to 0 -- the one outcome no margin leaves open)
+    assert (on, depth) == (True, 3) and b.trials - (3 if gcmc else 0) <= undecided <= b.trials
+    assert b.trials == a.trials and b.skipped == a.skipped
+    assert np.array_equal(a.counts(), b.counts())
     assert a.counters() == b.counters() and a.accepted == b.accepted > 0
     for r in range(R):
         assert np.array_equal(a.energy(r), b.energy(r)), r
