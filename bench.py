@@ -332,7 +332,7 @@ def cpu_baseline_gcmc(system, t_act, p_move, translation_step, rotation_step, fu
 
 
 
-def replicas_sweep(system, counts, device, host_threads, seconds, t_step, r_step):
+def replicas_sweep(system, counts, device, host_threads, seconds, t_step, r_step, farm_kw=None):
     """Throughput against the number of chains a GPU holds (same SPC/E step, same Fortran farm, device-built moves).  A farm
     of R chains advances in lock step.  Up to 1024 chains a lane step is ONE launch (window mode: mgpu_farm_window_submit --
     the engine builds, evaluates, decides with the driver's draws and commits; mc_farm.f90 checks every decision against its
@@ -347,14 +347,22 @@ def replicas_sweep(system, counts, device, host_threads, seconds, t_step, r_step
         # window mode, round 5 (profiles/r05/farm_window_speed.txt): ONE lane -- a second lane doubles the driver's launches per
         # lock step, and two lanes' launches sharing the chip scatter from box to box (512 chains: 3.9-6.3 M on two lanes,
         # 5.1-5.5 M on one)
-        window = R <= 1024
+        # insertion / deletion farms (farm_kw: the CO2 box; its steps are host-bound): windows up to the engine's 4096 chains
+        # per launch, and from 1024 chains two lanes, each with a driver thread of its own (round 5, accepted moves/s, batched /
+        # windows: 512 chains 2.5 / 8.5 M on one lane, 1024: 4.5 / 13.0 M, 4096: 10.2 / 12.6 M on two lanes with two drivers)
+        gc = farm_kw is not None
+        window = R <= (4096 if gc else 1024)
+        drivers = 1
         if window:
-            lanes = 1
+            lanes = 2 if gc and R >= 1024 else 1
+            drivers = lanes
         else:
             lanes = 2 if R < 8192 else 4
-        farm = FortranFarm(system, R, device=device, seed=77, translation_step=t_step, rotation_step=r_step, p_translation=0.5,
-                           n_threads=max(1, min(host_threads, 2 if R < 512 else 4)), n_lanes=lanes, n_drivers=1, device_build=True,
-                           window=window, window_depth=2)
+            drivers = 2 if gc and lanes == 4 else 1
+        kw = farm_kw if gc else dict(p_translation=0.5)
+        farm = FortranFarm(system, R, device=device, seed=77, translation_step=t_step, rotation_step=r_step,
+                           n_threads=max(drivers, min(host_threads, 2 if R < 512 else (6 if gc else 4))), n_lanes=lanes,
+                           n_drivers=drivers, device_build=True, window=window, window_depth=3 if gc else 2, **kw)
         try:
             farm.run(20)
             chunk = 50
@@ -372,7 +380,8 @@ def replicas_sweep(system, counts, device, host_threads, seconds, t_step, r_step
             out.append({"replicas": R, "lanes": farm.n_lanes, "value": acc / el, "unit": "accepted MC moves/s",
                         "trial_moves_per_s": steps * R / el, "steps": steps, "us_per_step": el / steps * 1e6,
                         "per_chain_steps_per_s": steps / el,
-                        "path": ("window: one launch per lane step, two in flight (mgpu_farm_window_submit)" if farm.window
+                        "drivers": drivers,
+                        "path": (f"window: one launch per lane step, {farm.window_mode()[1]} in flight (mgpu_farm_window_submit)" if farm.window
                                  else "batched: mgpu_move_trial_submit / wait, rule in Fortran, mgpu_commit_submit"),
                         "steps_left_to_the_driver": farm.window_mode()[2],
                         "engine_nsplit_note": "engine constant of this replica count"})
@@ -1013,12 +1022,14 @@ def main():
         comm.close()
     if rank == 0:
         # GPU legs first, CPU baselines last (short), so that whoever samples the GPU from outside sees it busy
-        if world == 1 and args.replicas_sweep and wl == "spce" and args.host == "fortran":
+        if world == 1 and args.replicas_sweep and wl in ("spce", "co2_gcmc") and args.host == "fortran":
             pts = [int(x) for x in args.replicas_sweep.split(",") if x.strip()]
+            gc_kw = None if wl == "spce" else dict(mol_capacity=[400], gcmc=dict(p_translation=0.0, p_rotation=0.0, fugacity=fug_one))
             try:                                           # an extra leg must never take the bench line down
-                out["replicas_sweep"] = replicas_sweep(system, pts, device, args.host_threads, args.sweep_seconds, t_step, r_step)
+                out["replicas_sweep"] = replicas_sweep(system, pts, device, args.host_threads, args.sweep_seconds, t_step, r_step, gc_kw)
             except Exception as exc:
                 out["replicas_sweep"] = {"error": str(exc)}
+        if world == 1 and args.replicas_sweep and wl == "spce" and args.host == "fortran":
             try:
                 out["single_chain"] = single_chain_leg(system, device, t_step, r_step)
             except Exception as exc:

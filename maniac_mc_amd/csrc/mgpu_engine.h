@@ -17,6 +17,8 @@
 #include <deque>
 #include <omp.h>
 #include <string>
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "../../include/maniac_gpu.h"
@@ -157,7 +159,7 @@ struct Lane {
 };
 constexpr int kLanes = 4;
 constexpr int kFarmDepth = 4;           // farm windows a lane may have in flight
-constexpr int kFarmMaxChains = 1024;   // chains per farm window
+constexpr int kFarmMaxChains = 4096;   // chains per farm window
 
 }  // namespace mgpu
 
@@ -264,8 +266,9 @@ struct mgpu_engine {
     struct Farm {
         double2 *d_A_alt = nullptr;
         int *d_acur = nullptr, *d_stalled = nullptr;
-        bool dirty = false;
-        long long windows = 0, undecided = 0;
+        std::atomic<bool> dirty{false};
+        std::atomic<long long> windows{0}, undecided{0};   // (the lanes may be driven by different host threads)
+        std::mutex mu;                                     // the engine-wide blocks' first allocation
     } farm;
     // profiling
     bool profiling = false;

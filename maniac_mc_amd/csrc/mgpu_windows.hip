@@ -335,9 +335,13 @@ int mgpu_farm_window_submit(mgpu_engine *e, int lane, int n, const int *replica,
     if ((int)fw.pending.size() >= kFarmDepth) return set_error(MGPU_ERR_STATE, "farm_window_submit: too many windows of this lane in flight");
     if (!fw.pending.empty() && fw.pending.back().counts_change)
         return set_error(MGPU_ERR_STATE, "farm_window_submit: the lane's last window carries an insertion / deletion: collect it first");
-    if ((rc = farm_reserve(e, ln, n))) return rc;
     const Topo *d_topo = nullptr;
-    if ((rc = chain_topo(e, &d_topo))) return rc;
+    {
+        // (one lane at a time: the engine's second A(k) buffer, its flags and the device topology are made on first use)
+        std::lock_guard<std::mutex> lock(e->farm.mu);
+        if ((rc = farm_reserve(e, ln, n))) return rc;
+        if ((rc = chain_topo(e, &d_topo))) return rc;
+    }
     const int slot = (int)(fw.seq % kFarmDepth);
     Lane::FarmWindow::Pending pd;
     pd.seq = fw.seq + 1;

@@ -92,6 +92,7 @@ module mc_farm
         integer(c_int), allocatable :: forced(:), verdict(:)
         real(c_double), allocatable :: slot_u(:)                  ! insertion / deletion farms: the draw the engine picks the molecule with
         integer(int64) :: outstanding = 0, in_flight = 0          ! steps of the run not yet resolved / records in flight
+        integer(int64) :: undecided = 0                           ! steps the device left to the driver (folded into the farm's)
         ! per-lane accumulators (lanes may run on different host threads), folded into the farm's totals by mfarm_run
         integer(int64) :: trials = 0, accepted = 0, skipped = 0, counters(8) = 0, ticks(7) = 0
     end type lane_buffers
@@ -938,7 +939,7 @@ contains
                 k = mgpu_rng_fill(F%cxs(:, L%first + i), int(min(RNG_BLOCK, L%n - i + 1), c_int), int(NRAND, c_int), L%w_u(:, i, b))
             end do
         end if
-        ! (one thread: a chain's record costs ~25 ns and a lane holds at most 1024 chains -- measured round 5, a team of two made
+        ! (one thread: a chain's record costs ~25 ns and a lane holds at most a few thousand chains -- measured round 5, a team of two made
         !  this loop 31 us at 512 chains against 12: the fork / join of a region outweighs a loop this short)
         do i = 1, L%n
             r = L%first + i
@@ -1115,7 +1116,7 @@ contains
         L%trials = L%trials + k_tt + k_rt + k_ct + k_dt
         L%skipped = L%skipped + n_skip
         L%outstanding = L%outstanding - n_done
-        F%undecided = F%undecided + n_und
+        L%undecided = L%undecided + n_und
         L%w_head = mod(L%w_head + 1, MGPU_FARM_DEPTH)
         L%w_count = L%w_count - 1
         call system_clock(c2)
@@ -1124,16 +1125,17 @@ contains
         if (bad) rc = 7                   ! a device decision the driver's rule contradicts: never outside the margin
     end function resolve_window
 
-    ! n_steps move selections of every chain through windows: the lanes take turns; a lane keeps up to `depth` windows in
-    ! flight while it has steps to send and collects its oldest one each turn.
-    function run_windows(n_steps) result(rc)
-        integer, intent(in) :: n_steps
+    ! n_steps move selections of every chain through windows: a driver's lanes take turns; a lane keeps up to `depth` windows
+    ! in flight while it has steps to send and collects its oldest one each turn.  n_drv > 1: n_drv host threads, driver d
+    ! with the lanes d, d + n_drv, ... (the lanes share nothing on either side of the C ABI: own stream, own ring of
+    ! windows, own chains).
+    function run_windows(n_steps, n_drv) result(rc)
+        integer, intent(in) :: n_steps, n_drv
         integer(c_int) :: rc
-        integer :: g, depth
-        logical :: busy
+        integer :: g, d
+        integer(c_int) :: rc_drv(0:MGPU_LANES - 1)
         type(lane_buffers), pointer :: L
         rc = MGPU_OK
-        depth = max(1, min(F%depth, int(MGPU_FARM_DEPTH)))
         do g = 0, F%n_lanes - 1
             L => F%lane(g)
             if (L%n == 0) cycle
@@ -1141,9 +1143,35 @@ contains
             L%outstanding = int(L%n, int64) * int(n_steps, int64)
             L%in_flight = 0
         end do
+        rc_drv = MGPU_OK
+        if (n_drv <= 1) then
+            rc_drv(0) = drive_windows(0, 1, n_steps)
+        else
+            !$omp parallel num_threads(n_drv) private(d) proc_bind(spread)
+            d = omp_get_thread_num()
+            rc_drv(d) = drive_windows(d, n_drv, n_steps)
+            !$omp end parallel
+        end if
+        do d = 0, MGPU_LANES - 1
+            if (rc_drv(d) /= MGPU_OK) rc = rc_drv(d)
+        end do
+        do g = 0, F%n_lanes - 1
+            F%undecided = F%undecided + F%lane(g)%undecided
+            F%lane(g)%undecided = 0
+        end do
+    end function run_windows
+
+    function drive_windows(d, n_drv, n_steps) result(rc)
+        integer, intent(in) :: d, n_drv, n_steps
+        integer(c_int) :: rc
+        integer :: g, depth
+        logical :: busy
+        type(lane_buffers), pointer :: L
+        rc = MGPU_OK
+        depth = max(1, min(F%depth, int(MGPU_FARM_DEPTH)))
         do
             busy = .false.
-            do g = 0, F%n_lanes - 1
+            do g = d, F%n_lanes - 1, n_drv
                 L => F%lane(g)
                 if (L%n == 0) cycle
                 do while (L%w_count < depth .and. L%outstanding - L%in_flight > 0)
@@ -1158,7 +1186,7 @@ contains
             end do
             if (.not. busy) exit
         end do
-    end function run_windows
+    end function drive_windows
 
     !---------------------------------------------------------------------------
     ! Advance every chain by n_steps move selections.  out = trials, accepted, skipped selections.
@@ -1205,11 +1233,13 @@ contains
         n_drv = max(1, min(n_drv, F%n_lanes))
         F%lane_threads = n_drv > 1 .and. F%rng_kind /= 0 .and. .not. allocated(slog) .and. F%n_threads >= 2 * n_drv
         if (n_steps > 0 .and. F%window) then
+            ! (the window loops run on one thread per driver: no teams)
+            if (.not. (F%rng_kind /= 0 .and. F%n_threads >= n_drv)) n_drv = 1
             F%lane_threads = .false.
-            F%team = F%n_threads
+            F%team = max(1, F%n_threads / n_drv)
             rc = mgpu_set_host_team(F%engine, int(F%team, c_int))
             if (rc /= MGPU_OK) return
-            rc = run_windows(int(n_steps))
+            rc = run_windows(int(n_steps), n_drv)
             if (rc /= MGPU_OK) return
         else if (n_steps > 0 .and. F%lane_threads) then
             F%team = max(1, F%n_threads / n_drv)

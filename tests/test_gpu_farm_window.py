@@ -252,7 +252,7 @@ def test_farm_window_refusals():
     e.close()
 
 
-@pytest.mark.parametrize("case", ["spce_nvt", "spce_nvt_64", "mixture_nvt", "co2_gcmc", "framework_water_gcmc"])
+@pytest.mark.parametrize("case", ["spce_nvt", "spce_nvt_64", "mixture_nvt", "co2_gcmc", "framework_water_gcmc", "co2_gcmc_drivers"])
 def test_window_farm_is_the_batched_farm(case):
     """mfarm_configure(3): mc_farm.f90 sends ONE launch per lane step (mgpu_farm_window_submit) and follows the outcomes,
     checking every device decision against its own rule.  Same seeds, same chains: counters, counts, running energies,
@@ -272,10 +272,12 @@ def test_window_farm_is_the_batched_farm(case):
     elif case == "mixture_nvt":
         s, R, steps = synth.mixture_box(seed=4), 6, 60
         kw.update(translation_step=0.4, rotation_step=0.4)
-    elif case == "co2_gcmc":
+    elif case in ("co2_gcmc", "co2_gcmc_drivers"):
         s, R, steps = synth.co2_box(20, seed=13), 12, 150
         kw.update(translation_step=1.0, rotation_step=0.6, mol_capacity=[90],
                   gcmc=dict(p_translation=0.2, p_rotation=0.2, fugacity=np.repeat([10.0, 30.0], 6) / 50.0 ** 3))
+        if case == "co2_gcmc_drivers":            # three lanes, each driven by a host thread of its own
+            kw.update(n_lanes=3, n_threads=3, n_drivers=3)
     else:
         s, R, steps = synth.framework_water_box(n_water=12, n_frame=300, L=24.0, seed=7), 8, 120
         kw.update(translation_step=0.5, rotation_step=0.5, mol_capacity=[1, 60],
