@@ -204,6 +204,8 @@ struct mgpu_engine {
     int pair_blocks_per_cu = kPairBlock >= 1024 ? 1 : 2;      // resident pair-sweep workgroups per CU (VGPR / LDS bound)
     int pair_nsplit = 1;             // waves per pair-sweep item: an engine constant (see engine_nsplit)
     std::vector<double> self_of_type; // ComputeEwaldSelfInteractionSingleMol per residue type (host constant)
+    bool rows_contiguous = false;    // every row's tasks are consecutive |kz| (the matrix-unit row sweep's addressing)
+    bool recip_no_mfma = false;      // MGPU_RECIP_NO_MFMA=1: many-site molecules through the vector form of the wide row sweep
     bool pair_fast_fold = true;      // two-instruction minimum-image fold where the atoms' range allows it (MGPU_PAIR_EXACT_FOLD=1: off)
     bool recip_force_per_k = false;  // MGPU_RECIP_PER_K=1: per-k reciprocal kernel even where the row form fits (tests)
     double *d_res_q = nullptr;
@@ -309,6 +311,7 @@ int recip_tile_sites(const mgpu_engine *e, int n1_max);
 size_t recip_rows_lds_bytes(const mgpu_engine *e, int n1_max);
 bool recip_by_rows(const mgpu_engine *e, int n1_max);
 int recip_wide_rows_per_tile(const mgpu_engine *e, int n1_max);   // 0: the wide row form does not apply
+bool recip_wide_mfma(const mgpu_engine *e, int n1_max);
 int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items, int n1_max, int site_stride,
                  bool commit, double2 *A_base, double *d_u, double *d_u_old = nullptr, const AcceptBits *accept = nullptr,
                  const double *sites_override = nullptr, const DecideArgs *decide = nullptr);

@@ -412,6 +412,7 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
         }
     }
     e->pair_fast_fold = std::getenv("MGPU_PAIR_EXACT_FOLD") == nullptr;
+    e->recip_no_mfma = std::getenv("MGPU_RECIP_NO_MFMA") != nullptr;
     e->recip_force_per_k = std::getenv("MGPU_RECIP_PER_K") != nullptr;
 
     BoxDev &bx = e->bx;
@@ -459,6 +460,11 @@ int mgpu_engine_create(mgpu_engine **out, int device, int n_replicas, int n_res,
         size_t covered = 0;
         for (const auto &tk : rtasks) covered += (tk.kp >= 0) + (tk.km >= 0);
         if (covered != (size_t)e->nk) { rrows.clear(); rtasks.clear(); }   // fall back to the per-k kernel
+        // a row's tasks a run of consecutive |kz| (a k list cut by |k|^2: always; checked because the matrix-unit form of the
+        // row sweep addresses task = first task of the row + (kz - first kz))
+        e->rows_contiguous = !rtasks.empty() && e->kmax[2] < 255;
+        for (size_t ti = 1; ti < rtasks.size(); ++ti)
+            if (rtasks[ti].row == rtasks[ti - 1].row && rtasks[ti].j != rtasks[ti - 1].j + 1) e->rows_contiguous = false;
     }
     e->n_rrows = (int)rrows.size();
     e->n_rtasks = (int)rtasks.size();

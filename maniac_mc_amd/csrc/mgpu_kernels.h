@@ -1966,7 +1966,14 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
 // Molecules whose phase tables alone exceed the budget (hundreds of sites) keep the per-k form with its site tiles.
 // Dynamic LDS: tab [nss][ktot] | xy [rows_per_tile][nss] | signed charges [nss].
 // ------------------------------------------------------------------------------------------
-template <bool COMMIT, bool BOTH>
+// MFMA: per item the row form's sums ARE four real matrix products [kz][site-state] x [site-state][row] (sac, sbd, sad, sbc
+// of the pass above), so each wave takes tiles of 16 rows x 16 kz through v_mfma_f64_16x16x4_f64, twelve steps of four
+// site-states for a 24-site move: operand traffic 16 B per lane per 2 x 2048 flop instead of 32 B per 8 -- the vector form is
+// LDS-bound at a quarter of the fp64 peak before bank conflicts (measured 0.07).  The XY factor of a (row, site-state) is
+// formed in registers from the 1-D tables (no XY table, no row tiles, no barrier after phase 1).  Needs every row's tasks
+// to be a run of consecutive kz (the engine checks: rows_contiguous).  A sum over site-states in the matrix unit's order:
+// the trial and the commit pass share it, so A + delta is the same in both.
+template <bool COMMIT, bool BOTH, bool MFMA = false>
 __global__ __launch_bounds__(kBlock, 2) void recip_rows_wide_kernel(
     Topo tp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
     const int *__restrict__ trj, const double2 *__restrict__ tw, const RecipRow *__restrict__ rows, const int *__restrict__ row_first,
@@ -1989,8 +1996,12 @@ __global__ __launch_bounds__(kBlock, 2) void recip_rows_wide_kernel(
     const double *cand_row = cand_sites + (size_t)(it.src < 0 ? 0 : it.src) * site_stride * 3;
     // ---- phase 1, once: entry (s, axis, k >= 0) at tab[s * ktot + kofs[axis] + k]; s = set * n1 + a with both sets (set 0 =
     //      the new sites, 1 = the old ones), s = a with one
-    for (int e = tid; e < nss * ktot; e += kBlock) {
+    // (matrix-unit form: the site-states padded to a multiple of four with entries of 0 and charge 0 -- its steps of four
+    //  site-states then need no mask)
+    const int nss_fill = MFMA ? ((nss + 3) & ~3) : nss;
+    for (int e = tid; e < nss_fill * ktot; e += kBlock) {
         const int s = e / ktot, kk = e - s * ktot;
+        if (MFMA && s >= nss) { tab[e] = make_double2(0.0, 0.0); continue; }
         const int set = two_sets ? (s >= n1 ? 1 : 0) : (use_old ? 1 : 0), a = s - (s >= n1 ? n1 : 0);
         double x = 0.0, y = 0.0, z = 0.0;
         if (used) {
@@ -2001,15 +2012,108 @@ __global__ __launch_bounds__(kBlock, 2) void recip_rows_wide_kernel(
         const int k0 = axis == 2 ? kofs2 : (axis == 1 ? kofs1 : 0);
         tab[e] = used ? phase_entry(atom_phase(bx, axis, x, y, z), kk - k0) : make_double2(0.0, 0.0);
     }
-    for (int s = tid; s < nss; s += kBlock) {
+    for (int s = tid; s < nss_fill; s += kBlock) {
+        if (MFMA && s >= nss) { sq[s] = 0.0; continue; }
         const int set = two_sets ? (s >= n1 ? 1 : 0) : (use_old ? 1 : 0), a = s - (s >= n1 ? n1 : 0);
         const double q = res_q[it.t * tp.max_atom + a];
-        sq[s] = set == 0 ? q : -q;                      // + for the new sites, - for the old ones (ewald_energy.f90:241-256)
+        sq[s] = (set == 0 ? q : -q) * (used ? 1.0 : 0.0);   // + for the new sites, - for the old ones (ewald_energy.f90:241-256)
+    }
+    // matrix-unit form: every row's {kx, ky, first task, first kz | tasks << 8} beside the tables, so that a tile's
+    // addresses cost one LDS read instead of a chain of three global loads per tile
+    [[maybe_unused]] int4 *rowmeta = reinterpret_cast<int4 *>(sq + nss_max);
+    if constexpr (MFMA) {
+        for (int rr = tid; rr < n_rows; rr += kBlock) {
+            const RecipRow r = rows[rr];
+            const int t0 = row_first[rr], t1 = row_first[rr + 1];
+            const int j0 = t1 > t0 ? (trj[t0] & 0xff) : 0;
+            rowmeta[rr] = make_int4(r.kx, r.ky, t0, j0 | ((t1 - t0) << 8));
+        }
     }
     __syncthreads();
     double2 *A = A_base + (size_t)it.replica * bx.n_slots;
     const double2 *zt = tab + kofs2;
     double acc = 0.0, acc0 = 0.0;
+    if constexpr (MFMA) {
+        typedef double double4v __attribute__((ext_vector_type(4)));
+        const int lane = tid & 63, wave = tid >> 6;
+        const int li = lane & 15, lk = lane >> 4;          // operand A: (kz li, site-state lk); B: (site-state lk, row li); D: (kz lk + 4 i, row li)
+        // kz columns in tiles of 16; a tile of rows takes as many as its longest row needs (kmax_z = 16: 17 columns, the 17th
+        // in the few rows around kx = ky = 0 only -- a second column tile for every tile of rows would double the work)
+        const int n_rt = (n_rows + 15) >> 4;
+        for (int rt = wave; rt < n_rt; rt += kWavesPerBlock) {
+            int zmax;
+            {
+                const int rowq = rt * 16 + li;
+                const int4 rq = rowmeta[rowq < n_rows ? rowq : n_rows - 1];
+                zmax = rowq < n_rows ? (rq.w & 0xff) + (rq.w >> 8) : 0;
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) zmax = max(zmax, __shfl_xor(zmax, off, 64));
+                zmax = __builtin_amdgcn_readfirstlane(zmax);
+            }
+            const int n_zt = (zmax + 15) >> 4;
+            for (int ztile = 0; ztile < n_zt; ++ztile) {
+            const int row = rt * 16 + li;
+            const bool rv = row < n_rows;
+            const int4 rm = rowmeta[rv ? row : n_rows - 1];
+            const RecipRow r{rm.x, rm.y};
+            // this lane's four tasks: kz = 16 ztile + lk + 4 i of its row, where the row has them
+            const int t0 = rm.z, t1 = rv ? rm.z + (rm.w >> 8) : rm.z;
+            const int j0 = rm.w & 0xff;
+            int tt[4], rjv[4];
+            double2 Apv[4], Amv[4], wv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kzz = ztile * 16 + lk + 4 * i;
+                const int t = t0 + (kzz - j0);
+                tt[i] = (kzz >= j0 && t < t1) ? t : -1;
+                const int tc = tt[i] >= 0 ? tt[i] : 0;
+                rjv[i] = trj[tc];
+                Apv[i] = A[2 * tc]; Amv[i] = A[2 * tc + 1];
+                wv[i] = COMMIT ? make_double2(0.0, 0.0) : tw[tc];
+            }
+            const int aky = r.ky < 0 ? -r.ky : r.ky;
+            const double ysign = r.ky < 0 ? -1.0 : 1.0;          // conjugate for -ky (times -1: exact)
+            // Branch-free steps: every address is valid -- the site-states are padded with zeros, a row beyond the last reads
+            // the last row's, a kz beyond the table's reads the neighbouring entries -- and what such lanes feed the matrix
+            // unit only reaches outputs no task owns (an output depends on its own kz's and its own row's operands alone).
+            const double2 *xp = tab + lk * ktot + r.kx, *yp = tab + lk * ktot + kofs1 + aky, *zp = zt + lk * ktot + ztile * 16 + li;
+            const double *qp = sq + lk;
+            double4v d_ac = {0.0, 0.0, 0.0, 0.0}, d_bd = d_ac, d_ad = d_ac, d_bc = d_ac;
+            double2 Xn = xp[0], Yn = yp[0], zn = zp[0];
+            double qn = qp[0];
+            for (int s0 = 0; s0 < nss_fill; s0 += 4) {
+                const double2 X = Xn, z = zn;
+                double2 Y = Yn;
+                const double q = qn;
+                const int sn = s0 + 4 < nss_fill ? s0 + 4 : s0;    // (the last step re-reads its own operands)
+                Xn = xp[sn * ktot]; Yn = yp[sn * ktot]; zn = zp[sn * ktot]; qn = qp[sn];
+                Y.y *= ysign;
+                double2 xy = cmul(X, Y);
+                xy.x *= q; xy.y *= q;
+                d_ac = __builtin_amdgcn_mfma_f64_16x16x4f64(z.x, xy.x, d_ac, 0, 0, 0);
+                d_bd = __builtin_amdgcn_mfma_f64_16x16x4f64(z.y, xy.y, d_bd, 0, 0, 0);
+                d_ad = __builtin_amdgcn_mfma_f64_16x16x4f64(z.y, xy.x, d_ad, 0, 0, 0);
+                d_bc = __builtin_amdgcn_mfma_f64_16x16x4f64(z.x, xy.y, d_bc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (tt[i] < 0) continue;
+                const int t = tt[i];
+                const double sac = d_ac[i], sbd = d_bd[i], sad = d_ad[i], sbc = d_bc[i];
+                const double2 Ap = Apv[i], Am = Amv[i], w = wv[i];
+                if (BOTH && !COMMIT) acc0 += fma(w.x, fma(Ap.x, Ap.x, Ap.y * Ap.y), w.y * fma(Am.x, Am.x, Am.y * Am.y));
+                const double npx = Ap.x + (sac - sbd), npy = Ap.y + (sad + sbc);
+                const double nmx = Am.x + (sac + sbd), nmy = Am.y + (sbc - sad);
+                if (COMMIT) {
+                    A[2 * t] = (rjv[i] & kTaskHasP) ? make_double2(npx, npy) : make_double2(0.0, 0.0);
+                    A[2 * t + 1] = (rjv[i] & kTaskHasM) ? make_double2(nmx, nmy) : make_double2(0.0, 0.0);
+                } else {
+                    acc += fma(w.x, fma(npx, npx, npy * npy), w.y * fma(nmx, nmx, nmy * nmy));   // ewald_energy.f90:259-266
+                }
+            }
+            }
+        }
+    } else
     for (int r0 = 0; r0 < n_rows; r0 += rows_per_tile) {
         const int r1 = min(n_rows, r0 + rows_per_tile);
         // ---- phase 2 for the rows of this tile: XY[row][s] = +-q X[kx] Y[ky]  (recip_rows_phase2's expression)

@@ -6,6 +6,8 @@ Tolerance: BASELINE.json north_star -- every energy component within 1e-10 kcal/
 (= 5.03e-8 K in the reference's internal unit) of the reference; components whose magnitude
 exceeds ~1e8 K (static self / intra totals) get 16 ulp instead (tests/util.py::tol_for).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -468,15 +470,22 @@ def test_maximum_molecule_count(refcpu_mod):
     eng.close()
 
 
-def test_wide_row_form_for_a_24_site_adsorbate(refcpu_mod):
+@pytest.mark.parametrize("form", ["matrix_unit", "vector"])
+def test_wide_row_form_for_a_24_site_adsorbate(refcpu_mod, form):
     """A 24-site rigid adsorbate: the row-form k sweep's XY table exceeds its 40 KiB budget, so the WIDE row form runs (the
-    phase tables of all 48 site-states in LDS, the rows a tile at a time: recip_rows_wide_kernel; until round 5 such a
-    molecule took the per-k kernel) -- no environment switch.  Trial energies, a committed move (A(k) and coordinates), an
-    insertion and a deletion against the oracle; tests/test_gpu_parity.py::test_per_k_reciprocal_kernel re-runs the file
-    with MGPU_RECIP_PER_K=1, which sends the same molecule through the per-k kernel."""
+    phase tables of all 48 site-states in LDS: recip_rows_wide_kernel; until round 5 such a molecule took the per-k kernel)
+    -- by default its matrix-unit form (tiles of 16 rows x 16 kz through v_mfma_f64_16x16x4_f64), with MGPU_RECIP_NO_MFMA=1
+    the vector form (the rows a tile at a time through an XY table).  Trial energies, a committed move (A(k) and
+    coordinates), an insertion and a deletion against the oracle; tests/test_gpu_parity.py::test_per_k_reciprocal_kernel
+    re-runs the file with MGPU_RECIP_PER_K=1, which sends the same molecule through the per-k kernel."""
     s = synth.rigid_adsorbate_box()
     n1 = int(s.topo.atoms_in_res[0])
-    eng = Engine.from_system(s, n_replicas=2, mol_capacity=[10])
+    if form == "vector":
+        os.environ["MGPU_RECIP_NO_MFMA"] = "1"
+    try:
+        eng = Engine.from_system(s, n_replicas=2, mol_capacity=[10])
+    finally:
+        os.environ.pop("MGPU_RECIP_NO_MFMA", None)
     kv = eng.kvectors()
     ktot = int(eng.kmax.sum()) + 3
     n_rows = len(set(zip(kv["kx"].tolist(), kv["ky"].tolist())))
@@ -526,6 +535,67 @@ def test_wide_row_form_for_a_24_site_adsorbate(refcpu_mod):
     o5, n5 = eng.gcmc_trial([0], [0], [-1], [MGPU_CREATION], csite[None], lane=0)
     close(o5[0], exp_o, "24-site creation old")
     close(n5[0], exp_n, "24-site creation new")
+    eng.close()
+
+
+@pytest.mark.parametrize("n_sites,tilt", [(6, None), (7, None), (23, None), (64, None), (7, (2.0, -1.5, 1.0)), (24, (2.0, -1.5, 1.0))])
+def test_molecules_of_6_to_64_sites(refcpu_mod, n_sites, tilt):
+    """Molecules of 6 .. 64 sites, orthorhombic and triclinic boxes, sites without charge and atom types without LJ among them:
+    the LDS-staged pair sweep (pair_sweep_kernel<0, ...>) with a last chunk of fewer sites, and the three reciprocal forms by
+    size -- row form (6, 7 sites), the matrix-unit wide row form (23, 24 sites: v_mfma_f64_16x16x4_f64 over tiles of 16 rows
+    x 16 kz, site-states padded to a multiple of four; triclinic too), per-k form with site tiles (64).  Trial moves, an
+    insertion and a deletion against the oracle (SingleMolPairwiseEnergy, src/pairwise_energy.f90:17-120;
+    ewald_energy.f90:232-272)."""
+    s = synth.large_adsorbate_box(n_sites=n_sites, n_mol=4, L=34.0, seed=31 + n_sites)
+    if tilt is not None:
+        L = float(s.box_matrix[0, 0])
+        s.box_matrix = np.array([[L, 0.0, 0.0], [tilt[0], L, 0.0], [tilt[1], tilt[2], L]])
+        frac = (s.com[0] - s.bounds_lo[None, :]) / L
+        s.com[0] = s.bounds_lo[None, :] + frac @ s.box_matrix.T
+    n1, cap = n_sites, 6
+    eng = Engine.from_system(s, n_replicas=2, mol_capacity=[cap])
+    P = refcpu_mod.RefCPU(s, mol_capacity=cap)
+    e_sys = P.system_energy()
+    for r in range(2):
+        eng.init_structure_factor(r, True)
+    P.init_amplitude(True)
+    P.set_energy_recip(e_sys["recip_coulomb"])
+    rng = np.random.default_rng(n_sites)
+    n = int(s.n_mol[0])
+    sites = np.zeros((n, n1, 3)); exp_old = np.zeros((n, 3)); exp_new = np.zeros((n, 3))
+    for m in range(n):
+        com, off = P.get_molecule(0, m)
+        P.save_fourier(0, m)
+        exp_old[m] = P.old_energy(0, m, 0)[:3]
+        sites[m] = P.apply_pbc(com + rng.uniform(-0.4, 0.4, 3))[None, :] + off @ P.rotation_matrix(1 + m % 3, 0.3).T
+        P.set_molecule(0, m, sites[m, 0], sites[m] - sites[m, 0][None, :])
+        exp_new[m] = P.new_energy(0, m, 0)[:3]
+        P.set_molecule(0, m, com, off)
+        P.restore_fourier(0, m)
+    idx = np.arange(n, dtype=np.int32)
+    old, new = eng.trial_energy_candidates(np.zeros(n, np.int32), np.zeros(n, np.int32), idx, sites)
+    close(old, exp_old, f"{n1}-site old")
+    close(new, exp_new, f"{n1}-site new")
+    # the stand-alone pair entry point takes the same kernels
+    lj, cc = eng.pair_energy_candidates(np.zeros(n, np.int32), np.zeros(n, np.int32), idx, sites)
+    assert np.array_equal(lj, new[:, 0]) and np.array_equal(cc, new[:, 1])
+    # an insertion beside molecule 0 (shells 2 A apart) and a deletion
+    rad = float(np.max(np.linalg.norm(s.offsets[0][0], axis=1)))
+    csite = P.get_molecule(0, 0)[0][None, :] + np.array([2.0 * rad + 2.0, 0.3, -0.2]) + s.offsets[0][1] @ P.rotation_matrix(2, 0.7).T
+    exp_o = P.old_energy(0, n, 1)[:5]
+    P.set_num_residues(0, n + 1)
+    P.save_fourier(0, n)
+    P.set_molecule(0, n, csite[0], csite - csite[0][None, :])
+    exp_n = P.new_energy(0, n, 1)[:5]
+    P.restore_fourier(0, n)
+    P.set_num_residues(0, n)
+    o5, n5 = eng.gcmc_trial([0], [0], [-1], [MGPU_CREATION], csite[None], lane=0)
+    close(o5[0], exp_o, f"{n1}-site creation old")
+    close(n5[0], exp_n, f"{n1}-site creation new")
+    P.save_fourier(0, 2)
+    exp_o = P.old_energy(0, 2, 2)[:5]
+    o5, n5 = eng.gcmc_trial([1], [0], [2], [MGPU_DELETION], np.zeros((1, n1, 3)), lane=1)
+    close(o5[0], exp_o, f"{n1}-site deletion old")
     eng.close()
 
 

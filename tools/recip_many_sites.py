@@ -49,8 +49,12 @@ def main():
         eng.commit_candidates(rep, tt, m, np.full(R, MGPU_MOVE, np.int32), sites, np.ones(R, np.int32))
         n_c, ms_c = eng.profile_get(_lib.KERNEL_COMMIT)
         nk = eng.nk
-        flop = 2.0 * 2 * n_sites * nk * 16        # two site sets, two complex products of 8 flops per site and k
-        print(f"sites {n_sites:4d}  Nk {nk:5d}  candidates {R}: k sweep {ms_k / max(1, n_k) * 1e3:9.1f} us  ({R * flop / (ms_k / max(1, n_k) * 1e-3) / 1e12:6.2f} TFLOP/s)"
+        # per-k form: two site sets, two complex products of 8 flops per site and k; row form (wide / matrix-unit kernels, the
+        # molecules whose tables fit LDS): 4 FMAs per site-state and TASK (a +-kz pair) -- the figure is the form's own count
+        wide = 2 * n_sites * (sum(int(x) for x in eng.kmax) + 3) * 16 <= 60 * 1024
+        flop = 2.0 * n_sites * (nk / 2.0) * 8 if wide else 2.0 * 2 * n_sites * nk * 16
+        print(f"sites {n_sites:4d}  Nk {nk:5d}  candidates {R}: k sweep {ms_k / max(1, n_k) * 1e3:9.1f} us  ({R * flop / (ms_k / max(1, n_k) * 1e-3) / 1e12:6.2f} TFLOP/s, "
+              f"{'row' if wide else 'per-k'} form count)"
               f"   commit {ms_c / max(1, n_c) * 1e3:9.1f} us   pair sweep {ms_p / max(1, n_p) * 1e3:9.1f} us", flush=True)
         eng.close()
 
