@@ -48,11 +48,14 @@ extern "C" {
  *                               centre, which the engine tracks on the host; both folds see the same raw separation
  *                               and return the same bits)
  *   MGPU_PAIR_FLAT=0 / 1        plane-by-plane (pair_sweep_kernel) / flat (pair_flat_kernel) register-site pair sweep
- *                               (default: flat for topologies with short planes -- every plane-major residue type has
- *                               at most 1024 molecule slots -- or a frozen framework, orthorhombic boxes)
+ *                               (default: flat for orthorhombic boxes with a frozen framework -- an inactive residue type
+ *                               of 64 sites or more -- and at most 64 planes; plane by plane otherwise)
  *   MGPU_NO_FROZEN_BATCH=1      framework boxes keep one wave per candidate (pair_flat_kernel) instead of 64 candidates
  *                               per wave against chunks of the framework (pair_frozen_kernel; default where exactly one
  *                               frozen residue type exists and it is identical in every replica)
+ *   MGPU_RECIP_NO_MFMA=1        molecules of a few dozen sites (wide row form of the k sweep): the vector form (rows a tile
+ *                               at a time through an XY table in LDS) instead of the matrix-unit form (tiles of 16 rows x
+ *                               16 kz through v_mfma_f64_16x16x4_f64; another order of the same sum over site-states)
  *   MGPU_TRI_FULL_SEARCH=1      triclinic boxes: always ComputeDistance's full 27-image search (default: for the reader's
  *                               lower-triangular cells the same minimum in eight evaluations, the full search only
  *                               where its certificate fails; bit-identical results)

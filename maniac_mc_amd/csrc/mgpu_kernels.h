@@ -589,7 +589,7 @@ __device__ __forceinline__ void pair_sweep_item(
                             }
                             for (int s = 0; s < ns; ++s) {
                                 const double qs = w_site[s * 4 + 3];
-                                const double2 pt = pair_tab[w_sty[s] * nt + tyj];
+                                const double2 pt = s_pair[w_sty[s] * nt + tyj];              // (the LDS copy: a global load here sat in the serial chain of every site-term)
                                 const bool do_c = qj_on && (fabs(qs) >= kErrorTol);   // energy_utils.f90:430
                                 const bool do_lj = pt.x != 0.0;                        // epsilon = 0 contributes 0
                                 if ((do_c || do_lj) && valid)

@@ -18,6 +18,9 @@ cp $src/bench_co2_isotherm_exchange_torch.json $dst/bench_co2_isotherm_exchange_
 for wl in spce_triclinic adsorbate24; do cp $src/bench_$wl.json $dst/bench_$wl.json; done
 cp $src/farm_window_speed.txt $dst/farm_window_speed.txt
 cp $src/recip_many_sites.txt $dst/recip_many_sites.txt
+cp $src/recip_many_sites_vector_form.txt $dst/recip_many_sites_vector_form.txt 2>/dev/null || true
+cp $src/farm_window_speed_co2.txt $dst/farm_window_speed_co2.txt 2>/dev/null || true
+cp $src/probe_mfma_f64.txt $dst/probe_mfma_f64.txt 2>/dev/null || true
 cp $src/host_team_matrix.txt $dst/host_team_matrix.txt 2>/dev/null || true
 cp $src/bench_driver_format.json $dst/bench_driver_format_steps20_warmup5.json
 cp $src/bench_driver_format_with_pmc.json $dst/bench_driver_format_steps20_warmup5_with_pmc.json 2>/dev/null || true

@@ -26,7 +26,7 @@ if [ "$part" = 1 ]; then
   python tools/bench_kernels.py --replicas 4096 --reps 5 --workload co2_gcmc --decide > $out/k_co2_gcmc_R4096_decide.json
   python bench.py --steps 20 --warmup 5 > $out/bench_driver_format.json 2> $out/bench_driver_format.err
   python bench.py --configs 0 --replicas-sweep "" > $out/bench_spce.json 2> $out/bench_spce.err
-  python bench.py --workload co2_gcmc > $out/bench_co2_gcmc.json 2> $out/bench_co2_gcmc.err
+  python bench.py --workload co2_gcmc --replicas-sweep 1,8,64,512,1024,4096 > $out/bench_co2_gcmc.json 2> $out/bench_co2_gcmc.err
   python bench.py --workload framework_water > $out/bench_framework_water.json 2> $out/bench_framework_water.err
   python bench.py --workload co2_isotherm > $out/bench_co2_isotherm.json 2> $out/bench_co2_isotherm.err
   python bench.py --workload co2_isotherm --exchange torch --no-cpu-baseline > $out/bench_co2_isotherm_exchange_torch.json 2> $out/bench_co2_isotherm_exchange_torch.err
@@ -34,7 +34,10 @@ if [ "$part" = 1 ]; then
   python bench.py --workload adsorbate24 > $out/bench_adsorbate24.json 2> $out/bench_adsorbate24.err
   # round 5: the few-chain regime (one launch per lane step) against the batched path, and the many-site reciprocal kernels
   python tools/farm_window_speed.py --replicas 1,8,64,512,1024 --modes batched,w1,w2,w3 --lanes 1,2 --seconds 0.5 --json $out/farm_window_speed.json > $out/farm_window_speed.txt 2>&1
+  python tools/farm_window_speed.py --workload co2_gcmc --replicas 1,8,64,512,1024,4096 --modes batched,w1,w3 --lanes 1,2 --drivers 1,2 --threads 6 --seconds 0.4 > $out/farm_window_speed_co2.txt 2>&1
   python tools/recip_many_sites.py > $out/recip_many_sites.txt 2>&1
+  MGPU_RECIP_NO_MFMA=1 python tools/recip_many_sites.py --sites 24 > $out/recip_many_sites_vector_form.txt 2>&1
+  hipcc -O3 --offload-arch=gfx950 -o /tmp/probe_mfma_f64 tools/probe_mfma_f64.hip > /dev/null 2>&1 && /tmp/probe_mfma_f64 > $out/probe_mfma_f64.txt 2>&1 || true
   python tools/host_team_matrix.py > $out/host_team_matrix.txt 2>&1 || true
 else
   bash tools/pmc_passes.sh $out/pmc r05 4096 1 spce > $out/pmc_spce.log 2>&1   # the default bench: 16384 chains on 4 lanes, engine nsplit 1
