@@ -365,7 +365,9 @@ def replicas_sweep(system, counts, device, host_threads, seconds, t_step, r_step
                            n_drivers=drivers, device_build=True, window=window, window_depth=3 if gc else 2, **kw)
         try:
             farm.run(20)
-            chunk = 50
+            # (a chunk ends with mgpu_synchronize, which drains the windows in flight and copies A(k) back to its primary buffer:
+            #  ~40 us that a real run pays once per block, so a window farm's chunk is a few thousand lock steps' worth of time)
+            chunk = (400 if R <= 64 else 200) if farm.window else 50
             farm.run(chunk)
             farm.eng.synchronize()
             steps = acc = 0

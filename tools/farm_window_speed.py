@@ -48,7 +48,7 @@ def main():
                                    window=window, window_depth=depth, **kw)
                 try:
                     farm.run(20)
-                    chunk = 50
+                    chunk = (400 if R <= 64 else 200) if window else 50       # (see bench.py replicas_sweep: a chunk ends with a synchronise)
                     farm.run(chunk)
                     farm.eng.synchronize()
                     steps = acc = 0
