@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmaniac_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["mgpu_engine.hip", "mgpu_launch.hip", "mgpu_lanes.hip", "mgpu_windows.hip", "mgpu_host_setup.cpp", "mgpu_comm.cpp"]
-HEADERS = ["mgpu_kernels.h", "mgpu_internal.h", "mgpu_engine.h"]
+HEADERS = ["mgpu_kernels.h", "mgpu_kernels_common.h", "mgpu_kernels_pair.h", "mgpu_kernels_recip.h", "mgpu_kernels_windows.h",
+           "mgpu_internal.h", "mgpu_engine.h"]
 
 MGPU_OK = 0
 ABI_VERSION = 2          # include/maniac_gpu.h MGPU_ABI_VERSION: the library must report exactly this

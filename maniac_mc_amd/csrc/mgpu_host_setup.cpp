@@ -355,7 +355,7 @@ int mgpu_ewald_setup(const double metrics[9], double *rc, double *tol, double *a
 }
 
 // Host evaluation of the Coulomb table the pair sweep reads from LDS (same rows and the same
-// index / Horner / FMA arithmetic as coul_lds() in mgpu_kernels.h), so its accuracy can be checked
+// index / Horner / FMA arithmetic as coul_lds() in mgpu_kernels_common.h), so its accuracy can be checked
 // without a GPU.  out[i] = erfc(alpha sqrt(r2[i])) / sqrt(r2[i]).
 int mgpu_coulomb_table_eval(double alpha, double r2_max, int n, const double *r2, double *out) {
     if (n < 0 || (n > 0 && (!r2 || !out))) return mgpu::set_error(MGPU_ERR_INVALID_ARG, "mgpu_coulomb_table_eval: bad argument");

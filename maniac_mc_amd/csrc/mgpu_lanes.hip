@@ -144,7 +144,7 @@ struct TrialBuild {
     double t_step, r_step;
 };
 // decide != nullptr: the acceptance test runs on the device behind the k sweep and accepted candidates are committed there
-// (DecideItem, mgpu_kernels.h); accept_u[n] = the test's uniform numbers, accept_pref[n] = its prefactors
+// (DecideItem, mgpu_kernels_recip.h); accept_u[n] = the test's uniform numbers, accept_pref[n] = its prefactors
 struct TrialDecide {
     const double *u, *pref;
     double temperature;

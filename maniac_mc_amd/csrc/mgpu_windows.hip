@@ -240,7 +240,7 @@ int mgpu_chain_window(mgpu_engine *e, int replica, int n, const int *t, const in
 
 
 // ---- farm windows ------------------------------------------------------------------------------
-// One launch per lane step of a farm of chains (farm_window_kernel, mgpu_kernels.h): the caller hands over, per chain, the
+// One launch per lane step of a farm of chains (farm_window_kernel, mgpu_kernels_windows.h): the caller hands over, per chain, the
 // move it selected and the uniform numbers of its construction and of its acceptance test; the launch evaluates,
 // decides and commits; the host collects energies and verdicts from pinned memory by polling per-chain tags.  Up to
 // kFarmDepth windows per lane may be in flight (a farm whose move selection does not depend on earlier outcomes -- NVT --

@@ -389,7 +389,7 @@ def test_per_k_reciprocal_kernel():
 
 
 def test_phase_factors_are_within_two_ulp():
-    """The device's own sin / cos of the phase tables (sincos_bounded, csrc/mgpu_kernels.h) against extended precision
+    """The device's own sin / cos of the phase tables (sincos_bounded, csrc/mgpu_kernels_recip.h) against extended precision
     on the rounded product k * theta (ComputePhaseFactors1D, ewald_phase.f90:100-109): every argument the tables can
     meet (|k| <= 255, theta = 2 pi * a fractional coordinate of a few box lengths), arguments next to the multiples of
     pi / 2 where the reduction cancels, zero, and far beyond the tables' range (|x| up to 2^29)."""
