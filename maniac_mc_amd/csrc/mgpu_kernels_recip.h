@@ -840,16 +840,19 @@ __global__ __launch_bounds__(kBlock, 2) void recip_rows_wide_kernel(
             }
             const int aky = r.ky < 0 ? -r.ky : r.ky;
             const double ysign = r.ky < 0 ? -1.0 : 1.0;          // conjugate for -ky (times -1: exact)
-            // Branch-free steps: every address is valid -- the site-states are padded with zeros, a row beyond the last reads
-            // the last row's, a kz beyond the table's reads the neighbouring entries -- and what such lanes feed the matrix
-            // unit only reaches outputs no task owns (an output depends on its own kz's and its own row's operands alone).
-            const double2 *xp = tab + lk * ktot + r.kx, *yp = tab + lk * ktot + kofs1 + aky, *zp = zt + lk * ktot + ztile * 16 + li;
+            // Branch-free steps, every address inside the tables, nothing undefined into the matrix unit: the site-states are
+            // padded with zeros, a row beyond the last reads the last row's (its outputs belong to no task), a kz beyond the
+            // table reads the last kz's entry and is cleared by an AND mask (a select would become a branch around the load).
+            const int kz_a = ztile * 16 + li, nkz = bx.kmax[2] + 1;
+            const unsigned zmask = kz_a < nkz ? 0xffffffffu : 0u;
+            auto keep = [&](double v) { return __hiloint2double(__double2hiint(v) & (int)zmask, __double2loint(v) & (int)zmask); };
+            const double2 *xp = tab + lk * ktot + r.kx, *yp = tab + lk * ktot + kofs1 + aky, *zp = zt + lk * ktot + min(kz_a, nkz - 1);
             const double *qp = sq + lk;
             double4v d_ac = {0.0, 0.0, 0.0, 0.0}, d_bd = d_ac, d_ad = d_ac, d_bc = d_ac;
             double2 Xn = xp[0], Yn = yp[0], zn = zp[0];
             double qn = qp[0];
             for (int s0 = 0; s0 < nss_fill; s0 += 4) {
-                const double2 X = Xn, z = zn;
+                const double2 X = Xn, z = make_double2(keep(zn.x), keep(zn.y));
                 double2 Y = Yn;
                 const double q = qn;
                 const int sn = s0 + 4 < nss_fill ? s0 + 4 : s0;    // (the last step re-reads its own operands)

@@ -233,7 +233,7 @@ bool recip_wide_mfma(const mgpu_engine *e, int n1_max) {
     if (e->recip_force_per_k || e->recip_no_mfma || e->n_rtasks <= 0 || !e->d_row_first || !e->rows_contiguous) return false;
     const int ktot = e->kmax[0] + e->kmax[1] + e->kmax[2] + 3;
     const size_t nss = ((size_t)2 * n1_max + 3) & ~(size_t)3;
-    return nss * ktot * sizeof(double2) + nss * sizeof(double) + (size_t)e->n_rrows * sizeof(int4) + 256 <= kRecipWideLdsBytes;
+    return nss * ktot * sizeof(double2) + nss * sizeof(double) + (size_t)e->n_rrows * sizeof(int4) <= kRecipWideLdsBytes;
 }
 
 // accept != nullptr (commit, row form only): d_items are the candidates of the lane's last trial and only
@@ -276,11 +276,10 @@ int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items
     const bool wide_mfma = wide_ok && recip_wide_mfma(e, n1_max);
     const int wide_rpt = wide_mfma ? 0 : (wide_ok ? recip_wide_rows_per_tile(e, n1_max) : 0);
     if (wide_mfma || wide_rpt > 0) {
-        // (matrix-unit form: the site-states padded to a multiple of four, and 256 B behind the tables for the reads of a kz tile's
-        //  unused columns)
+        // (matrix-unit form: the site-states padded to a multiple of four)
         const int ktot = e->kmax[0] + e->kmax[1] + e->kmax[2] + 3, nss_max = wide_mfma ? ((2 * n1_max + 3) & ~3) : 2 * n1_max;
         const size_t lds_w = (size_t)nss_max * ktot * sizeof(double2) + (size_t)wide_rpt * nss_max * sizeof(double2) + (size_t)nss_max * sizeof(double) +
-                             (wide_mfma ? (size_t)e->n_rrows * sizeof(int4) + 256 : 0);
+                             (wide_mfma ? (size_t)e->n_rrows * sizeof(int4) : 0);
 #define MGPU_LAUNCH_WIDE(COMMIT, BOTH, MF)                                                                           \
         hipExtLaunchKernelGGL((recip_rows_wide_kernel<COMMIT, BOTH, MF>), dim3(n_items), dim3(kBlock), lds_w, ln.stream, a, b, 0, e->tp, \
                               e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_trj, e->d_tw, e->d_rrows, e->d_row_first, e->n_rrows, wide_rpt, \

@@ -252,7 +252,8 @@ def test_farm_window_refusals():
     e.close()
 
 
-@pytest.mark.parametrize("case", ["spce_nvt", "spce_nvt_64", "mixture_nvt", "co2_gcmc", "framework_water_gcmc", "co2_gcmc_drivers"])
+@pytest.mark.parametrize("case", ["spce_nvt", "spce_nvt_64", "mixture_nvt", "co2_gcmc", "framework_water_gcmc", "co2_gcmc_drivers",
+                                  "mixture_gcmc", "spce_nvt_drivers"])
 def test_window_farm_is_the_batched_farm(case):
     """mfarm_configure(3): mc_farm.f90 sends ONE launch per lane step (mgpu_farm_window_submit) and follows the outcomes,
     checking every device decision against its own rule.  Same seeds, same chains: counters, counts, running energies,
@@ -272,6 +273,13 @@ def test_window_farm_is_the_batched_farm(case):
     elif case == "mixture_nvt":
         s, R, steps = synth.mixture_box(seed=4), 6, 60
         kw.update(translation_step=0.4, rotation_step=0.4)
+    elif case == "mixture_gcmc":                  # two active residue types, each with its own count, capacity and fugacity
+        s, R, steps = synth.mixture_box(seed=4), 10, 120
+        kw.update(translation_step=0.4, rotation_step=0.4, mol_capacity=[16, 11],
+                  gcmc=dict(p_translation=0.2, p_rotation=0.2, fugacity=np.array([14.0, 8.0]) / (18.0 * 21.0 * 24.0)))
+    elif case == "spce_nvt_drivers":              # four lanes, two driver threads
+        s, R, steps = synth.spce_box(6, seed=3), 22, 40
+        kw.update(translation_step=0.4, rotation_step=0.4, n_lanes=4, n_threads=2, n_drivers=2)
     elif case in ("co2_gcmc", "co2_gcmc_drivers"):
         s, R, steps = synth.co2_box(20, seed=13), 12, 150
         kw.update(translation_step=1.0, rotation_step=0.6, mol_capacity=[90],
