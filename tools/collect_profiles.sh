@@ -23,6 +23,7 @@ cp $src/farm_window_speed_co2.txt $dst/farm_window_speed_co2.txt 2>/dev/null || 
 cp $src/probe_mfma_f64.txt $dst/probe_mfma_f64.txt 2>/dev/null || true
 cp $src/host_team_matrix.txt $dst/host_team_matrix.txt 2>/dev/null || true
 cp $src/bench_driver_format.json $dst/bench_driver_format_steps20_warmup5.json
+cp $src/bench_driver_format_wall.txt $dst/bench_driver_format_wall.txt 2>/dev/null || true
 cp $src/bench_driver_format_with_pmc.json $dst/bench_driver_format_steps20_warmup5_with_pmc.json 2>/dev/null || true
 cp $src/chain_speed.txt $dst/chain_speed.txt
 cp $src/chain_speed_batched_calls.txt $dst/chain_speed_batched_calls.txt

@@ -24,7 +24,7 @@ if [ "$part" = 1 ]; then
   MGPU_PAIR_NSPLIT=1 python tools/bench_kernels.py --replicas 4096 --reps 5 --workload spce > $out/k_spce_R4096_nsplit1.json   # the default bench's launch shape
   for wl in spce framework_water; do python tools/bench_kernels.py --replicas 2048 --reps 5 --workload $wl --decide > $out/k_${wl}_R2048_decide.json; done
   python tools/bench_kernels.py --replicas 4096 --reps 5 --workload co2_gcmc --decide > $out/k_co2_gcmc_R4096_decide.json
-  python bench.py --steps 20 --warmup 5 > $out/bench_driver_format.json 2> $out/bench_driver_format.err
+  t0=$(date +%s); python bench.py --steps 20 --warmup 5 > $out/bench_driver_format.json 2> $out/bench_driver_format.err; echo "bench.py --steps 20 --warmup 5: $(( $(date +%s) - t0 )) s wall" > $out/bench_driver_format_wall.txt
   python bench.py --configs 0 --replicas-sweep "" > $out/bench_spce.json 2> $out/bench_spce.err
   python bench.py --workload co2_gcmc --replicas-sweep 1,8,64,512,1024,4096 > $out/bench_co2_gcmc.json 2> $out/bench_co2_gcmc.err
   python bench.py --workload framework_water > $out/bench_framework_water.json 2> $out/bench_framework_water.err
