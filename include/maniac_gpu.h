@@ -434,7 +434,9 @@ int mgpu_chain_get_timing(mgpu_engine *e, double us[15]);
  *               it runs -- slot int(u N) of N (nothing to do for a move or deletion of an empty type or an insertion into a
  *               full one: verdict 5), prefactor phi V / (N + 1) or N / (phi V) -- so that insertion / deletion farms, too,
  *               queue a window before they have seen the last (the type and the kind of move do not depend on N); the
- *               driver replays the same arithmetic with its own counts when it collects the window
+ *               driver replays the same arithmetic with its own counts when it collects the window (a by-count record of
+ *               a replica that waits for the driver's decision comes back 4 whatever its count says: the step it waits
+ *               for may change the count)
  * mgpu_farm_window_wait collects the lane's OLDEST window: old_energy / new_energy [n][5] as mgpu_gcmc_trial_wait fills
  * them, verdict[c] = 0 rejected, 1 accepted and committed, 2 UNDECIDED, 4 nothing done (the replica waits for the driver's
  * decision of an earlier step), 5 idle record.  Undecided: the draw lies within the engine's relative margin (16 ulp;
@@ -446,7 +448,8 @@ int mgpu_chain_get_timing(mgpu_engine *e, double us[15]);
  * submit (the engine validates slots against its molecule counts).  A(k): a farm window leaves a replica's current A(k) in
  * one of two buffers; every other entry point that touches A(k) copies it back first (mgpu_farm_window_flush does only
  * that).  mgpu_farm_window_capacity: chains per launch (0: the path does not apply -- triclinic box, per-k reciprocal
- * form, an active molecule of more than 5 sites) and windows per lane in flight. */
+ * form, an active molecule of more than 5 sites; otherwise min(4096, replicas)) and windows per lane in flight.  Lanes may be
+ * driven by different host threads (one thread per lane at a time), as the other per-lane entry points. */
 int mgpu_farm_window_capacity(const mgpu_engine *e, int *max_chains, int *max_in_flight);
 int mgpu_farm_window_submit(mgpu_engine *e, int lane, int n, const int *replica, const int *t, const int *m, const int *move,
                             const int *forced, const double *u5, const double *accept_u, const double *accept_pref,
