@@ -97,6 +97,7 @@ struct Lane {
     std::vector<int> ent_off, ent_stride, ent_ns;     // ... ent_ns[i] of them
     std::vector<char> ent_extra;          // entry i has an extra record (the framework part, pair_frozen_kernel) behind the energies
     DevBuf d_scratch;                     // chunk partials of pair_frozen_kernel
+    DevBuf d_recip_sums;                  // [item][task][4]: a task's sums between the site tiles of the matrix-unit row sweep
     DevBuf d_tickets;                     // its per-group tickets: zero between launches (the kernel leaves them so)
     const RecipItem *d_trial_items = nullptr;   // RecipItems of the last trial, resident while last_trial_n != 0
     const RecipItem *h_trial_items = nullptr;   // their host image in h_in (valid until the next trial_submit)
@@ -152,7 +153,7 @@ struct Lane {
         farm.release();
         if (commit_staged_ev) { (void)hipEventDestroy(commit_staged_ev); commit_staged_ev = nullptr; }
         d_items.release(); d_items2.release(); d_sites.release(); d_partials.release(); d_out.release();
-        d_scratch.release();
+        d_scratch.release(); d_recip_sums.release();
         d_tickets.release();
         h_in.release(); h_commit.release(); h_out.release();
     }
@@ -312,6 +313,7 @@ size_t recip_rows_lds_bytes(const mgpu_engine *e, int n1_max);
 bool recip_by_rows(const mgpu_engine *e, int n1_max);
 int recip_wide_rows_per_tile(const mgpu_engine *e, int n1_max);   // 0: the wide row form does not apply
 bool recip_wide_mfma(const mgpu_engine *e, int n1_max);
+int recip_wide_mfma_tile(const mgpu_engine *e, int n1_max);       // site-states per LDS tile (0: the matrix-unit form does not apply)
 int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items, int n1_max, int site_stride,
                  bool commit, double2 *A_base, double *d_u, double *d_u_old = nullptr, const AcceptBits *accept = nullptr,
                  const double *sites_override = nullptr, const DecideArgs *decide = nullptr);

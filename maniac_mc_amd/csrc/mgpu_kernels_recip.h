@@ -740,12 +740,13 @@ __global__ __launch_bounds__(kBlock, COMMIT ? MGPU_COMMIT_MINWAVES : MGPU_RECIP_
 // formed in registers from the 1-D tables (no XY table, no row tiles, no barrier after phase 1).  Needs every row's tasks
 // to be a run of consecutive kz (the engine checks: rows_contiguous).  A sum over site-states in the matrix unit's order:
 // the trial and the commit pass share it, so A + delta is the same in both.
-template <bool COMMIT, bool BOTH, bool MFMA = false>
+template <bool COMMIT, bool BOTH, bool MFMA = false, bool TILED = false>
 __global__ __launch_bounds__(kBlock, 2) void recip_rows_wide_kernel(
     Topo tp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
     const int *__restrict__ trj, const double2 *__restrict__ tw, const RecipRow *__restrict__ rows, const int *__restrict__ row_first,
     int n_rows, int rows_per_tile, int nss_max, double2 *__restrict__ A_base, const RecipItem *__restrict__ items,
-    const double *__restrict__ cand_sites, int site_stride, double *__restrict__ u_new, double *__restrict__ u_old) {
+    const double *__restrict__ cand_sites, int site_stride, double *__restrict__ u_new, double *__restrict__ u_old,
+    double *__restrict__ site_tile_sums, int n_tasks) {
     extern __shared__ double2 s_tab[];
     __shared__ double s_red[2 * kWavesPerBlock];
     const RecipItem it = items[blockIdx.x];
@@ -766,8 +767,21 @@ __global__ __launch_bounds__(kBlock, 2) void recip_rows_wide_kernel(
     // (matrix-unit form: the site-states padded to a multiple of four with entries of 0 and charge 0 -- its steps of four
     //  site-states then need no mask)
     const int nss_fill = MFMA ? ((nss + 3) & ~3) : nss;
-    for (int e = tid; e < nss_fill * ktot; e += kBlock) {
-        const int s = e / ktot, kk = e - s * ktot;
+    // Matrix-unit form, molecules of ANY size: the site-states pass through LDS in tiles of nss_max (a multiple of four; one
+    // tile where everything fits); the four sums of every task go from tile to tile through site_tile_sums[item][task][4]
+    // (written by the first tile, added to by the middle ones, read by the last, which finishes the task with A(k)); a task
+    // is always worked by the same lane, tile after tile.
+    // (TILED is a template flag so that the one-tile kernel keeps its 118 registers: with the carried sums compiled in it took 156)
+    const int tile_ss = MFMA ? nss_max : nss_fill, n_st = (MFMA && TILED) ? (nss_fill + tile_ss - 1) / tile_ss : 1;
+    [[maybe_unused]] int4 *rowmeta = reinterpret_cast<int4 *>(sq + nss_max);
+    double2 *A = A_base + (size_t)it.replica * bx.n_slots;
+    const double2 *zt = tab + kofs2;
+    double acc = 0.0, acc0 = 0.0;
+    for (int st = 0; st < n_st; ++st) {
+    const int ss0 = (MFMA && TILED) ? st * tile_ss : 0, ssn = (MFMA && TILED) ? min(tile_ss, nss_fill - ss0) : nss_fill;
+    if (st > 0) __syncthreads();                        // every wave has left the tables of the tile before
+    for (int e = tid; e < ssn * ktot; e += kBlock) {
+        const int sl = e / ktot, kk = e - sl * ktot, s = ss0 + sl;
         if (MFMA && s >= nss) { tab[e] = make_double2(0.0, 0.0); continue; }
         const int set = two_sets ? (s >= n1 ? 1 : 0) : (use_old ? 1 : 0), a = s - (s >= n1 ? n1 : 0);
         double x = 0.0, y = 0.0, z = 0.0;
@@ -779,27 +793,25 @@ __global__ __launch_bounds__(kBlock, 2) void recip_rows_wide_kernel(
         const int k0 = axis == 2 ? kofs2 : (axis == 1 ? kofs1 : 0);
         tab[e] = used ? phase_entry(atom_phase(bx, axis, x, y, z), kk - k0) : make_double2(0.0, 0.0);
     }
-    for (int s = tid; s < nss_fill; s += kBlock) {
-        if (MFMA && s >= nss) { sq[s] = 0.0; continue; }
+    for (int sl = tid; sl < ssn; sl += kBlock) {
+        const int s = ss0 + sl;
+        if (MFMA && s >= nss) { sq[sl] = 0.0; continue; }
         const int set = two_sets ? (s >= n1 ? 1 : 0) : (use_old ? 1 : 0), a = s - (s >= n1 ? n1 : 0);
         const double q = res_q[it.t * tp.max_atom + a];
-        sq[s] = (set == 0 ? q : -q) * (used ? 1.0 : 0.0);   // + for the new sites, - for the old ones (ewald_energy.f90:241-256)
+        sq[sl] = (set == 0 ? q : -q) * (used ? 1.0 : 0.0);   // + for the new sites, - for the old ones (ewald_energy.f90:241-256)
     }
     // matrix-unit form: every row's {kx, ky, first task, first kz | tasks << 8} beside the tables, so that a tile's
     // addresses cost one LDS read instead of a chain of three global loads per tile
-    [[maybe_unused]] int4 *rowmeta = reinterpret_cast<int4 *>(sq + nss_max);
     if constexpr (MFMA) {
-        for (int rr = tid; rr < n_rows; rr += kBlock) {
-            const RecipRow r = rows[rr];
-            const int t0 = row_first[rr], t1 = row_first[rr + 1];
-            const int j0 = t1 > t0 ? (trj[t0] & 0xff) : 0;
-            rowmeta[rr] = make_int4(r.kx, r.ky, t0, j0 | ((t1 - t0) << 8));
-        }
+        if (st == 0)
+            for (int rr = tid; rr < n_rows; rr += kBlock) {
+                const RecipRow r = rows[rr];
+                const int t0 = row_first[rr], t1 = row_first[rr + 1];
+                const int j0 = t1 > t0 ? (trj[t0] & 0xff) : 0;
+                rowmeta[rr] = make_int4(r.kx, r.ky, t0, j0 | ((t1 - t0) << 8));
+            }
     }
     __syncthreads();
-    double2 *A = A_base + (size_t)it.replica * bx.n_slots;
-    const double2 *zt = tab + kofs2;
-    double acc = 0.0, acc0 = 0.0;
     if constexpr (MFMA) {
         typedef double double4v __attribute__((ext_vector_type(4)));
         const int lane = tid & 63, wave = tid >> 6;
@@ -826,6 +838,8 @@ __global__ __launch_bounds__(kBlock, 2) void recip_rows_wide_kernel(
             // this lane's four tasks: kz = 16 ztile + lk + 4 i of its row, where the row has them
             const int t0 = rm.z, t1 = rv ? rm.z + (rm.w >> 8) : rm.z;
             const int j0 = rm.w & 0xff;
+            const bool last_st = !TILED || st == n_st - 1;
+            [[maybe_unused]] double *sums = site_tile_sums + (size_t)blockIdx.x * n_tasks * 4;
             int tt[4], rjv[4];
             double2 Apv[4], Amv[4], wv[4];
 #pragma unroll
@@ -834,9 +848,11 @@ __global__ __launch_bounds__(kBlock, 2) void recip_rows_wide_kernel(
                 const int t = t0 + (kzz - j0);
                 tt[i] = (kzz >= j0 && t < t1) ? t : -1;
                 const int tc = tt[i] >= 0 ? tt[i] : 0;
-                rjv[i] = trj[tc];
-                Apv[i] = A[2 * tc]; Amv[i] = A[2 * tc + 1];
-                wv[i] = COMMIT ? make_double2(0.0, 0.0) : tw[tc];
+                if (last_st) {                                          // (uniform: the last tile of sites finishes the tasks)
+                    rjv[i] = trj[tc];
+                    Apv[i] = A[2 * tc]; Amv[i] = A[2 * tc + 1];
+                    wv[i] = COMMIT ? make_double2(0.0, 0.0) : tw[tc];
+                }
             }
             const int aky = r.ky < 0 ? -r.ky : r.ky;
             const double ysign = r.ky < 0 ? -1.0 : 1.0;          // conjugate for -ky (times -1: exact)
@@ -851,11 +867,11 @@ __global__ __launch_bounds__(kBlock, 2) void recip_rows_wide_kernel(
             double4v d_ac = {0.0, 0.0, 0.0, 0.0}, d_bd = d_ac, d_ad = d_ac, d_bc = d_ac;
             double2 Xn = xp[0], Yn = yp[0], zn = zp[0];
             double qn = qp[0];
-            for (int s0 = 0; s0 < nss_fill; s0 += 4) {
+            for (int s0 = 0; s0 < ssn; s0 += 4) {
                 const double2 X = Xn, z = make_double2(keep(zn.x), keep(zn.y));
                 double2 Y = Yn;
                 const double q = qn;
-                const int sn = s0 + 4 < nss_fill ? s0 + 4 : s0;    // (the last step re-reads its own operands)
+                const int sn = s0 + 4 < ssn ? s0 + 4 : s0;         // (the last step re-reads its own operands)
                 Xn = xp[sn * ktot]; Yn = yp[sn * ktot]; zn = zp[sn * ktot]; qn = qp[sn];
                 Y.y *= ysign;
                 double2 xy = cmul(X, Y);
@@ -869,7 +885,16 @@ __global__ __launch_bounds__(kBlock, 2) void recip_rows_wide_kernel(
             for (int i = 0; i < 4; ++i) {
                 if (tt[i] < 0) continue;
                 const int t = tt[i];
-                const double sac = d_ac[i], sbd = d_bd[i], sad = d_ad[i], sbc = d_bc[i];
+                double sac = d_ac[i], sbd = d_bd[i], sad = d_ad[i], sbc = d_bc[i];
+                if constexpr (TILED) {
+                    // the sums of the tiles before, in tile order (this lane's own earlier stores)
+                    double2 *sm = reinterpret_cast<double2 *>(sums + (size_t)t * 4);
+                    if (st > 0) {
+                        const double2 p0 = sm[0], p1 = sm[1];
+                        sac = p0.x + sac; sbd = p0.y + sbd; sad = p1.x + sad; sbc = p1.y + sbc;
+                    }
+                    if (!last_st) { sm[0] = make_double2(sac, sbd); sm[1] = make_double2(sad, sbc); continue; }
+                }
                 const double2 Ap = Apv[i], Am = Amv[i], w = wv[i];
                 if (BOTH && !COMMIT) acc0 += fma(w.x, fma(Ap.x, Ap.x, Ap.y * Ap.y), w.y * fma(Am.x, Am.x, Am.y * Am.y));
                 const double npx = Ap.x + (sac - sbd), npy = Ap.y + (sad + sbc);
@@ -883,7 +908,9 @@ __global__ __launch_bounds__(kBlock, 2) void recip_rows_wide_kernel(
             }
             }
         }
-    } else
+    }
+    }                                                    // site tiles
+    if constexpr (!MFMA)
     for (int r0 = 0; r0 < n_rows; r0 += rows_per_tile) {
         const int r1 = min(n_rows, r0 + rows_per_tile);
         // ---- phase 2 for the rows of this tile: XY[row][s] = +-q X[kx] Y[ky]  (recip_rows_phase2's expression)

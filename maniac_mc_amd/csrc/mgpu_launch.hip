@@ -227,14 +227,22 @@ int recip_wide_rows_per_tile(const mgpu_engine *e, int n1_max) {
     return rpt >= 8 ? std::min(rpt, e->n_rrows) : 0;
 }
 
-// The matrix-unit form of the wide row sweep (recip_rows_wide_kernel<..., MFMA>): only the 1-D phase tables in LDS, so
-// molecules up to kRecipWideLdsBytes of tables (~40 sites for a move at kmax 14).
-bool recip_wide_mfma(const mgpu_engine *e, int n1_max) {
-    if (e->recip_force_per_k || e->recip_no_mfma || e->n_rtasks <= 0 || !e->d_row_first || !e->rows_contiguous) return false;
+// The matrix-unit form of the wide row sweep (recip_rows_wide_kernel<..., MFMA>): only the 1-D phase tables of a TILE of
+// site-states in LDS.  Site-states per tile (a multiple of four; 0: the form does not apply): the fewest tiles of at most
+// kRecipWideLdsBytes each, balanced -- one tile for a molecule of a few dozen sites; a molecule of any size otherwise, the four
+// sums of a task carried from tile to tile.  (Measured, 1024 candidates of 128 / 300 sites: tiles of 52-72 KB 147 / 456-466 us,
+// of 100-144 KB -- one workgroup per CU, opted in with hipFuncAttributeMaxDynamicSharedMemorySize -- 148-184 / 613-623 us.)
+int recip_wide_mfma_tile(const mgpu_engine *e, int n1_max) {
+    if (e->recip_force_per_k || e->recip_no_mfma || e->n_rtasks <= 0 || !e->d_row_first || !e->rows_contiguous) return 0;
     const int ktot = e->kmax[0] + e->kmax[1] + e->kmax[2] + 3;
     const size_t nss = ((size_t)2 * n1_max + 3) & ~(size_t)3;
-    return nss * ktot * sizeof(double2) + nss * sizeof(double) + (size_t)e->n_rrows * sizeof(int4) <= kRecipWideLdsBytes;
+    const size_t per_ss = (size_t)ktot * sizeof(double2) + sizeof(double), fixed = (size_t)e->n_rrows * sizeof(int4);
+    if (fixed + 4 * per_ss > kRecipWideLdsBytes) return 0;
+    const size_t fit = ((kRecipWideLdsBytes - fixed) / per_ss) & ~(size_t)3;
+    const size_t n_tiles = (nss + fit - 1) / fit;
+    return (int)((((nss + n_tiles - 1) / n_tiles) + 3) & ~(size_t)3);
 }
+bool recip_wide_mfma(const mgpu_engine *e, int n1_max) { return recip_wide_mfma_tile(e, n1_max) > 0; }
 
 // accept != nullptr (commit, row form only): d_items are the candidates of the lane's last trial and only
 // those whose bit is set are applied
@@ -276,14 +284,24 @@ int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items
     const bool wide_mfma = wide_ok && recip_wide_mfma(e, n1_max);
     const int wide_rpt = wide_mfma ? 0 : (wide_ok ? recip_wide_rows_per_tile(e, n1_max) : 0);
     if (wide_mfma || wide_rpt > 0) {
-        // (matrix-unit form: the site-states padded to a multiple of four)
-        const int ktot = e->kmax[0] + e->kmax[1] + e->kmax[2] + 3, nss_max = wide_mfma ? ((2 * n1_max + 3) & ~3) : 2 * n1_max;
+        // (matrix-unit form: nss_max = the site-states of one LDS tile, a multiple of four)
+        const int ktot = e->kmax[0] + e->kmax[1] + e->kmax[2] + 3, nss_max = wide_mfma ? recip_wide_mfma_tile(e, n1_max) : 2 * n1_max;
         const size_t lds_w = (size_t)nss_max * ktot * sizeof(double2) + (size_t)wide_rpt * nss_max * sizeof(double2) + (size_t)nss_max * sizeof(double) +
                              (wide_mfma ? (size_t)e->n_rrows * sizeof(int4) : 0);
+        // more than one tile of site-states: the tasks' four sums travel through a per-lane block [item][task][4]
+        double *tile_sums = nullptr;
+        if (wide_mfma && nss_max < ((2 * n1_max + 3) & ~3)) {
+            if ((rc = ln.d_recip_sums.reserve((size_t)n_items * e->n_rtasks * 4 * sizeof(double)))) return rc;
+            tile_sums = (double *)ln.d_recip_sums.p;
+        }
+#define MGPU_LAUNCH_WIDE_1(COMMIT, BOTH, MF, TI)                                                                     \
+        do {                                                                                                         \
+            hipExtLaunchKernelGGL((recip_rows_wide_kernel<COMMIT, BOTH, MF, TI>), dim3(n_items), dim3(kBlock), lds_w, ln.stream, a, b, 0, e->tp, \
+                                  e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_trj, e->d_tw, e->d_rrows, e->d_row_first, e->n_rrows, wide_rpt, \
+                                  nss_max, A_base, d_items, d_cand, site_stride, d_u, d_u_old, tile_sums, e->n_rtasks);     \
+        } while (0)
 #define MGPU_LAUNCH_WIDE(COMMIT, BOTH, MF)                                                                           \
-        hipExtLaunchKernelGGL((recip_rows_wide_kernel<COMMIT, BOTH, MF>), dim3(n_items), dim3(kBlock), lds_w, ln.stream, a, b, 0, e->tp, \
-                              e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_trj, e->d_tw, e->d_rrows, e->d_row_first, e->n_rrows, wide_rpt, \
-                              nss_max, A_base, d_items, d_cand, site_stride, d_u, d_u_old)
+        do { if (MF && tile_sums) MGPU_LAUNCH_WIDE_1(COMMIT, BOTH, MF, true); else MGPU_LAUNCH_WIDE_1(COMMIT, BOTH, MF, false); } while (0)
         if (wide_mfma) {
             if (commit) MGPU_LAUNCH_WIDE(true, false, true);
             else if (d_u_old) MGPU_LAUNCH_WIDE(false, true, true);
@@ -294,6 +312,7 @@ int launch_recip(mgpu_engine *e, Lane &ln, const RecipItem *d_items, int n_items
             else MGPU_LAUNCH_WIDE(false, false, false);
         }
 #undef MGPU_LAUNCH_WIDE
+#undef MGPU_LAUNCH_WIDE_1
     } else if (decide)
         hipExtLaunchKernelGGL((recip_rows_kernel<false, true, true>), dim3(n_items), dim3(kBlock), lds, ln.stream, a, b, 0, e->tp,
                               e->bx, e->d_pos, e->d_nmol, e->d_res_q, e->d_trj, e->d_tw, e->n_rtasks, e->d_rrows, e->n_rrows, A_base,

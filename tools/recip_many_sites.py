@@ -49,9 +49,9 @@ def main():
         eng.commit_candidates(rep, tt, m, np.full(R, MGPU_MOVE, np.int32), sites, np.ones(R, np.int32))
         n_c, ms_c = eng.profile_get(_lib.KERNEL_COMMIT)
         nk = eng.nk
-        # per-k form: two site sets, two complex products of 8 flops per site and k; row form (wide / matrix-unit kernels, the
-        # molecules whose tables fit LDS): 4 FMAs per site-state and TASK (a +-kz pair) -- the figure is the form's own count
-        wide = 2 * n_sites * (sum(int(x) for x in eng.kmax) + 3) * 16 <= 60 * 1024
+        # row form (narrow / wide / matrix-unit kernels: every molecule unless MGPU_RECIP_PER_K is set): 4 FMAs per site-state and
+        # TASK (a +-kz pair); per-k form: two site sets, two complex products of 8 flops per site and k -- the form's own count
+        wide = os.environ.get("MGPU_RECIP_PER_K") is None
         flop = 2.0 * n_sites * (nk / 2.0) * 8 if wide else 2.0 * 2 * n_sites * nk * 16
         print(f"sites {n_sites:4d}  Nk {nk:5d}  candidates {R}: k sweep {ms_k / max(1, n_k) * 1e3:9.1f} us  ({R * flop / (ms_k / max(1, n_k) * 1e-3) / 1e12:6.2f} TFLOP/s, "
               f"{'row' if wide else 'per-k'} form count)"
