@@ -375,14 +375,17 @@ def test_edge_cases_and_errors():
 def test_per_k_reciprocal_kernel():
     """The per-k form of the reciprocal update (fallback for molecules whose XY table exceeds the LDS
     budget of the row form) is selected once per process by MGPU_RECIP_PER_K: re-run the golden-vector
-    test of two systems (moves, creation, deletion, commits) in a child process with the variable set."""
+    test of two systems (moves, creation, deletion, commits) in a child process with the variable set -- and the 24-, 128-
+    and 300-site adsorbates, whose sites the per-k kernel passes through LDS in tiles (by default they take the matrix-unit
+    row sweep)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MGPU_RECIP_PER_K="1")
     p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-q", "-x", "-m", "gpu", "-k",
-                        "(test_engine_vs_golden and (co2_20 or mixture)) or test_wide_row_form_for_a_24_site_adsorbate"],
+                        "(test_engine_vs_golden and (co2_20 or mixture)) or test_wide_row_form_for_a_24_site_adsorbate or "
+                        "test_large_adsorbate_moves_inserts_and_deletes"],
                        capture_output=True, text=True, env=env,
                        cwd=root, timeout=900)
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
@@ -601,9 +604,10 @@ def test_molecules_of_6_to_64_sites(refcpu_mod, n_sites, tilt):
 
 @pytest.mark.parametrize("n_sites", [128, 300])
 def test_large_adsorbate_moves_inserts_and_deletes(refcpu_mod, n_sites):
-    """A rigid adsorbate of 128 / 300 sites -- two table sets of 66-158 KiB, beyond any LDS budget: the per-k kernel passes
-    the sites through LDS in tiles (delta(k) in registers across the tiles) and the intra-molecular sum runs a wave per
-    molecule.  The reference sizes its tables by max_atom_in_residue (src/prepare_utils.f90:233-235) and moves, inserts and
+    """A rigid adsorbate of 128 / 300 sites -- two table sets of 66-158 KiB, beyond any LDS budget: the matrix-unit row sweep
+    passes the site-states through LDS in tiles (a task's four sums carried from tile to tile; under MGPU_RECIP_PER_K=1, in
+    test_per_k_reciprocal_kernel's child run, the per-k kernel with its own site tiles) and the intra-molecular sum runs a
+    wave per molecule.  The reference sizes its tables by max_atom_in_residue (src/prepare_utils.f90:233-235) and moves, inserts and
     deletes such a residue like any other (src/ewald_phase.f90:383-420, src/ewald_energy.f90:232-256, :371-411): trial
     energies, a committed move, an insertion and a deletion (energies, A(k), coordinates after each commit) vs the oracle."""
     s = synth.large_adsorbate_box(n_sites=n_sites, n_mol=3, L=44.0 if n_sites > 128 else 36.0)
