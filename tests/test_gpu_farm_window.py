@@ -352,3 +352,15 @@ def test_window_farm_with_every_step_left_to_the_driver(gcmc):
         assert np.array_equal(a.eng.structure_factor(r), b.eng.structure_factor(r)), r
         assert np.array_equal(a.eng.get_molecules(r, 0), b.eng.get_molecules(r, 0))
     a.close(); b.close()
+
+
+def test_randomised_window_farms_are_the_batched_farms():
+    """tools/window_farm_stress.py: 30 random combinations of box (SPC/E, CO2 insertion / deletion, two active types with and without
+    insertion / deletion, framework + water), chain count, lanes, driver threads, windows in flight, undecided margin and run length;
+    every window farm must leave counters, counts, energies, coordinates and A(k) of the batched farm, bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "window_farm_stress.py"), "--cases", "30", "--seed", "3"],
+                       capture_output=True, text=True, cwd=root, timeout=900)
+    assert p.returncode == 0 and "30 cases, 0 different" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
