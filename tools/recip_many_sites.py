@@ -24,7 +24,7 @@ def main():
     args = ap.parse_args()
     for n_sites in [int(x) for x in args.sites.split(",")]:
         if n_sites <= 24:
-            s = synth.rigid_adsorbate_box(n_mol=64, L=60.0, seed=17)
+            s = synth.rigid_adsorbate_box(n_mol=64, n_sites=n_sites, L=60.0, seed=17)
         else:
             s = synth.large_adsorbate_box(n_sites=n_sites, n_mol=3, L=44.0 if n_sites > 128 else 36.0)
         R = args.replicas
