@@ -388,7 +388,7 @@ int mgpu_replica_set_num_molecules(mgpu_engine *e, int replica, int t, int n_mol
  *               The device's exp (OCML) and the host's (glibc) may differ in the last bits there; the device stops at
  *               such a step -- nothing at or after it is committed -- and the host decides it with its own exp from the
  *               energies returned.  Every decision the device takes is therefore the host's decision.
- * mgpu_chain_window_capacity: the largest n (0: the one-launch path does not apply -- triclinic box, per-k reciprocal
+ * mgpu_chain_window_capacity: the largest n (0: the one-launch path does not apply -- per-k reciprocal
  * form, active molecules of more than 5 sites -- use mgpu_gcmc_trial_submit / wait).  Lane 0's stream carries the launch:
  * no trial may be in flight on lane 0. */
 int mgpu_chain_window_capacity(const mgpu_engine *e, int *max_candidates);

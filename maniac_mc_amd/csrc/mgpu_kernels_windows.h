@@ -69,7 +69,10 @@ static_assert(sizeof(BoxDev) + sizeof(ChainArgs) + 160 <= 4096, "a window must f
 
 // (The topology comes through a pointer: a by-value Topo indexed by a residue type that is itself loaded -- g.t[c] -- makes
 //  the compiler copy all 664 bytes of it into every lane's scratch at kernel start: measured 4 us per window.)
-template <bool FLAT, bool FASTW>
+// TRI: triclinic box -- the pair role runs the register-site sweeps with ComputeDistance's image search (the batched path's
+// kernels for such boxes: the same sums); everything else of a window is the same (the phase tables take the box's reciprocal
+// matrix either way).
+template <bool FLAT, bool FASTW, bool TRI = false>
 __global__ __launch_bounds__(kChainBlock, 1) void chain_window_kernel(
     const Topo *__restrict__ tpp, BoxDev bx, double *__restrict__ pos, int *__restrict__ nmol, const double *__restrict__ res_q,
     const int *__restrict__ res_atype, const double2 *__restrict__ pair_tab, const char *__restrict__ coul_tab_g,
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(kChainBlock, 1) void chain_window_kernel(
                     pair_flat_item<NS, false, FASTW, true>(tp, bx, pos, nmol, res_q, res_atype, s_dyn, s_pair, s_grp,         \
                                                      s_plane + wave * kFlatMaxPlanes, it, cand_sites, kMaxFusedSitesWide, split, g.nsplit, lane, 0, g.partials, w); \
                 else                                                                                                     \
-                    pair_sweep_item<NS, false, false, false, FASTW, true>(tp, bx, pos, nmol, res_q, res_atype, pair_tab, s_dyn, s_pair, nullptr, \
+                    pair_sweep_item<NS, false, TRI, false, FASTW, true>(tp, bx, pos, nmol, res_q, res_atype, pair_tab, s_dyn, s_pair, nullptr, \
                                                                     nullptr, it, cand_sites, kMaxFusedSitesWide, split, g.nsplit, lane, g.partials, w);   \
             } while (0)
             switch (n1) {

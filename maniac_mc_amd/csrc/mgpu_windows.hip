@@ -41,10 +41,9 @@ extern "C" {
 
 // ---- single-chain windows --------------------------------------------------------------------
 
-// largest window the engine accepts, 0 where the one-launch path does not apply (triclinic box, molecules of more than
-// kMaxFusedSitesWide sites among the active types, per-k reciprocal form)
+// largest window the engine accepts, 0 where the one-launch path does not apply (molecules of more than kMaxFusedSitesWide sites
+// among the active types, per-k reciprocal form)
 static int chain_max_candidates(const mgpu_engine *e) {
-    if (e->bx.triclinic) return 0;
     int n1_max = 1;
     for (int t = 0; t < e->tp.n_res; ++t) {
         if (!e->is_active[t]) continue;
@@ -197,7 +196,11 @@ int mgpu_chain_window(mgpu_engine *e, int replica, int n, const int *t, const in
     hipLaunchKernelGGL((chain_window_kernel<FL, FW>), dim3(grid), dim3(kChainBlock), lds, ln.stream, d_topo, e->bx, e->d_pos, e->d_nmol, \
                        e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab, e->d_trj, e->d_tw, e->n_rtasks, e->d_rrows, e->n_rrows, \
                        e->d_A, g)
-    if (e->pair_flat) { if (ff) MGPU_LAUNCH_CHAIN(true, true); else MGPU_LAUNCH_CHAIN(true, false); }
+    if (e->bx.triclinic)
+        hipLaunchKernelGGL((chain_window_kernel<false, false, true>), dim3(grid), dim3(kChainBlock), lds, ln.stream, d_topo, e->bx, e->d_pos,
+                           e->d_nmol, e->d_res_q, e->d_res_atype, e->d_pair_tab, e->d_coul_tab, e->d_trj, e->d_tw, e->n_rtasks, e->d_rrows,
+                           e->n_rrows, e->d_A, g);
+    else if (e->pair_flat) { if (ff) MGPU_LAUNCH_CHAIN(true, true); else MGPU_LAUNCH_CHAIN(true, false); }
     else { if (ff) MGPU_LAUNCH_CHAIN(false, true); else MGPU_LAUNCH_CHAIN(false, false); }
 #undef MGPU_LAUNCH_CHAIN
     HIP_TRY(hipGetLastError());

@@ -62,11 +62,15 @@ def _same_state(a, b, n_res):
     assert np.array_equal(a.structure_factor(0), b.structure_factor(0))
 
 
-@pytest.mark.parametrize("name", ["spce216", "mixture", "framework_small"])
+@pytest.mark.parametrize("name", ["spce216", "mixture", "framework_small", "mixture_triclinic"])
 def test_window_of_moves_is_the_batched_path(name):
     """Several windows in a row: energies bitwise those of the batched path (same kernels' pieces, same nsplit), the
-    device's verdict = the rule applied in order with numpy's exp, the committed state bitwise the batched commit's."""
-    _, s = golden_system(name)
+    device's verdict = the rule applied in order with numpy's exp, the committed state bitwise the batched commit's.
+    Triclinic boxes too (round 5: the window's pair role runs the register-site sweeps with ComputeDistance's image search)."""
+    if name == "mixture_triclinic":
+        s = synth.mixture_box(tilt=(1.5, -0.8, 0.6))
+    else:
+        _, s = golden_system(name)
     A, B = _twin(s)
     assert A.chain_window_capacity() >= 8
     rng = np.random.default_rng(5)
@@ -238,9 +242,9 @@ def test_steps_too_close_to_call_are_left_to_the_host():
 
 
 def test_capacity_is_zero_where_the_path_does_not_apply():
-    s = synth.mixture_box(tilt=(1.5, -0.8, 0.6))          # triclinic
+    s = synth.mixture_box(tilt=(1.5, -0.8, 0.6))          # triclinic: single-chain windows yes, farm windows (device-built moves) no
     e = Engine.from_system(s, n_replicas=1)
-    assert e.chain_window_capacity() == 0
+    assert e.chain_window_capacity() > 0 and e.farm_window_capacity()[0] == 0
     e.close()
     s = synth.rigid_adsorbate_box()                        # a 24-site active molecule
     e = Engine.from_system(s, n_replicas=1)

@@ -40,6 +40,16 @@ def main():
     files = io_maniac.write_input_files(s, tmp + "/spce_in", nb_block=2, nb_step=100, translation_step=0.3, rotation_step_angle=0.3,
                                         translation_proba=0.5, rotation_proba=0.5, masses=[15.9994, 1.008], atom_names=["OW", "HW"])
     cases.append(("spce_10125_nvt", list(files), dict(seed=5)))
+    # the same box sheared (bench.py's spce_triclinic workload): single-chain windows in a triclinic cell (round 5)
+    import numpy as np
+    st = synth.spce_box(15)
+    L = float(st.box_matrix[0, 0])
+    st.box_matrix = np.array([[L, 0.0, 0.0], [3.0, L, 0.0], [-2.0, 1.5, L]])
+    frac = (st.com[0] - st.bounds_lo[None, :]) / L
+    st.com[0] = st.bounds_lo[None, :] + frac @ st.box_matrix.T
+    files_t = io_maniac.write_input_files(st, tmp + "/spce_tri_in", nb_block=2, nb_step=100, translation_step=0.3, rotation_step_angle=0.3,
+                                          translation_proba=0.5, rotation_proba=0.5, masses=[15.9994, 1.008], atom_names=["OW", "HW"])
+    cases.append(("spce_10125_triclinic_nvt", list(files_t), dict(seed=5)))
     want = a.cases.split(",")
     for name, files, kw in cases:
         if name not in want:
