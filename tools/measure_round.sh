@@ -12,8 +12,8 @@ sha256sum maniac_mc_amd/libmaniac_hip.so > $out/lib_sha256.txt
 if [ "$part" = 1 ]; then
   python -m pytest tests -m gpu -x -q > $out/pytest.log 2>&1 || { tail -80 $out/pytest.log; exit 1; }
   tail -3 $out/pytest.log
-  python tools/chain_speed.py > $out/chain_speed.txt 2>&1
-  python tools/chain_speed.py --chain-windows 0 --ks 1,8 > $out/chain_speed_batched_calls.txt 2>&1
+  python tools/chain_speed.py --cases co2_gcmc,framework_water_gcmc,spce_10125_nvt,spce_10125_triclinic_nvt > $out/chain_speed.txt 2>&1
+  python tools/chain_speed.py --chain-windows 0 --ks 1,8 --cases co2_gcmc,framework_water_gcmc,spce_10125_nvt,spce_10125_triclinic_nvt > $out/chain_speed_batched_calls.txt 2>&1
   python tools/chain_stages.py --ks 1,4 > $out/chain_stages.md 2>&1
   bash tools/trace_chain.sh $out/trace_window 1 4 > $out/trace.log 2>&1
   # the batched-call path (round 3's single-chain loop) under the same tracer, for the before / after table
@@ -36,6 +36,8 @@ if [ "$part" = 1 ]; then
   python tools/farm_window_speed.py --replicas 1,8,64,512,1024 --modes batched,w1,w2,w3 --lanes 1,2 --seconds 0.5 --json $out/farm_window_speed.json > $out/farm_window_speed.txt 2>&1
   python tools/farm_window_speed.py --workload co2_gcmc --replicas 1,8,64,512,1024,4096 --modes batched,w1,w3 --lanes 1,2 --drivers 1,2 --threads 6 --seconds 0.4 > $out/farm_window_speed_co2.txt 2>&1
   python tools/recip_many_sites.py > $out/recip_many_sites.txt 2>&1
+  python tools/window_farm_stress.py --cases 400 --seed 11 > $out/window_farm_stress_full.txt 2>&1 || true
+  python tools/recip_forms_stress.py --cases 60 --seed 9 > $out/recip_forms_stress_full.txt 2>&1 || true
   MGPU_RECIP_NO_MFMA=1 python tools/recip_many_sites.py --sites 24 > $out/recip_many_sites_vector_form.txt 2>&1
   hipcc -O3 --offload-arch=gfx950 -o /tmp/probe_mfma_f64 tools/probe_mfma_f64.hip > /dev/null 2>&1 && /tmp/probe_mfma_f64 > $out/probe_mfma_f64.txt 2>&1 || true
   python tools/host_team_matrix.py > $out/host_team_matrix.txt 2>&1 || true
