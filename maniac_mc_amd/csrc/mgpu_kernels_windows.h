@@ -347,11 +347,21 @@ struct FarmArgs {
 };
 static_assert(sizeof(BoxDev) + sizeof(FarmArgs) + 160 <= 4096, "a farm window must fit the kernel-argument segment");
 
+// Diagnostic builds only (-DMGPU_FARM_STAMPS, tools/farm_stages.py; the shipped library has none of this): wall-clock stamps of
+// chain 0's k role (row 0), the launch's first pair workgroup (row 1) and chain 0's resolver (row 2).
+#ifdef MGPU_FARM_STAMPS
+static __device__ long long g_farm_stamps[3][8];
+#define MGPU_FSTAMP(cond, role, i) do { if (cond) g_farm_stamps[role][i] = wall_clock64(); } while (0)
+#else
+#define MGPU_FSTAMP(cond, role, i) do { } while (0)
+#endif
+
 // One chain resolved by ONE WAVE (all 64 lanes arrive): `scratch` = 4 nsplit + 4 doubles of LDS of its own.
 __device__ __forceinline__ void farm_resolve(const Topo &tp, const BoxDev &bx, double *__restrict__ pos, int *__restrict__ nmol,
                                              const FarmArgs &g, const FarmRec &rec, int c, int lane, double *scratch) {
     double *ho = g.host_out + (size_t)kFarmOut * c;
     int verdict;
+    MGPU_FSTAMP(c == 0 && lane == 0, 2, 0);
     // the roles sweep whatever the replica's stall flag says (they only read, and the k role's A + delta goes to the buffer
     // that is NOT current): the flag is looked at here, once, beside the partials -- not on every role's critical path
     const int waits = rec.forced == 0 && g.stalled[rec.replica] != 0;
@@ -375,6 +385,7 @@ __device__ __forceinline__ void farm_resolve(const Topo &tp, const BoxDev &bx, d
         if (lane < 3) scratch[np + lane] = load_sc1(reinterpret_cast<const double *>(g.res + c) + lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        MGPU_FSTAMP(c == 0 && lane == 0, 2, 1);
         double sum = 0.0;
         if (lane < 4) {
             const int ent = lane >> 1, comp = lane & 1;
@@ -405,6 +416,7 @@ __device__ __forceinline__ void farm_resolve(const Topo &tp, const BoxDev &bx, d
     // XCD's whole L2 -- every chain's freshly stored A + delta -- once per chain (measured: 256 chains per launch took as
     // long as 512, ~94 us, and two lanes' launches ran at half speed).  The block is fine-grained host memory: the stores
     // are system-scope write-through stores, the wave waits for them to be acknowledged, then stores the tag.
+    MGPU_FSTAMP(c == 0 && lane == 0, 2, 2);
     {
         double val = 0.0;
         if (lane < 5) val = o[lane];
@@ -413,6 +425,7 @@ __device__ __forceinline__ void farm_resolve(const Topo &tp, const BoxDev &bx, d
         if (lane < kFarmOut) __hip_atomic_store(ho + lane, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(g.host_tag + c, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        MGPU_FSTAMP(c == 0 && lane == 0, 2, 3);
     }
     // ---- the chain's device state: ticket, stall flag, and the accepted step itself
     if (lane == 0) {
@@ -453,6 +466,7 @@ __device__ __forceinline__ void farm_resolve(const Topo &tp, const BoxDev &bx, d
     }
     // A(k): the buffer the k role filled with A + delta becomes the replica's current one
     if (lane == 0) g.acur[rec.replica] ^= 1;
+    MGPU_FSTAMP(c == 0 && lane == 0, 2, 4);
 }
 
 // (launch bounds: four waves per SIMD = two of these 8-wave workgroups per CU, i.e. at most 128 VGPRs.  Left to itself
@@ -492,6 +506,8 @@ __global__ __launch_bounds__(kChainBlock, 4) void farm_window_kernel(
         w1 = min(w0 + kPairWaves, n * wpc);
         c_lo = w0 / wpc; n_c = (w1 - 1) / wpc - c_lo + 1;
     }
+    MGPU_FSTAMP(tid == 0 && blockIdx.x == 0, 1, 0);
+    MGPU_FSTAMP(tid == 0 && k_role && c_lo == 0, 0, 0);
     // ---- records: ten 8-byte words per chain from the kernel arguments (few chains) or from pinned host memory
     {
         const double *src = reinterpret_cast<const double *>((n <= kFarmInline ? g.inline_recs : g.recs) + c_lo);
@@ -523,6 +539,8 @@ __global__ __launch_bounds__(kChainBlock, 4) void farm_window_kernel(
     if (tid < n_c) s_skip[tid] = s_rec[tid].move == 0 ? 1 : 0;          // (a stalled replica is the resolver's business)
     if (k_role && tid == 0) s_acur = s_rec[0].move != 0 ? g.acur[s_rec[0].replica] : 0;
     __syncthreads();
+    MGPU_FSTAMP(tid == 0 && blockIdx.x == 0, 1, 1);
+    MGPU_FSTAMP(tid == 0 && k_role && c_lo == 0, 0, 1);
 
     if (k_role) {
         // ---------------- k role: chain c_lo
@@ -538,6 +556,7 @@ __global__ __launch_bounds__(kChainBlock, 4) void farm_window_kernel(
                 for (int d = 0; d < 3; ++d) s_cand[0][tid * 3 + d] = f.com[d] + off[d];
             }
             __syncthreads();                                           // (uniform: s_skip is the workgroup's)
+            MGPU_FSTAMP(tid == 0 && c == 0, 0, 2);
             double2 *A = (s_acur ? g.A_alt : A_base) + (size_t)rec.replica * bx.n_slots;
             double2 *A_other = (s_acur ? A_base : g.A_alt) + (size_t)rec.replica * bx.n_slots;
             RecipItem it{rec.replica, rec.t, kind == 1 ? -1 : rec.m, kind, 0, 0, 0};
@@ -547,7 +566,9 @@ __global__ __launch_bounds__(kChainBlock, 4) void farm_window_kernel(
             recip_rows_tables(tp, bx, pos, res_q, rows, n_rows, it, &s_cand[0][0], v, tid, active,
                               [&] { recip_rows_prefetch<false>(inflight, trj, tw, n_tasks, A, tid); });
             double acc = 0.0, acc0 = 0.0;
+            MGPU_FSTAMP(tid == 0 && c == 0, 0, 3);
             if (active) recip_rows_pass<false, true, kRecipTaskChunk, 1>(v, trj, tw, n_tasks, A, tid, inflight, acc, acc0, A_other);
+            MGPU_FSTAMP(tid == 0 && c == 0, 0, 4);
             if (tid == kBlock && kind != 0) {
                 // ComputeIntraResidueRealCoulombEnergySingleMol of the inserted (candidate row) / deleted (resident) molecule
                 const PairItem pit{rec.replica, rec.t, rec.m, kind == 1 ? 0 : -1, 0};
@@ -565,6 +586,7 @@ __global__ __launch_bounds__(kChainBlock, 4) void farm_window_kernel(
                 for (int wv = 0; wv < kWavesPerBlock; ++wv) { u += s_red[2 * wv]; u0 += s_red[2 * wv + 1]; }
                 __hip_atomic_store(&g.res[c].u_new, u * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ewald_energy.f90:272
                 __hip_atomic_store(&g.res[c].u_old, u0 * kEps0InvEvA / kKbEvK * kTwoPi / bx.volume, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                MGPU_FSTAMP(c == 0, 0, 5);
             }
         }
     } else {
@@ -609,6 +631,7 @@ __global__ __launch_bounds__(kChainBlock, 4) void farm_window_kernel(
 #undef MGPU_FARM_PAIR
             }
         }
+        MGPU_FSTAMP(tid == 0 && blockIdx.x == 0, 1, 2);
     }
 
     // ---------------- tickets: one counter per chain; the workgroup whose add completes a chain's count resolves it
@@ -616,6 +639,8 @@ __global__ __launch_bounds__(kChainBlock, 4) void farm_window_kernel(
     // resolving wave loads with `sc1` behind a second barrier that the adding wave joins)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    MGPU_FSTAMP(tid == 0 && blockIdx.x == 0, 1, 3);
+    MGPU_FSTAMP(tid == 0 && k_role && c_lo == 0, 0, 6);
     if (tid < n_c) {
         int count = 1;
         if (!k_role) {
@@ -625,6 +650,8 @@ __global__ __launch_bounds__(kChainBlock, 4) void farm_window_kernel(
         s_resolve[tid] = (atomicAdd(g.tickets + c_lo + tid, count) + count == expected) ? 1 : 0;
     }
     __syncthreads();
+    MGPU_FSTAMP(tid == 0 && blockIdx.x == 0, 1, 4);
+    MGPU_FSTAMP(tid == 0 && k_role && c_lo == 0, 0, 7);
     if (wave < n_c && s_resolve[wave]) {
         double *scratch = reinterpret_cast<double *>(s_dyn) + (size_t)wave * (4 * ns + 4);
         farm_resolve(tp, bx, pos, nmol, g, s_rec[wave], c_lo + wave, lane, scratch);

@@ -487,6 +487,18 @@ int mgpu_farm_window_wait(mgpu_engine *e, int lane, double *old_energy, double *
     return MGPU_OK;
 }
 
+#ifdef MGPU_FARM_STAMPS
+// diagnostic builds only (tools/farm_stages.py): the last window's stamps, 3 x 8 ticks of the 100 MHz wall clock
+int mgpu_farm_window_get_stamps(mgpu_engine *e, long long *out24) {
+    if (!e || !out24) return set_error(MGPU_ERR_INVALID_ARG, "farm_window_get_stamps: null argument");
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_farm_stamps), 24 * sizeof(long long)));
+    return MGPU_OK;
+}
+#endif
+
 int mgpu_farm_window_flush(mgpu_engine *e) {
     if (!e) return set_error(MGPU_ERR_INVALID_ARG, "null engine");
     int rc = use_device(e);
