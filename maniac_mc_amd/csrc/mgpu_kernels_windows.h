@@ -423,16 +423,21 @@ __device__ __forceinline__ void farm_resolve(const Topo &tp, const BoxDev &bx, d
         else if (lane < 10) val = w[lane - 5];
         else if (lane == 10) val = (double)verdict;
         if (lane < kFarmOut) __hip_atomic_store(ho + lane, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // (the tag follows BEHIND the commit: the eleven words cross PCIe while the accepted step is committed -- stage stamps, 8
+    //  chains: 0.9 us of acknowledgement and 1.4 us of commit were one after the other; the launch's end is what the next
+    //  window waits for, and the driver, with windows in flight, is not waiting for this tag)
+    auto publish_tag = [&] {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(g.host_tag + c, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         MGPU_FSTAMP(c == 0 && lane == 0, 2, 3);
-    }
+    };
     // ---- the chain's device state: ticket, stall flag, and the accepted step itself
     if (lane == 0) {
         __hip_atomic_store(g.tickets + c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (rec.move != 0 && (verdict == kFarmVerdictUndecided || rec.forced)) g.stalled[rec.replica] = verdict == kFarmVerdictUndecided ? 1 : 0;
     }
-    if (verdict != kFarmVerdictAccepted) return;
+    if (verdict != kFarmVerdictAccepted) { publish_tag(); return; }
     const int n1 = tp.n1[rec.t];
     double *px = pos + (size_t)rec.replica * 3 * tp.n_cap_atoms;
     double *py = px + tp.n_cap_atoms, *pz = py + tp.n_cap_atoms;
@@ -467,6 +472,7 @@ __device__ __forceinline__ void farm_resolve(const Topo &tp, const BoxDev &bx, d
     // A(k): the buffer the k role filled with A + delta becomes the replica's current one
     if (lane == 0) g.acur[rec.replica] ^= 1;
     MGPU_FSTAMP(c == 0 && lane == 0, 2, 4);
+    publish_tag();
 }
 
 // (launch bounds: four waves per SIMD = two of these 8-wave workgroups per CU, i.e. at most 128 VGPRs.  Left to itself

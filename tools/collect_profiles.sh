@@ -18,6 +18,7 @@ cp $src/bench_co2_isotherm_exchange_torch.json $dst/bench_co2_isotherm_exchange_
 for wl in spce_triclinic adsorbate24; do cp $src/bench_$wl.json $dst/bench_$wl.json; done
 cp $src/farm_window_speed.txt $dst/farm_window_speed.txt
 cp $src/recip_many_sites.txt $dst/recip_many_sites.txt
+cp $src/farm_stages.md $dst/farm_stages.md 2>/dev/null || true
 (head -3 $src/window_farm_stress_full.txt; echo "..."; tail -4 $src/window_farm_stress_full.txt) > $dst/window_farm_stress.txt 2>/dev/null || true
 (head -4 $src/recip_forms_stress_full.txt; echo "..."; grep "kmax (1[6-9]\|kmax (2" $src/recip_forms_stress_full.txt | head -4; tail -1 $src/recip_forms_stress_full.txt) > $dst/recip_forms_stress.txt 2>/dev/null || true
 cp $src/recip_many_sites_vector_form.txt $dst/recip_many_sites_vector_form.txt 2>/dev/null || true

@@ -35,6 +35,7 @@ if [ "$part" = 1 ]; then
   # round 5: the few-chain regime (one launch per lane step) against the batched path, and the many-site reciprocal kernels
   python tools/farm_window_speed.py --replicas 1,8,64,512,1024 --modes batched,w1,w2,w3 --lanes 1,2 --seconds 0.5 --json $out/farm_window_speed.json > $out/farm_window_speed.txt 2>&1
   python tools/farm_window_speed.py --workload co2_gcmc --replicas 1,8,64,512,1024,4096 --modes batched,w1,w3 --lanes 1,2 --drivers 1,2 --threads 6 --seconds 0.4 > $out/farm_window_speed_co2.txt 2>&1
+  python tools/farm_stages.py --chains 1,8,64,512 --windows 300 > $out/farm_stages.md 2>&1 || true
   python tools/recip_many_sites.py > $out/recip_many_sites.txt 2>&1
   python tools/window_farm_stress.py --cases 400 --seed 11 > $out/window_farm_stress_full.txt 2>&1 || true
   python tools/recip_forms_stress.py --cases 60 --seed 9 > $out/recip_forms_stress_full.txt 2>&1 || true
